@@ -1,0 +1,17 @@
+"""MI355X-native OETR overlap-estimation hot path.
+
+Drop-in for the inference half of TencentYoutuResearch/ImageMatching-OETR's
+``src/model.py``: same ``OETR`` constructor, checkpoint keys and
+``forward_dummy`` signature; the feature-correlation transformer and the
+centre/size regression heads run as hand-written HIP kernels for gfx950
+behind the C ABI in ``include/oetr_hip.h``.
+"""
+from .config import Cfg, get_cfg_defaults  # noqa: F401
+from .model import OETR, build_detectors  # noqa: F401
+from .hip_engine import (HotPathEngine, OetrError, box_tlbr_to_xyxy,  # noqa: F401
+                         full_attention, hot_path_keys, linear_attention,
+                         load_library)
+
+__all__ = ['Cfg', 'get_cfg_defaults', 'OETR', 'build_detectors',
+           'HotPathEngine', 'OetrError', 'box_tlbr_to_xyxy', 'full_attention',
+           'linear_attention', 'hot_path_keys', 'load_library']

@@ -1,0 +1,404 @@
+"""ctypes binding of ``liboetr_hip.so`` (C ABI: ``include/oetr_hip.h``).
+
+PyTorch is used here for device memory and the current HIP stream only; all
+arithmetic of the hot path happens inside the library.  Loading fails loudly:
+there is no fallback implementation.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / 'csrc' / 'liboetr_hip.so'
+
+N_ENC, N_DEC, D_MODEL, N_HEAD = 8, 2, 256, 8
+_f32p = C.POINTER(C.c_float)
+
+
+class _EncW(C.Structure):
+    _fields_ = [(n, _f32p) for n in (
+        'q_proj', 'k_proj', 'v_proj', 'merge', 'mlp0', 'mlp2',
+        'pre_norm_q_w', 'pre_norm_q_b', 'pre_norm_kv_w', 'pre_norm_kv_b',
+        'norm2_w', 'norm2_b')]
+
+
+class _MhaW(C.Structure):
+    _fields_ = [(n, _f32p) for n in (
+        'q_proj_w', 'q_proj_b', 'k_proj_w', 'k_proj_b', 'v_proj_w',
+        'v_proj_b', 'merge')]
+
+
+class _DecW(C.Structure):
+    _fields_ = [('self_attn', _MhaW), ('multihead_attn', _MhaW)] + [
+        (n, _f32p) for n in ('mlp0', 'mlp2', 'norm1_w', 'norm1_b', 'norm2_w',
+                             'norm2_b', 'norm3_w', 'norm3_b')]
+
+
+class _Weights(C.Structure):
+    _fields_ = [('struct_size', C.c_uint32), ('abi_version', C.c_uint32),
+                ('enc', _EncW * N_ENC), ('dec', _DecW * N_DEC)] + [
+        (n, _f32p) for n in ('query_embed1', 'query_embed2', 'tlbr0_w',
+                             'tlbr2_w', 'tlbr2_b', 'heat_conv_w',
+                             'heat_conv_b', 'heat_gn_w', 'heat_gn_b',
+                             'heat_out_w', 'heat_out_b')]
+
+
+class _Stages(C.Structure):
+    _fields_ = [('struct_size', C.c_uint32), ('enc_layers', C.c_int32)] + [
+        (n, C.c_void_p) for n in ('hs1', 'hs2', 'memory1', 'memory2',
+                                  'logits1', 'logits2', 'cxy1', 'cxy2',
+                                  'tlbr1', 'tlbr2')]
+
+
+ABI_VERSION = 1
+EXPORTS = (
+    'oetr_last_error', 'oetr_abi_version', 'oetr_create', 'oetr_destroy',
+    'oetr_workspace_bytes', 'oetr_forward', 'oetr_forward_stages',
+    'oetr_feature_correlation', 'oetr_center_estimation',
+    'oetr_size_regression', 'oetr_box_tlbr_to_xyxy', 'oetr_linear_attention',
+    'oetr_full_attention')
+
+
+def hot_path_keys():
+    """State-dict keys (reference checkpoint names) the library consumes."""
+    keys = []
+    for i in range(N_ENC):
+        p = f'transformer.encoder.{i}.'
+        keys += [p + s for s in (
+            'q_proj.weight', 'k_proj.weight', 'v_proj.weight', 'merge.weight',
+            'mlp.0.weight', 'mlp.2.weight', 'pre_norm_q.weight',
+            'pre_norm_q.bias', 'pre_norm_kv.weight', 'pre_norm_kv.bias',
+            'norm2.weight', 'norm2.bias')]
+    for i in range(N_DEC):
+        p = f'transformer.decoder.layers.{i}.'
+        for a in ('self_attn', 'multihead_attn'):
+            keys += [p + f'{a}.{s}' for s in (
+                'q_proj.weight', 'q_proj.bias', 'k_proj.weight', 'k_proj.bias',
+                'v_proj.weight', 'v_proj.bias', 'merge.weight')]
+        keys += [p + s for s in (
+            'mlp.0.weight', 'mlp.2.weight', 'norm1.weight', 'norm1.bias',
+            'norm2.weight', 'norm2.bias', 'norm3.weight', 'norm3.bias')]
+    keys += ['query_embed1.weight', 'query_embed2.weight', 'tlbr_reg.0.weight',
+             'tlbr_reg.2.weight', 'tlbr_reg.2.bias', 'heatmap_conv.0.weight',
+             'heatmap_conv.0.bias', 'heatmap_conv.1.weight',
+             'heatmap_conv.1.bias', 'heatmap_conv.3.weight',
+             'heatmap_conv.3.bias']
+    return keys
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library and declare signatures.  Raises if missing.
+
+    torch is imported first on purpose: its bundled libamdhip64.so.7 is then
+    the HIP runtime the library binds to, so device pointers and streams are
+    shared with torch."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path or os.environ.get('OETR_HIP_LIB', LIB_PATH))
+    if not p.exists():
+        raise RuntimeError(
+            f'{p} not found: build it with `python -c "import __graft_entry__ '
+            f'as g; g.build()"` or `make -C {_PKG_DIR / "csrc"}`. The OETR hot '
+            'path has no non-HIP fallback.')
+    lib = C.CDLL(str(p))
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.oetr_last_error.restype = C.c_char_p
+    lib.oetr_last_error.argtypes = []
+    lib.oetr_abi_version.restype = i
+    lib.oetr_abi_version.argtypes = []
+    lib.oetr_create.restype = i
+    lib.oetr_create.argtypes = [C.POINTER(_Weights), i, i, C.POINTER(vp)]
+    lib.oetr_destroy.restype = None
+    lib.oetr_destroy.argtypes = [vp]
+    lib.oetr_workspace_bytes.restype = sz
+    lib.oetr_workspace_bytes.argtypes = [vp, i, i, i, i, i]
+    fwd = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, sz, vp, vp]
+    lib.oetr_forward.restype = i
+    lib.oetr_forward.argtypes = fwd + [vp]
+    lib.oetr_forward_stages.restype = i
+    lib.oetr_forward_stages.argtypes = fwd + [C.POINTER(_Stages), vp]
+    lib.oetr_feature_correlation.restype = i
+    lib.oetr_feature_correlation.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i,
+                                             vp, sz, vp, vp, vp, vp, vp]
+    lib.oetr_center_estimation.restype = i
+    lib.oetr_center_estimation.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i,
+                                           i, i, vp, sz, vp, vp, vp]
+    lib.oetr_size_regression.restype = i
+    lib.oetr_size_regression.argtypes = [vp, vp, vp, i, vp, vp, vp]
+    lib.oetr_box_tlbr_to_xyxy.restype = i
+    lib.oetr_box_tlbr_to_xyxy.argtypes = [vp, vp, i, i, i, vp, vp]
+    for name in ('oetr_linear_attention', 'oetr_full_attention'):
+        fn = getattr(lib, name)
+        fn.restype = i
+        fn.argtypes = [vp, vp, vp, i, i, i, vp, vp]
+    if lib.oetr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'{p}: ABI version {lib.oetr_abi_version()} != '
+                           f'{ABI_VERSION}')
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class OetrError(RuntimeError):
+    pass
+
+
+def _check(lib, status, what):
+    if status != 0:
+        msg = lib.oetr_last_error().decode(errors='replace')
+        exc = ValueError if status in (1, 2) else OetrError
+        raise exc(f'{what} failed (status {status}): {msg}')
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name):
+    if not t.is_cuda:
+        raise OetrError(f'{name} must be a GPU tensor (got {t.device}); the '
+                        'OETR hot path has no CPU implementation')
+    if t.dtype != torch.float32:
+        raise ValueError(f'{name} must be float32 (got {t.dtype})')
+    return t.contiguous()
+
+
+class HotPathEngine:
+    """Owns one ``oetr_handle`` (repacked weights on one GPU) and a growable
+    workspace tensor."""
+
+    def __init__(self, weights, device=None):
+        self.lib = load_library()
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise OetrError('HotPathEngine needs a GPU device')
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = device
+        missing = [k for k in hot_path_keys() if k not in weights]
+        if missing:
+            raise KeyError(f'missing hot-path weights: {missing[:4]}...')
+        host = {k: weights[k].detach().to('cpu', torch.float32).contiguous()
+                for k in hot_path_keys()}
+        w = _Weights()
+        w.struct_size = C.sizeof(_Weights)
+        w.abi_version = ABI_VERSION
+
+        def ptr(key):
+            return C.cast(host[key].data_ptr(), _f32p)
+
+        for li in range(N_ENC):
+            p, e = f'transformer.encoder.{li}.', w.enc[li]
+            e.q_proj, e.k_proj = ptr(p + 'q_proj.weight'), ptr(p + 'k_proj.weight')
+            e.v_proj, e.merge = ptr(p + 'v_proj.weight'), ptr(p + 'merge.weight')
+            e.mlp0, e.mlp2 = ptr(p + 'mlp.0.weight'), ptr(p + 'mlp.2.weight')
+            e.pre_norm_q_w = ptr(p + 'pre_norm_q.weight')
+            e.pre_norm_q_b = ptr(p + 'pre_norm_q.bias')
+            e.pre_norm_kv_w = ptr(p + 'pre_norm_kv.weight')
+            e.pre_norm_kv_b = ptr(p + 'pre_norm_kv.bias')
+            e.norm2_w, e.norm2_b = ptr(p + 'norm2.weight'), ptr(p + 'norm2.bias')
+        for li in range(N_DEC):
+            p, d = f'transformer.decoder.layers.{li}.', w.dec[li]
+            for attr in ('self_attn', 'multihead_attn'):
+                m = getattr(d, attr)
+                q = p + attr + '.'
+                m.q_proj_w, m.q_proj_b = ptr(q + 'q_proj.weight'), ptr(q + 'q_proj.bias')
+                m.k_proj_w, m.k_proj_b = ptr(q + 'k_proj.weight'), ptr(q + 'k_proj.bias')
+                m.v_proj_w, m.v_proj_b = ptr(q + 'v_proj.weight'), ptr(q + 'v_proj.bias')
+                m.merge = ptr(q + 'merge.weight')
+            d.mlp0, d.mlp2 = ptr(p + 'mlp.0.weight'), ptr(p + 'mlp.2.weight')
+            for nn_ in ('norm1', 'norm2', 'norm3'):
+                setattr(d, nn_ + '_w', ptr(p + nn_ + '.weight'))
+                setattr(d, nn_ + '_b', ptr(p + nn_ + '.bias'))
+        w.query_embed1 = ptr('query_embed1.weight')
+        w.query_embed2 = ptr('query_embed2.weight')
+        w.tlbr0_w = ptr('tlbr_reg.0.weight')
+        w.tlbr2_w, w.tlbr2_b = ptr('tlbr_reg.2.weight'), ptr('tlbr_reg.2.bias')
+        w.heat_conv_w = ptr('heatmap_conv.0.weight')
+        w.heat_conv_b = ptr('heatmap_conv.0.bias')
+        w.heat_gn_w, w.heat_gn_b = ptr('heatmap_conv.1.weight'), ptr('heatmap_conv.1.bias')
+        w.heat_out_w, w.heat_out_b = ptr('heatmap_conv.3.weight'), ptr('heatmap_conv.3.bias')
+
+        handle = C.c_void_p()
+        _check(self.lib, self.lib.oetr_create(C.byref(w), 0, device.index,
+                                              C.byref(handle)), 'oetr_create')
+        self._h = handle
+        self._ws = None
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                self.lib.oetr_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------ helpers
+    def workspace(self, n, hf1, wf1, hf2, wf2):
+        need = self.lib.oetr_workspace_bytes(self._h, n, hf1, wf1, hf2, wf2)
+        if need == 0:
+            raise ValueError(
+                f'invalid shape N={n} grids {hf1}x{wf1}, {hf2}x{wf2}: '
+                + self.lib.oetr_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @staticmethod
+    def _grid(feat, pos, name):
+        if feat.dim() != 4 or feat.shape[1] != D_MODEL:
+            raise ValueError(f'{name} must be [N,{D_MODEL},hf,wf], got '
+                             f'{tuple(feat.shape)}')
+        hf, wf = int(feat.shape[2]), int(feat.shape[3])
+        if tuple(pos.shape[-3:]) != (D_MODEL, hf, wf) or pos.numel() != D_MODEL * hf * wf:
+            raise ValueError(f'pos for {name} must be [1,{D_MODEL},{hf},{wf}], '
+                             f'got {tuple(pos.shape)}')
+        return hf, wf
+
+    # -------------------------------------------------------------- calls
+    def forward(self, feat1, feat2, pos1, pos2, img_hw1, img_hw2, stages=None,
+                enc_layers=N_ENC):
+        """feats [N,256,hf,wf] + pos [1,256,hf,wf] -> (box1, box2) [N,4].
+        With ``stages=True`` returns a dict of intermediates as well."""
+        feat1, feat2 = _dev(feat1, 'feat1'), _dev(feat2, 'feat2')
+        pos1, pos2 = _dev(pos1, 'pos1'), _dev(pos2, 'pos2')
+        n = int(feat1.shape[0])
+        if feat2.shape[0] != n:
+            raise ValueError('feat1/feat2 batch sizes differ')
+        hf1, wf1 = self._grid(feat1, pos1, 'feat1')
+        hf2, wf2 = self._grid(feat2, pos2, 'feat2')
+        ws = self.workspace(n, hf1, wf1, hf2, wf2)
+        dev = self.device
+        box1 = torch.empty(n, 4, device=dev)
+        box2 = torch.empty(n, 4, device=dev)
+        args = [self._h, feat1.data_ptr(), feat2.data_ptr(), pos1.data_ptr(),
+                pos2.data_ptr(), n, hf1, wf1, hf2, wf2, int(img_hw1[0]),
+                int(img_hw1[1]), int(img_hw2[0]), int(img_hw2[1]),
+                ws.data_ptr(), ws.numel(), box1.data_ptr(), box2.data_ptr()]
+        with torch.cuda.device(dev):
+            if not stages:
+                _check(self.lib, self.lib.oetr_forward(*args, _stream()),
+                       'oetr_forward')
+                return box1, box2
+            L1, L2 = hf1 * wf1, hf2 * wf2
+            out = dict(
+                hs1=torch.empty(n, 1, D_MODEL, device=dev),
+                hs2=torch.empty(n, 1, D_MODEL, device=dev),
+                memory1=torch.empty(n, L1, D_MODEL, device=dev),
+                memory2=torch.empty(n, L2, D_MODEL, device=dev),
+                logits1=torch.empty(n, L1, device=dev),
+                logits2=torch.empty(n, L2, device=dev),
+                cxy1=torch.empty(n, 2, device=dev),
+                cxy2=torch.empty(n, 2, device=dev),
+                tlbr1=torch.empty(n, 4, device=dev),
+                tlbr2=torch.empty(n, 4, device=dev))
+            st = _Stages()
+            st.struct_size = C.sizeof(_Stages)
+            st.enc_layers = int(enc_layers)
+            for k, t in out.items():
+                setattr(st, k, t.data_ptr())
+            _check(self.lib, self.lib.oetr_forward_stages(
+                *args, C.byref(st), _stream()), 'oetr_forward_stages')
+            out['box1'], out['box2'] = box1, box2
+            if enc_layers < N_ENC:
+                out = {k: out[k] for k in ('memory1', 'memory2')}
+            return out
+
+    def feature_correlation(self, feat1, feat2, pos1, pos2):
+        feat1, feat2 = _dev(feat1, 'feat1'), _dev(feat2, 'feat2')
+        pos1, pos2 = _dev(pos1, 'pos1'), _dev(pos2, 'pos2')
+        n = int(feat1.shape[0])
+        hf1, wf1 = self._grid(feat1, pos1, 'feat1')
+        hf2, wf2 = self._grid(feat2, pos2, 'feat2')
+        ws = self.workspace(n, hf1, wf1, hf2, wf2)
+        dev = self.device
+        hs1 = torch.empty(n, 1, D_MODEL, device=dev)
+        hs2 = torch.empty(n, 1, D_MODEL, device=dev)
+        m1 = torch.empty(n, hf1 * wf1, D_MODEL, device=dev)
+        m2 = torch.empty(n, hf2 * wf2, D_MODEL, device=dev)
+        with torch.cuda.device(dev):
+            _check(self.lib, self.lib.oetr_feature_correlation(
+                self._h, feat1.data_ptr(), feat2.data_ptr(), pos1.data_ptr(),
+                pos2.data_ptr(), n, hf1, wf1, hf2, wf2, ws.data_ptr(),
+                ws.numel(), hs1.data_ptr(), hs2.data_ptr(), m1.data_ptr(),
+                m2.data_ptr(), _stream()), 'oetr_feature_correlation')
+        return hs1, hs2, m1, m2
+
+    def center_estimation(self, hs1, hs2, memory1, memory2, hf1, wf1, hf2, wf2,
+                          img_h1, img_h2):
+        hs1, hs2 = _dev(hs1, 'hs1'), _dev(hs2, 'hs2')
+        memory1, memory2 = _dev(memory1, 'memory1'), _dev(memory2, 'memory2')
+        n = int(hs1.shape[0])
+        if memory1.shape != (n, hf1 * wf1, D_MODEL) or \
+                memory2.shape != (n, hf2 * wf2, D_MODEL):
+            raise ValueError('memory shapes do not match the token grids')
+        ws = self.workspace(n, hf1, wf1, hf2, wf2)
+        c1 = torch.empty(n, 2, device=self.device)
+        c2 = torch.empty(n, 2, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.oetr_center_estimation(
+                self._h, hs1.data_ptr(), hs2.data_ptr(), memory1.data_ptr(),
+                memory2.data_ptr(), n, hf1, wf1, hf2, wf2, int(img_h1),
+                int(img_h2), ws.data_ptr(), ws.numel(), c1.data_ptr(),
+                c2.data_ptr(), _stream()), 'oetr_center_estimation')
+        return c1, c2
+
+    def size_regression(self, hs1, hs2):
+        hs1, hs2 = _dev(hs1, 'hs1'), _dev(hs2, 'hs2')
+        n = int(hs1.shape[0])
+        t1 = torch.empty(n, 4, device=self.device)
+        t2 = torch.empty(n, 4, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.oetr_size_regression(
+                self._h, hs1.data_ptr(), hs2.data_ptr(), n, t1.data_ptr(),
+                t2.data_ptr(), _stream()), 'oetr_size_regression')
+        return t1, t2
+
+
+def box_tlbr_to_xyxy(cxy, tlbr, max_h, max_w):
+    """HIP version of reference ``src/models/utils.py:16-28``."""
+    lib = load_library()
+    cxy, tlbr = _dev(cxy, 'cxy'), _dev(tlbr, 'tlbr')
+    n = int(cxy.shape[0])
+    box = torch.empty(n, 4, device=cxy.device)
+    with torch.cuda.device(cxy.device):
+        _check(lib, lib.oetr_box_tlbr_to_xyxy(
+            cxy.data_ptr(), tlbr.data_ptr(), n, int(max_h), int(max_w),
+            box.data_ptr(), _stream()), 'oetr_box_tlbr_to_xyxy')
+    return box
+
+
+def _attention(fn_name, q, k, v):
+    lib = load_library()
+    q, k, v = _dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v')
+    n, L, h, d = q.shape
+    S = int(k.shape[1])
+    if (h, d) != (N_HEAD, D_MODEL // N_HEAD) or k.shape != (n, S, h, d) \
+            or v.shape != k.shape:
+        raise ValueError('attention expects q [N,L,8,32], k,v [N,S,8,32]')
+    out = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        _check(lib, getattr(lib, fn_name)(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), n, L, S, out.data_ptr(),
+            _stream()), fn_name)
+    return out
+
+
+def linear_attention(q, k, v):
+    """HIP version of reference ``LinearAttention.forward``
+    (``src/models/linear_attention.py:22-50``)."""
+    return _attention('oetr_linear_attention', q, k, v)
+
+
+def full_attention(q, k, v):
+    """HIP version of reference ``FullAttention.forward``
+    (``src/models/linear_attention.py:53-87``)."""
+    return _attention('oetr_full_attention', q, k, v)

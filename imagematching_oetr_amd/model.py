@@ -1,0 +1,202 @@
+"""Drop-in ``OETR`` module: reference constructor, state-dict keys and
+``forward_dummy(image1, image2, mask1=None, mask2=None)`` signature, with the
+feature-correlation transformer and the regression heads executed by the
+hand-written HIP library (``csrc/`` -> ``liboetr_hip.so``).
+
+Mirrors reference ``src/model.py:38-252`` (inference half) and
+``build_detectors`` (:380-384).  Only ``feature_extraction`` runs as torch ops
+(host code, MIOpen); everything from ``feature_correlation`` to the final
+boxes goes through the C ABI declared in ``include/oetr_hip.h``.  There is no
+CPU or eager fallback for that part: if the extension is missing or the
+tensors are not on a GPU the call raises.
+
+The hot-path sub-modules below are *parameter containers*: they exist so that
+``state_dict()``/``load_state_dict(strict=True)`` match a reference checkpoint
+key for key and so that random init follows the reference's
+(Xavier-uniform on the transformer matrices, ``transformer.py:308-311``).
+Their ``forward`` is never called.
+"""
+import torch
+import torch.nn as nn
+
+from .backbone import PatchMerging, PositionEncodingSine, ResnetEncoder
+from .hip_engine import HotPathEngine, hot_path_keys
+
+
+class _EncoderLayerParams(nn.Module):
+    # reference transformer.py:76-102
+    def __init__(self, d):
+        super().__init__()
+        self.q_proj = nn.Linear(d, d, bias=False)
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d, bias=False)
+        self.merge = nn.Linear(d, d, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(d, 2 * d, bias=False), nn.GELU(),
+                                 nn.Linear(2 * d, d, bias=False))
+        self.pre_norm_q = nn.LayerNorm(d)
+        self.pre_norm_kv = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+
+
+class _MultiHeadAttentionParams(nn.Module):
+    # reference transformer.py:46-53
+    def __init__(self, d):
+        super().__init__()
+        self.q_proj = nn.Linear(d, d)
+        self.k_proj = nn.Linear(d, d)
+        self.v_proj = nn.Linear(d, d)
+        self.merge = nn.Linear(d, d, bias=False)
+
+
+class _DecoderLayerParams(nn.Module):
+    # reference transformer.py:190-222; q/k/v_proj and merge at this level are
+    # parameters the reference registers but never uses.
+    def __init__(self, d):
+        super().__init__()
+        self.q_proj = nn.Linear(d, d, bias=False)
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d, bias=False)
+        self.self_attn = _MultiHeadAttentionParams(d)
+        self.multihead_attn = _MultiHeadAttentionParams(d)
+        self.merge = nn.Linear(d, d, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(d, 2 * d, bias=False),
+                                 nn.ReLU(True),
+                                 nn.Linear(2 * d, d, bias=False))
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+        self.norm3 = nn.LayerNorm(d)
+
+
+class _DecoderParams(nn.Module):
+    def __init__(self, d, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(
+            [_DecoderLayerParams(d) for _ in range(num_layers)])
+
+
+class _QueryTransformerParams(nn.Module):
+    # reference transformer.py:287-311 (nhead=8, 4x(self,cross), 2 decoder layers)
+    def __init__(self, d, nhead=8, num_layers=4):
+        super().__init__()
+        self.nhead = nhead
+        self.encoder = nn.ModuleList(
+            [_EncoderLayerParams(d) for _ in range(2 * num_layers)])
+        self.decoder = _DecoderParams(d, 2)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class OETR(nn.Module):
+    """OETR overlap estimator with the MI355X-native hot path."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = ResnetEncoder(cfg)
+        self.d_model = self.backbone.last_layer // 4
+        d = self.d_model
+        self.input_proj = nn.Conv2d(self.backbone.last_layer, d, kernel_size=1)
+        self.input_proj2 = nn.Conv2d(2 * d, d, kernel_size=1)
+        self.patchmerging = PatchMerging((20, 20), d, norm_layer=nn.LayerNorm,
+                                         patch_size=[4, 8, 16])
+        self.tlbr_reg = nn.Sequential(nn.Linear(d, d, False),
+                                      nn.ReLU(inplace=True), nn.Linear(d, 4))
+        self.heatmap_conv = nn.Sequential(
+            nn.Conv2d(d, d, (3, 3), padding=(1, 1), stride=(1, 1), bias=True),
+            nn.GroupNorm(32, d), nn.ReLU(inplace=True),
+            nn.Conv2d(d, 1, (1, 1)))
+        self.query_embed1 = nn.Embedding(1, d)
+        self.query_embed2 = nn.Embedding(1, d)
+        self.transformer = _QueryTransformerParams(d, nhead=8, num_layers=4)
+        self.pos_encoding = PositionEncodingSine(d, max_shape=cfg.NECK.MAX_SHAPE)
+        self.max_shape = cfg.NECK.MAX_SHAPE
+        self.cycle = cfg.LOSS.CYCLE_OVERLAP
+        self.softmax_temperature = 1
+        self._engine = None
+        self._engine_key = None
+
+    # ---------------------------------------------------------------- host
+    def feature_extraction(self, image1, image2, mask1=None, mask2=None):
+        """Reference ``src/model.py:109-130`` (torch ops, any device)."""
+        feats = []
+        for img in (image1, image2):
+            f = self.input_proj(self.backbone(img))
+            feats.append(self.input_proj2(self.patchmerging(f)))
+        feat1, feat2 = feats
+        hf1, wf1 = feat1.shape[2:]
+        hf2, wf2 = feat2.shape[2:]
+        return (feat1, feat2, self.pos_encoding(feat1), self.pos_encoding(feat2),
+                hf1, wf1, hf2, wf2)
+
+    # -------------------------------------------------------------- engine
+    def hot_path_state(self):
+        sd = self.state_dict()
+        return {k: sd[k] for k in hot_path_keys()}
+
+    def engine(self):
+        """HIP engine bound to the current hot-path weights; rebuilt when a
+        weight tensor was replaced or written in place."""
+        params = [self.get_parameter(k) for k in hot_path_keys()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._engine is None or key != self._engine_key:
+            dev = params[0].device
+            if dev.type != 'cuda':
+                raise RuntimeError(
+                    'OETR hot path needs the model on a GPU (HIP) device; '
+                    f'weights are on {dev}. There is no CPU implementation.')
+            self._engine = HotPathEngine(self.hot_path_state(), device=dev)
+            self._engine_key = key
+        return self._engine
+
+    @staticmethod
+    def _no_masks(mask1, mask2):
+        if mask1 is not None or mask2 is not None:
+            raise NotImplementedError(
+                'masks are unreachable in the reference pipeline (SURVEY.md '
+                '§3.2) and not implemented by the HIP path')
+
+    # ---------------------------------------------- reference inner seams
+    def feature_correlation(self, feat1, feat2, pos1, pos2, mask1=None,
+                            mask2=None):
+        """Reference ``src/model.py:132-143``: -> hs1, hs2 [N,1,C],
+        memory1 [N,L1,C], memory2 [N,L2,C]."""
+        self._no_masks(mask1, mask2)
+        return self.engine().feature_correlation(feat1, feat2, pos1, pos2)
+
+    def center_estimation(self, hs1, hs2, memory1, memory2, hf1, wf1, hf2,
+                          wf2, mask1=None, mask2=None):
+        """Reference ``src/model.py:145-186``; image heights come from the
+        last ``forward_dummy`` call (``self.h1``/``self.h2``) as there."""
+        self._no_masks(mask1, mask2)
+        return self.engine().center_estimation(hs1, hs2, memory1, memory2, hf1,
+                                               wf1, hf2, wf2, self.h1, self.h2)
+
+    def size_regression(self, hs1, hs2):
+        """Reference ``src/model.py:188-191``."""
+        return self.engine().size_regression(hs1, hs2)
+
+    # ------------------------------------------------------------ inference
+    @torch.no_grad()
+    def forward_dummy(self, image1, image2, mask1=None, mask2=None):
+        """Reference ``src/model.py:229-252``: images [N,H,W,3] in [0,1] ->
+        (box1, box2), each [N,4] xyxy pixels."""
+        self._no_masks(mask1, mask2)
+        h1, w1 = image1.shape[1:3]
+        h2, w2 = image2.shape[1:3]
+        self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
+        feat1, feat2, pos1, pos2, _, _, _, _ = self.feature_extraction(
+            image1, image2)
+        return self.engine().forward(feat1, feat2, pos1, pos2, (h1, w1),
+                                     (h2, w2))
+
+    def forward(self, data, validation=False):
+        raise NotImplementedError(
+            'training forward (losses/autograd, reference src/model.py:255-376)'
+            ' is out of scope for the HIP path; use forward_dummy')
+
+
+def build_detectors(cfg):
+    """Reference ``src/model.py:380-384``."""
+    if cfg.MODEL == 'oetr':
+        return OETR(cfg)
+    raise ValueError(f'OETR.MODEL {cfg.MODEL} not supported.')

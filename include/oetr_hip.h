@@ -1,0 +1,203 @@
+/*
+ * liboetr_hip.so - C ABI of the MI355X (gfx950) OETR hot path.
+ *
+ * The reference (TencentYoutuResearch/ImageMatching-OETR) is pure Python and
+ * has no FFI of its own; the seams this library replaces are the Python
+ * methods of `OETR` in the reference's src/model.py.  Each entry point below
+ * names the reference interface it stands in for (file:line relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds
+ * on the reference side.
+ *
+ * Conventions
+ *  - every tensor is fp32, contiguous, DEVICE memory unless marked host;
+ *  - caller owns inputs, outputs and the workspace; the library owns only its
+ *    repacked copy of the weights (created by oetr_create);
+ *  - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*): no
+ *    allocation, no synchronisation, so a call sequence is hipGraph-capturable;
+ *  - a handle is immutable after creation: concurrent calls with distinct
+ *    workspaces are safe;
+ *  - every function returns an oetr_status; oetr_last_error() gives the text
+ *    for the calling thread.  Nothing throws.
+ *  - `N` is the number of image PAIRS; side 1 has token grid hf1 x wf1
+ *    (L1 = hf1*wf1 tokens), side 2 hf2 x wf2.  C = 256 channels, 8 heads.
+ */
+#ifndef OETR_HIP_H_
+#define OETR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OETR_ABI_VERSION 1
+#define OETR_D_MODEL 256
+#define OETR_N_HEAD 8
+#define OETR_N_ENC 8 /* self,cross x4  - reference src/models/transformer.py:295 */
+#define OETR_N_DEC 2 /* reference src/models/transformer.py:304 */
+#define OETR_MAX_TOKENS 10000 /* NECK.MAX_SHAPE 100x100, reference src/config/default.py:25-28 */
+
+typedef enum {
+  OETR_OK = 0,
+  OETR_ERR_BAD_ARG = 1,      /* null pointer, N<=0, bad struct size        */
+  OETR_ERR_BAD_SHAPE = 2,    /* token grid empty or > OETR_MAX_TOKENS      */
+  OETR_ERR_UNSUPPORTED = 3,  /* dtype / masks / attention mode not built   */
+  OETR_ERR_WORKSPACE = 4,    /* workspace too small or misaligned          */
+  OETR_ERR_HIP = 5,          /* a HIP runtime call failed                  */
+  OETR_ERR_NO_DEVICE = 6     /* no gfx950 device visible                   */
+} oetr_status;
+
+typedef enum { OETR_DTYPE_F32 = 0 } oetr_dtype;
+
+/* Encoder layer i - reference src/models/transformer.py:83-102.
+ * Linear weights are torch layout [out][in], row-major. */
+typedef struct {
+  const float *q_proj, *k_proj, *v_proj, *merge; /* [256][256], no bias */
+  const float *mlp0;                             /* [512][256] */
+  const float *mlp2;                             /* [256][512] */
+  const float *pre_norm_q_w, *pre_norm_q_b;      /* [256] */
+  const float *pre_norm_kv_w, *pre_norm_kv_b;    /* [256] */
+  const float *norm2_w, *norm2_b;                /* [256] */
+} oetr_encoder_layer_weights;
+
+/* MultiHeadAttention - reference src/models/transformer.py:46-53 */
+typedef struct {
+  const float *q_proj_w, *q_proj_b; /* [256][256], [256] */
+  const float *k_proj_w, *k_proj_b;
+  const float *v_proj_w, *v_proj_b;
+  const float *merge;               /* [256][256], no bias */
+} oetr_mha_weights;
+
+/* DecoderLayer - reference src/models/transformer.py:190-222 (live params) */
+typedef struct {
+  oetr_mha_weights self_attn, multihead_attn;
+  const float *mlp0; /* [512][256] */
+  const float *mlp2; /* [256][512] */
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
+} oetr_decoder_layer_weights;
+
+/* All HOST pointers; copied and repacked by oetr_create. */
+typedef struct {
+  uint32_t struct_size; /* = sizeof(oetr_weights) */
+  uint32_t abi_version; /* = OETR_ABI_VERSION */
+  oetr_encoder_layer_weights enc[OETR_N_ENC];
+  oetr_decoder_layer_weights dec[OETR_N_DEC];
+  const float *query_embed1, *query_embed2;   /* [256]   model.py:80-81 */
+  const float *tlbr0_w;                       /* [256][256] model.py:60 */
+  const float *tlbr2_w, *tlbr2_b;             /* [4][256],[4] model.py:62 */
+  const float *heat_conv_w, *heat_conv_b;     /* [256][256][3][3],[256] model.py:66-73 */
+  const float *heat_gn_w, *heat_gn_b;         /* [256] GroupNorm(32) model.py:74 */
+  const float *heat_out_w, *heat_out_b;       /* [256] (1x1 conv), [1] model.py:76 */
+} oetr_weights;
+
+typedef struct oetr_ctx *oetr_handle;
+
+/* Optional intermediate outputs (device pointers, any may be NULL).
+ * Used by parity tests to pin tensors the boxes alone do not constrain. */
+typedef struct {
+  uint32_t struct_size;     /* = sizeof(oetr_stage_outputs) */
+  int32_t enc_layers;       /* encoder layers to run, 1..8; <8 stops after the
+                               encoder (only memory1/2 are produced) */
+  float *hs1, *hs2;         /* [N][256]        decoder outputs           */
+  float *memory1, *memory2; /* [N][L][256]     encoder outputs           */
+  float *logits1, *logits2; /* [N][L]          heat-map logits           */
+  float *cxy1, *cxy2;       /* [N][2]          soft-argmax centres (x,y) */
+  float *tlbr1, *tlbr2;     /* [N][4]          sigmoid extents           */
+} oetr_stage_outputs;
+
+/* Text of the last error on this thread ("" if none). */
+const char *oetr_last_error(void);
+
+/* ABI version the library was built with. */
+int oetr_abi_version(void);
+
+/* Replaces: OETR.__init__ + load_state_dict for the hot-path modules
+ * (reference src/model.py:58-84, dloc/core/overlaps/oetr.py:36-42).
+ * Copies the weights to `device`, repacked into MFMA fragment order. */
+oetr_status oetr_create(const oetr_weights *w, oetr_dtype dtype, int device,
+                        oetr_handle *out);
+void oetr_destroy(oetr_handle h);
+
+/* Bytes of workspace a forward call needs for this shape (256-B aligned
+ * device buffer).  Returns 0 on invalid shape. */
+size_t oetr_workspace_bytes(oetr_handle h, int n_pairs, int hf1, int wf1,
+                            int hf2, int wf2);
+
+/* Replaces: everything OETR.forward_dummy does after feature_extraction
+ * (reference src/model.py:239-252): feature_correlation, center_estimation,
+ * size_regression, box_tlbr_to_xyxy.
+ *   feat1/feat2 [N][256][hf][wf] (NCHW, what input_proj2 emits)
+ *   pos1/pos2   [256][hf][wf]    (batch-broadcast sine table window)
+ *   img_h/img_w image sizes in pixels (the reference's mutable self.h1..w2)
+ *   box1/box2   [N][4] xyxy pixels (out)                                   */
+oetr_status oetr_forward(oetr_handle h, const float *feat1, const float *feat2,
+                         const float *pos1, const float *pos2, int n_pairs,
+                         int hf1, int wf1, int hf2, int wf2, int img_h1,
+                         int img_w1, int img_h2, int img_w2, void *workspace,
+                         size_t workspace_bytes, float *box1, float *box2,
+                         void *stream);
+
+/* Same as oetr_forward, additionally exporting intermediates. box1/box2 may
+ * be NULL when stages->enc_layers < 8. */
+oetr_status oetr_forward_stages(oetr_handle h, const float *feat1,
+                                const float *feat2, const float *pos1,
+                                const float *pos2, int n_pairs, int hf1,
+                                int wf1, int hf2, int wf2, int img_h1,
+                                int img_w1, int img_h2, int img_w2,
+                                void *workspace, size_t workspace_bytes,
+                                float *box1, float *box2,
+                                const oetr_stage_outputs *stages, void *stream);
+
+/* Replaces: OETR.feature_correlation (reference src/model.py:132-143 ->
+ * QueryTransformer.forward, src/models/transformer.py:313-383), masks None.
+ * Out: hs1,hs2 [N][256]; memory1 [N][L1][256]; memory2 [N][L2][256]. */
+oetr_status oetr_feature_correlation(oetr_handle h, const float *feat1,
+                                     const float *feat2, const float *pos1,
+                                     const float *pos2, int n_pairs, int hf1,
+                                     int wf1, int hf2, int wf2, void *workspace,
+                                     size_t workspace_bytes, float *hs1,
+                                     float *hs2, float *memory1, float *memory2,
+                                     void *stream);
+
+/* Replaces: OETR.center_estimation (reference src/model.py:145-186), masks
+ * None.  stride = img_h / hf (integer) scales both axes as in :176-181.
+ * In: hs [N][256], memory [N][L][256].  Out: cxy1,cxy2 [N][2] = (x,y). */
+oetr_status oetr_center_estimation(oetr_handle h, const float *hs1,
+                                   const float *hs2, const float *memory1,
+                                   const float *memory2, int n_pairs, int hf1,
+                                   int wf1, int hf2, int wf2, int img_h1,
+                                   int img_h2, void *workspace,
+                                   size_t workspace_bytes, float *cxy1,
+                                   float *cxy2, void *stream);
+
+/* Replaces: OETR.size_regression (reference src/model.py:188-191).
+ * In: hs [N][256].  Out: tlbr [N][4] (top,left,bottom,right fractions). */
+oetr_status oetr_size_regression(oetr_handle h, const float *hs1,
+                                 const float *hs2, int n_pairs, float *tlbr1,
+                                 float *tlbr2, void *stream);
+
+/* Replaces: box_tlbr_to_xyxy (reference src/models/utils.py:16-28).
+ * In: cxy [n][2], tlbr [n][4].  Out: box [n][4] xyxy clamped to the image. */
+oetr_status oetr_box_tlbr_to_xyxy(const float *cxy, const float *tlbr, int n,
+                                  int max_h, int max_w, float *box,
+                                  void *stream);
+
+/* Replaces: LinearAttention.forward (reference
+ * src/models/linear_attention.py:22-50), masks None.  Stand-alone entry for
+ * parity tests of the attention core.  q [N][L][8][32], k,v [N][S][8][32],
+ * out [N][L][8][32]. */
+oetr_status oetr_linear_attention(const float *q, const float *k,
+                                  const float *v, int n, int L, int S,
+                                  float *out, void *stream);
+
+/* Replaces: FullAttention.forward (reference
+ * src/models/linear_attention.py:53-87), no mask/dropout - the optional
+ * "all-pairs QK^T volume" variant, never materialised in HBM.  Same shapes. */
+oetr_status oetr_full_attention(const float *q, const float *k, const float *v,
+                                int n, int L, int S, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OETR_HIP_H_ */
