@@ -1,0 +1,507 @@
+// C ABI of liboetr_hip.so (declared in include/oetr_hip.h): weight repacking,
+// workspace layout and launch orchestration.  No torch types, no hidden
+// allocation or synchronisation inside forward calls.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/oetr_hip.h"
+#include "common.h"
+
+using namespace oetr;
+
+namespace {
+
+thread_local std::string g_err;
+
+oetr_status fail(oetr_status st, const std::string& msg) {
+  g_err = msg;
+  return st;
+}
+oetr_status hip_fail(hipError_t e, const char* what) {
+  return fail(OETR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e__ = (expr);                            \
+    if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+  } while (0)
+
+// ---- host-side weight repacking -------------------------------------------
+struct Packer {
+  std::vector<float> buf;
+  size_t reserve_aligned(size_t n) {
+    size_t off = (buf.size() + 63) & ~size_t(63);  // 256-B aligned offsets
+    buf.resize(off + n);
+    return off;
+  }
+  // W [nout][k] (torch Linear layout) -> MFMA B-fragment order (common.h).
+  size_t frag(const float* W, int nout, int k, int ld = -1, int stride_k = 1) {
+    if (ld < 0) ld = k;
+    const int ks_n = k / 8;
+    size_t off = reserve_aligned((size_t)nout * k);
+    float* dst = buf.data() + off;
+    for (int nt = 0; nt < nout / 32; ++nt)
+      for (int ks = 0; ks < ks_n; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j) {
+            const int n = nt * 32 + (lane & 31);
+            const int kk = ks * 8 + 4 * (lane >> 5) + j;
+            dst[(((size_t)nt * ks_n + ks) * 64 + lane) * 4 + j] =
+                W[(size_t)n * ld + (size_t)kk * stride_k];
+          }
+    return off;
+  }
+  // W [nout][k] -> transposed [k][nout]
+  size_t transposed(const float* W, int nout, int k) {
+    size_t off = reserve_aligned((size_t)nout * k);
+    float* dst = buf.data() + off;
+    for (int n = 0; n < nout; ++n)
+      for (int kk = 0; kk < k; ++kk) dst[(size_t)kk * nout + n] = W[(size_t)n * k + kk];
+    return off;
+  }
+  size_t copy(const float* v, int n) {
+    size_t off = reserve_aligned(n);
+    memcpy(buf.data() + off, v, sizeof(float) * n);
+    return off;
+  }
+};
+
+}  // namespace
+
+struct oetr_ctx {
+  int device = 0;
+  float* dev = nullptr;  // all repacked weights
+  size_t dev_floats = 0;
+  EncLayerDev enc[OETR_N_ENC];
+  DecKVDev dkv;
+  DecLayerDev dec[OETR_N_DEC];
+  const float* qe[2];
+  HeadsDev heads;
+};
+
+namespace {
+
+struct Workspace {
+  float *x, *qp, *pos, *kvp[2], *ksp[2], *dkv[2], *dks[2], *conv_out, *gn_part, *hs, *logits,
+      *cxy, *tlbr;
+  size_t bytes;
+};
+
+bool make_geom(int n, int hf1, int wf1, int hf2, int wf2, Geom* g) {
+  if (n <= 0 || hf1 <= 0 || wf1 <= 0 || hf2 <= 0 || wf2 <= 0) return false;
+  const long L1 = (long)hf1 * wf1, L2 = (long)hf2 * wf2;
+  if (L1 > OETR_MAX_TOKENS || L2 > OETR_MAX_TOKENS) return false;
+  if ((long)n * (L1 + L2) > (1L << 30) / C) return false;  // keep 32-bit row indices safe
+  g->N = n;
+  g->L[0] = (int)L1; g->L[1] = (int)L2;
+  g->hf[0] = hf1; g->wf[0] = wf1; g->hf[1] = hf2; g->wf[1] = wf2;
+  g->nt[0] = (g->L[0] + TM - 1) / TM; g->nt[1] = (g->L[1] + TM - 1) / TM;
+  g->row0[0] = 0; g->row0[1] = n * g->L[0];
+  g->prow0[0] = 0; g->prow0[1] = g->L[0];
+  g->tile0[0] = 0; g->tile0[1] = n * g->nt[0];
+  g->ntiles = n * (g->nt[0] + g->nt[1]);
+  g->rows = n * (g->L[0] + g->L[1]);
+  return true;
+}
+
+Workspace carve(const Geom& g, void* base) {
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr;
+    off += (floats * sizeof(float) + 255) & ~size_t(255);
+    return p;
+  };
+  const size_t rows = g.rows, nt = g.ntiles;
+  w.x = take(rows * C);
+  w.qp = take(rows * C);
+  w.pos = take((size_t)(g.L[0] + g.L[1]) * C);
+  for (int i = 0; i < 2; ++i) { w.kvp[i] = take(nt * KV_FLOATS); w.ksp[i] = take(nt * C); }
+  for (int i = 0; i < 2; ++i) { w.dkv[i] = take(nt * KV_FLOATS); w.dks[i] = take(nt * C); }
+  w.conv_out = take(rows * C);
+  w.gn_part = take(nt * 32 * 2);
+  w.hs = take((size_t)2 * g.N * C);
+  w.logits = take(rows);
+  w.cxy = take((size_t)2 * g.N * 2);
+  w.tlbr = take((size_t)2 * g.N * 4);
+  w.bytes = off;
+  return w;
+}
+
+oetr_status check_ws(const Geom& g, void* ws, size_t ws_bytes, Workspace* out) {
+  if (!ws) return fail(OETR_ERR_WORKSPACE, "workspace is NULL");
+  if (reinterpret_cast<uintptr_t>(ws) & 255)
+    return fail(OETR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  *out = carve(g, ws);
+  if (out->bytes > ws_bytes)
+    return fail(OETR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(out->bytes) +
+                                        " bytes, got " + std::to_string(ws_bytes));
+  return OETR_OK;
+}
+
+HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, const float* mem1,
+                       const float* mem2, const float* hs1, const float* hs2, float* cxy1,
+                       float* cxy2, int img_h1, int img_h2) {
+  HeatLaunch p;
+  p.g = g;
+  p.w = h->heads;
+  p.mem[0] = mem1; p.mem[1] = mem2;
+  p.hs[0] = hs1; p.hs[1] = hs2;
+  p.conv_out = w.conv_out;
+  p.gn_part = w.gn_part;
+  p.logits = w.logits;
+  p.cxy[0] = cxy1; p.cxy[1] = cxy2;
+  p.img_h[0] = img_h1; p.img_h[1] = img_h2;
+  return p;
+}
+
+// Encoder (+ decoder) shared by forward and feature_correlation.
+oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, const float* feat1,
+                            const float* feat2, const float* pos1, const float* pos2,
+                            int enc_layers, hipStream_t s) {
+  HIP_TRY(launch_prep_tokens(g, feat1, feat2, pos1, pos2, w.x, w.pos, s));
+  EncLaunch p;
+  memset(&p, 0, sizeof(p));
+  p.g = g;
+  p.x = w.x; p.qp = w.qp; p.pos = w.pos;
+  p.a = h->enc[0];
+  p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];
+  HIP_TRY(launch_encoder(p, false, 0, s));
+  for (int l = 0; l < enc_layers; ++l) {
+    p.b = h->enc[l];
+    p.b_cross = l & 1;
+    p.kv_in = w.kvp[l & 1]; p.ks_in = w.ksp[l & 1];
+    int tail;
+    if (l + 1 == OETR_N_ENC) {
+      tail = 1;
+      p.d = h->dkv;
+      for (int i = 0; i < 2; ++i) { p.dkv_out[i] = w.dkv[i]; p.dks_out[i] = w.dks[i]; }
+    } else if (l + 1 < enc_layers) {
+      tail = 0;
+      p.a = h->enc[l + 1];
+      p.kv_out = w.kvp[(l + 1) & 1]; p.ks_out = w.ksp[(l + 1) & 1];
+    } else {
+      tail = 2;
+    }
+    HIP_TRY(launch_encoder(p, true, tail, s));
+  }
+  if (enc_layers == OETR_N_ENC) {
+    DecLaunch d;
+    d.g = g;
+    for (int i = 0; i < 2; ++i) {
+      d.layer[i] = h->dec[i];
+      d.qe[i] = h->qe[i];
+      d.dkv[i] = w.dkv[i];
+      d.dks[i] = w.dks[i];
+    }
+    d.hs = w.hs;
+    HIP_TRY(launch_decoder(d, s));
+  }
+  return OETR_OK;
+}
+
+oetr_status copy_out(float* dst, const float* src, size_t floats, hipStream_t s) {
+  if (!dst) return OETR_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return OETR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* oetr_last_error(void) { return g_err.c_str(); }
+int oetr_abi_version(void) { return OETR_ABI_VERSION; }
+
+oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oetr_handle* out) {
+  if (!w || !out) return fail(OETR_ERR_BAD_ARG, "oetr_create: NULL argument");
+  if (w->struct_size != sizeof(oetr_weights) || w->abi_version != OETR_ABI_VERSION)
+    return fail(OETR_ERR_BAD_ARG, "oetr_create: oetr_weights size/ABI mismatch");
+  if (dtype != OETR_DTYPE_F32) return fail(OETR_ERR_UNSUPPORTED, "only OETR_DTYPE_F32 is built");
+  {  // every pointer must be set
+    const float* const* p = reinterpret_cast<const float* const*>(&w->enc[0]);
+    const size_t n = (sizeof(oetr_weights) - offsetof(oetr_weights, enc)) / sizeof(float*);
+    for (size_t i = 0; i < n; ++i)
+      if (!p[i]) return fail(OETR_ERR_BAD_ARG, "oetr_create: weight pointer #" +
+                                                   std::to_string(i) + " is NULL");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+    return fail(OETR_ERR_NO_DEVICE, "no HIP device " + std::to_string(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (!strstr(prop.gcnArchName, "gfx950"))
+    return fail(OETR_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName +
+                                        ", this library is built for gfx950 only");
+
+  oetr_ctx* h = new oetr_ctx();
+  h->device = device;
+  Packer pk;
+  struct EncOff { size_t wq, wk, wv, wm, w1, w2, v[6]; } eo[OETR_N_ENC];
+  for (int l = 0; l < OETR_N_ENC; ++l) {
+    const oetr_encoder_layer_weights& e = w->enc[l];
+    eo[l].wq = pk.frag(e.q_proj, C, C);
+    eo[l].wk = pk.frag(e.k_proj, C, C);
+    eo[l].wv = pk.frag(e.v_proj, C, C);
+    eo[l].wm = pk.frag(e.merge, C, C);
+    eo[l].w1 = pk.frag(e.mlp0, FF, C);
+    eo[l].w2 = pk.frag(e.mlp2, C, FF);
+    const float* vecs[6] = {e.pre_norm_q_w, e.pre_norm_q_b, e.pre_norm_kv_w,
+                            e.pre_norm_kv_b, e.norm2_w, e.norm2_b};
+    for (int i = 0; i < 6; ++i) eo[l].v[i] = pk.copy(vecs[i], C);
+  }
+  struct DecOff { size_t ck, cv, cbk, cbv, m[2][7], w1, w2, n[6]; } dof[OETR_N_DEC];
+  for (int l = 0; l < OETR_N_DEC; ++l) {
+    const oetr_decoder_layer_weights& d = w->dec[l];
+    dof[l].ck = pk.frag(d.multihead_attn.k_proj_w, C, C);
+    dof[l].cv = pk.frag(d.multihead_attn.v_proj_w, C, C);
+    dof[l].cbk = pk.copy(d.multihead_attn.k_proj_b, C);
+    dof[l].cbv = pk.copy(d.multihead_attn.v_proj_b, C);
+    const oetr_mha_weights* mh[2] = {&d.self_attn, &d.multihead_attn};
+    for (int a = 0; a < 2; ++a) {
+      dof[l].m[a][0] = pk.transposed(mh[a]->q_proj_w, C, C);
+      dof[l].m[a][1] = pk.transposed(mh[a]->k_proj_w, C, C);
+      dof[l].m[a][2] = pk.transposed(mh[a]->v_proj_w, C, C);
+      dof[l].m[a][3] = pk.transposed(mh[a]->merge, C, C);
+      dof[l].m[a][4] = pk.copy(mh[a]->q_proj_b, C);
+      dof[l].m[a][5] = pk.copy(mh[a]->k_proj_b, C);
+      dof[l].m[a][6] = pk.copy(mh[a]->v_proj_b, C);
+    }
+    dof[l].w1 = pk.transposed(d.mlp0, FF, C);
+    dof[l].w2 = pk.transposed(d.mlp2, C, FF);
+    const float* nv[6] = {d.norm1_w, d.norm1_b, d.norm2_w, d.norm2_b, d.norm3_w, d.norm3_b};
+    for (int i = 0; i < 6; ++i) dof[l].n[i] = pk.copy(nv[i], C);
+  }
+  const size_t qe1 = pk.copy(w->query_embed1, C), qe2 = pk.copy(w->query_embed2, C);
+  // conv weight [o][i][ky][kx] -> 9 fragment-packed [o][i] matrices, tap = ky*3+kx
+  size_t conv_off = 0;
+  for (int tap = 0; tap < 9; ++tap) {
+    const size_t o = pk.frag(w->heat_conv_w + tap, C, C, /*ld=*/C * 9, /*stride_k=*/9);
+    if (tap == 0) conv_off = o;
+  }
+  const size_t conv_b = pk.copy(w->heat_conv_b, C), gn_w = pk.copy(w->heat_gn_w, C),
+               gn_b = pk.copy(w->heat_gn_b, C), out_w = pk.copy(w->heat_out_w, C),
+               out_b = pk.copy(w->heat_out_b, 1);
+  const size_t t0 = pk.transposed(w->tlbr0_w, C, C), t2w = pk.copy(w->tlbr2_w, 4 * C),
+               t2b = pk.copy(w->tlbr2_b, 4);
+
+  int prev = 0;
+  hipGetDevice(&prev);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(&h->dev, pk.buf.size() * sizeof(float));
+  if (e == hipSuccess)
+    e = hipMemcpy(h->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
+  hipSetDevice(prev);
+  if (e != hipSuccess) {
+    if (h->dev) hipFree(h->dev);
+    delete h;
+    return hip_fail(e, "oetr_create: uploading weights");
+  }
+  h->dev_floats = pk.buf.size();
+  const float* B = h->dev;
+  auto F4 = [&](size_t off) { return reinterpret_cast<const f32x4*>(B + off); };
+  for (int l = 0; l < OETR_N_ENC; ++l) {
+    EncLayerDev& d = h->enc[l];
+    d.wq = F4(eo[l].wq); d.wk = F4(eo[l].wk); d.wv = F4(eo[l].wv); d.wmerge = F4(eo[l].wm);
+    d.w1 = F4(eo[l].w1); d.w2 = F4(eo[l].w2);
+    d.lnq_w = B + eo[l].v[0]; d.lnq_b = B + eo[l].v[1];
+    d.lnkv_w = B + eo[l].v[2]; d.lnkv_b = B + eo[l].v[3];
+    d.ln2_w = B + eo[l].v[4]; d.ln2_b = B + eo[l].v[5];
+  }
+  for (int l = 0; l < OETR_N_DEC; ++l) {
+    h->dkv.wk[l] = F4(dof[l].ck); h->dkv.wv[l] = F4(dof[l].cv);
+    h->dkv.bk[l] = B + dof[l].cbk; h->dkv.bv[l] = B + dof[l].cbv;
+    DecLayerDev& d = h->dec[l];
+    MhaDev* mh[2] = {&d.self_attn, &d.cross};
+    for (int a = 0; a < 2; ++a) {
+      mh[a]->wq_t = B + dof[l].m[a][0]; mh[a]->wk_t = B + dof[l].m[a][1];
+      mh[a]->wv_t = B + dof[l].m[a][2]; mh[a]->wm_t = B + dof[l].m[a][3];
+      mh[a]->bq = B + dof[l].m[a][4]; mh[a]->bk = B + dof[l].m[a][5];
+      mh[a]->bv = B + dof[l].m[a][6];
+    }
+    d.w1_t = B + dof[l].w1; d.w2_t = B + dof[l].w2;
+    d.n1w = B + dof[l].n[0]; d.n1b = B + dof[l].n[1]; d.n2w = B + dof[l].n[2];
+    d.n2b = B + dof[l].n[3]; d.n3w = B + dof[l].n[4]; d.n3b = B + dof[l].n[5];
+  }
+  h->qe[0] = B + qe1; h->qe[1] = B + qe2;
+  h->heads.conv_w = F4(conv_off);
+  h->heads.conv_b = B + conv_b; h->heads.gn_w = B + gn_w; h->heads.gn_b = B + gn_b;
+  h->heads.out_w = B + out_w; h->heads.out_b = B + out_b;
+  h->heads.tlbr0_t = B + t0; h->heads.tlbr2_w = B + t2w; h->heads.tlbr2_b = B + t2b;
+  *out = h;
+  return OETR_OK;
+}
+
+void oetr_destroy(oetr_handle h) {
+  if (!h) return;
+  if (h->dev) {
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipSetDevice(h->device);
+    hipFree(h->dev);
+    hipSetDevice(prev);
+  }
+  delete h;
+}
+
+size_t oetr_workspace_bytes(oetr_handle h, int n_pairs, int hf1, int wf1, int hf2, int wf2) {
+  (void)h;
+  Geom g;
+  if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g)) {
+    g_err = "invalid shape: need N>0 and 1 <= hf*wf <= " + std::to_string(OETR_MAX_TOKENS);
+    return 0;
+  }
+  return carve(g, nullptr).bytes;
+}
+
+oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* feat2,
+                                const float* pos1, const float* pos2, int n_pairs, int hf1,
+                                int wf1, int hf2, int wf2, int img_h1, int img_w1, int img_h2,
+                                int img_w2, void* workspace, size_t workspace_bytes,
+                                float* box1, float* box2, const oetr_stage_outputs* st,
+                                void* stream) {
+  if (!h || !feat1 || !feat2 || !pos1 || !pos2)
+    return fail(OETR_ERR_BAD_ARG, "oetr_forward: NULL handle/input");
+  int enc_layers = OETR_N_ENC;
+  if (st) {
+    if (st->struct_size != sizeof(oetr_stage_outputs))
+      return fail(OETR_ERR_BAD_ARG, "oetr_stage_outputs size mismatch");
+    enc_layers = st->enc_layers;
+    if (enc_layers < 1 || enc_layers > OETR_N_ENC)
+      return fail(OETR_ERR_BAD_ARG, "enc_layers must be in 1..8");
+  }
+  const bool full = enc_layers == OETR_N_ENC;
+  if (full && (!box1 || !box2)) return fail(OETR_ERR_BAD_ARG, "oetr_forward: NULL box output");
+  Geom g;
+  if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g))
+    return fail(OETR_ERR_BAD_SHAPE, "invalid shape: need N>0 and 1 <= hf*wf <= " +
+                                        std::to_string(OETR_MAX_TOKENS));
+  if (full && (img_h1 < hf1 || img_h2 < hf2 || img_w1 <= 0 || img_w2 <= 0))
+    return fail(OETR_ERR_BAD_SHAPE, "image size smaller than the token grid");
+  Workspace w;
+  oetr_status rc = check_ws(g, workspace, workspace_bytes, &w);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, enc_layers, s);
+  if (rc) return rc;
+  const size_t r1 = (size_t)g.N * g.L[0], r2 = (size_t)g.N * g.L[1];
+  if (st) {
+    if ((rc = copy_out(st->memory1, w.x, r1 * C, s))) return rc;
+    if ((rc = copy_out(st->memory2, w.x + r1 * C, r2 * C, s))) return rc;
+  }
+  if (!full) return OETR_OK;
+  const float* hs1 = w.hs;
+  const float* hs2 = w.hs + (size_t)g.N * C;
+  float* cxy1 = w.cxy;
+  float* cxy2 = w.cxy + 2 * g.N;
+  float* tl1 = w.tlbr;
+  float* tl2 = w.tlbr + 4 * g.N;
+  HeatLaunch hp = heat_launch(h, g, w, w.x, w.x + r1 * C, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
+  HIP_TRY(launch_heat_conv(hp, s));
+  HIP_TRY(launch_heat_final(hp, s));
+  HIP_TRY(launch_size_regression(h->heads, hs1, hs2, g.N, tl1, tl2, s));
+  HIP_TRY(launch_boxes(cxy1, tl1, g.N, img_h1, img_w1, box1, s));
+  HIP_TRY(launch_boxes(cxy2, tl2, g.N, img_h2, img_w2, box2, s));
+  if (st) {
+    if ((rc = copy_out(st->hs1, hs1, (size_t)g.N * C, s))) return rc;
+    if ((rc = copy_out(st->hs2, hs2, (size_t)g.N * C, s))) return rc;
+    if ((rc = copy_out(st->logits1, w.logits, r1, s))) return rc;
+    if ((rc = copy_out(st->logits2, w.logits + r1, r2, s))) return rc;
+    if ((rc = copy_out(st->cxy1, cxy1, 2 * g.N, s))) return rc;
+    if ((rc = copy_out(st->cxy2, cxy2, 2 * g.N, s))) return rc;
+    if ((rc = copy_out(st->tlbr1, tl1, 4 * g.N, s))) return rc;
+    if ((rc = copy_out(st->tlbr2, tl2, 4 * g.N, s))) return rc;
+  }
+  return OETR_OK;
+}
+
+oetr_status oetr_forward(oetr_handle h, const float* feat1, const float* feat2,
+                         const float* pos1, const float* pos2, int n_pairs, int hf1, int wf1,
+                         int hf2, int wf2, int img_h1, int img_w1, int img_h2, int img_w2,
+                         void* workspace, size_t workspace_bytes, float* box1, float* box2,
+                         void* stream) {
+  return oetr_forward_stages(h, feat1, feat2, pos1, pos2, n_pairs, hf1, wf1, hf2, wf2, img_h1,
+                             img_w1, img_h2, img_w2, workspace, workspace_bytes, box1, box2,
+                             nullptr, stream);
+}
+
+oetr_status oetr_feature_correlation(oetr_handle h, const float* feat1, const float* feat2,
+                                     const float* pos1, const float* pos2, int n_pairs, int hf1,
+                                     int wf1, int hf2, int wf2, void* workspace,
+                                     size_t workspace_bytes, float* hs1, float* hs2,
+                                     float* memory1, float* memory2, void* stream) {
+  if (!h || !feat1 || !feat2 || !pos1 || !pos2 || !hs1 || !hs2 || !memory1 || !memory2)
+    return fail(OETR_ERR_BAD_ARG, "oetr_feature_correlation: NULL argument");
+  Geom g;
+  if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g))
+    return fail(OETR_ERR_BAD_SHAPE, "invalid shape");
+  Workspace w;
+  oetr_status rc = check_ws(g, workspace, workspace_bytes, &w);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, OETR_N_ENC, s))) return rc;
+  const size_t r1 = (size_t)g.N * g.L[0], r2 = (size_t)g.N * g.L[1];
+  if ((rc = copy_out(memory1, w.x, r1 * C, s))) return rc;
+  if ((rc = copy_out(memory2, w.x + r1 * C, r2 * C, s))) return rc;
+  if ((rc = copy_out(hs1, w.hs, (size_t)g.N * C, s))) return rc;
+  return copy_out(hs2, w.hs + (size_t)g.N * C, (size_t)g.N * C, s);
+}
+
+oetr_status oetr_center_estimation(oetr_handle h, const float* hs1, const float* hs2,
+                                   const float* memory1, const float* memory2, int n_pairs,
+                                   int hf1, int wf1, int hf2, int wf2, int img_h1, int img_h2,
+                                   void* workspace, size_t workspace_bytes, float* cxy1,
+                                   float* cxy2, void* stream) {
+  if (!h || !hs1 || !hs2 || !memory1 || !memory2 || !cxy1 || !cxy2)
+    return fail(OETR_ERR_BAD_ARG, "oetr_center_estimation: NULL argument");
+  Geom g;
+  if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g))
+    return fail(OETR_ERR_BAD_SHAPE, "invalid shape");
+  if (img_h1 < hf1 || img_h2 < hf2)
+    return fail(OETR_ERR_BAD_SHAPE, "image height smaller than the token grid");
+  Workspace w;
+  oetr_status rc = check_ws(g, workspace, workspace_bytes, &w);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HeatLaunch hp = heat_launch(h, g, w, memory1, memory2, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
+  HIP_TRY(launch_heat_conv(hp, s));
+  HIP_TRY(launch_heat_final(hp, s));
+  return OETR_OK;
+}
+
+oetr_status oetr_size_regression(oetr_handle h, const float* hs1, const float* hs2, int n_pairs,
+                                 float* tlbr1, float* tlbr2, void* stream) {
+  if (!h || !hs1 || !hs2 || !tlbr1 || !tlbr2 || n_pairs <= 0)
+    return fail(OETR_ERR_BAD_ARG, "oetr_size_regression: bad argument");
+  HIP_TRY(launch_size_regression(h->heads, hs1, hs2, n_pairs, tlbr1, tlbr2,
+                                 static_cast<hipStream_t>(stream)));
+  return OETR_OK;
+}
+
+oetr_status oetr_box_tlbr_to_xyxy(const float* cxy, const float* tlbr, int n, int max_h,
+                                  int max_w, float* box, void* stream) {
+  if (!cxy || !tlbr || !box || n <= 0)
+    return fail(OETR_ERR_BAD_ARG, "oetr_box_tlbr_to_xyxy: bad argument");
+  HIP_TRY(launch_boxes(cxy, tlbr, n, max_h, max_w, box, static_cast<hipStream_t>(stream)));
+  return OETR_OK;
+}
+
+oetr_status oetr_linear_attention(const float* q, const float* k, const float* v, int n, int L,
+                                  int S, float* out, void* stream) {
+  if (!q || !k || !v || !out || n <= 0 || L <= 0 || S <= 0)
+    return fail(OETR_ERR_BAD_ARG, "oetr_linear_attention: bad argument");
+  HIP_TRY(launch_linear_attention(q, k, v, n, L, S, out, static_cast<hipStream_t>(stream)));
+  return OETR_OK;
+}
+
+oetr_status oetr_full_attention(const float* q, const float* k, const float* v, int n, int L,
+                                int S, float* out, void* stream) {
+  if (!q || !k || !v || !out || n <= 0 || L <= 0 || S <= 0)
+    return fail(OETR_ERR_BAD_ARG, "oetr_full_attention: bad argument");
+  HIP_TRY(launch_full_attention(q, k, v, n, L, S, out, static_cast<hipStream_t>(stream)));
+  return OETR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+// Shared definitions for the OETR gfx950 kernels (device helpers + host-side
+// launch declarations).  CDNA4 only: wave = 64 lanes, f32 MFMA 32x32x2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oetr {
+
+constexpr int C = 256;        // d_model
+constexpr int NH = 8;         // heads
+constexpr int HD = 32;        // head dim  (= one 32-wide MFMA n-tile)
+constexpr int FF = 512;       // MLP hidden
+constexpr int TM = 32;        // token rows per workgroup tile (= MFMA M)
+constexpr int LDA = C + 4;    // padded row stride (floats) of a [TM][256] LDS tile
+constexpr int LDH = FF + 4;   // padded row stride of the [TM][512] hidden tile
+constexpr int NTHREADS = 256; // 4 waves, one per SIMD
+constexpr int KV_FLOATS = NH * HD * HD;  // 8192: one KV state (all heads)
+constexpr float LN_EPS = 1e-5f;
+constexpr float ATTN_EPS = 1e-6f;
+constexpr int MAX_TOKENS = 10000;  // NECK.MAX_SHAPE 100x100 (reference default.py:25-28)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Token geometry of one forward call. "side" 0/1 = image1/image2 batch.
+struct Geom {
+  int N;         // pairs
+  int L[2];      // tokens per image
+  int hf[2], wf[2];
+  int nt[2];     // TM-row tiles per image
+  int row0[2];   // first row of the side in token-major [rows][256] buffers
+  int prow0[2];  // first row of the side in the position table buffer
+  int tile0[2];  // first tile slot of the side
+  int ntiles;    // N * (nt[0] + nt[1])
+  int rows;      // N * (L[0] + L[1])
+};
+
+// ---------------------------------------------------------------- device
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Row of accumulator register r for a 32x32 MFMA C/D tile (col = lane & 31).
+__device__ __forceinline__ int crow(int r, int half) {
+  return (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+
+// phi(x) = elu(x) + 1, computed as torch does: expm1(x) + 1 for x <= 0.
+__device__ __forceinline__ float elu1(float x) {
+  return x > 0.f ? x + 1.0f : expm1f(x) + 1.0f;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// XCD-aware bijective remap: hardware block b runs on XCD b % 8; give each
+// XCD a contiguous run of logical tiles so tiles of one image pair share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// acc[t] += A[32 x K] * W_tile(nt0 + t), t < NT.
+//   A : LDS, row-major, row stride lda floats (16-B aligned rows).
+//   Wp: weights repacked in MFMA B-fragment order:
+//       float4 index ((ntile * K/8 + ks) * 64 + lane) holds, for output column
+//       n = 32*ntile + (lane & 31), inputs k = 8*ks + 4*(lane >> 5) + {0..3}.
+//   Each wave streams its own weight fragments straight into registers with
+//   fully coalesced 1-KiB loads (prefetched one chunk of U k-steps ahead);
+//   the activation fragment is one ds_read_b128 per k-step.
+template <int K, int NT, int U = 4>
+__device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda,
+                                            const f32x4* __restrict__ Wp, int nt0,
+                                            int lane, f32x16 (&acc)[NT]) {
+  constexpr int KS = K / 8;
+  constexpr int NCH = KS / U;
+  static_assert(KS % U == 0, "K must be a multiple of 8*U");
+  const int half = lane >> 5;
+  const float* a_ptr = A + (lane & 31) * lda + 4 * half;
+  const f32x4* w_ptr[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) w_ptr[t] = Wp + (size_t)(nt0 + t) * KS * 64 + lane;
+
+  f32x4 bc[U][NT], bn[U][NT];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bc[u][t] = w_ptr[t][u * 64];
+
+#pragma unroll 2
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bn[u][t] = w_ptr[t][((c + 1) * U + u) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(a_ptr + (c * U + u) * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bc[u][t][j], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bc[u][t] = bn[u][t];
+  }
+}
+
+// Write a wave's two 32x32 accumulator tiles (columns col0 + 32*t + lane&31)
+// into a row-major LDS tile.
+template <int NT>
+__device__ __forceinline__ void acc_to_lds(float* S, int lds, int col0, int lane,
+                                           const f32x16 (&acc)[NT]) {
+  const int half = lane >> 5, c = col0 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[crow(r, half) * lds + c + 32 * t] = acc[t][r];
+}
+
+#endif  // __HIPCC__
+
+// ------------------------------------------------------------------ host
+// Repacked weights of one encoder layer (device pointers).
+struct EncLayerDev {
+  const f32x4 *wq, *wk, *wv, *wmerge, *w1, *w2;  // fragment-packed
+  const float *lnq_w, *lnq_b, *lnkv_w, *lnkv_b, *ln2_w, *ln2_b;
+};
+// Decoder cross-attention K/V projections applied to the encoder memory.
+struct DecKVDev {
+  const f32x4 *wk[2], *wv[2];
+  const float *bk[2], *bv[2];
+};
+
+struct EncLaunch {
+  Geom g;
+  float* x;              // [rows][256] token-major activations (in/out, in place)
+  float* qp;             // [rows][256] phi(Q) of the layer being finished / next
+  const float* pos;      // [L0+L1][256] token-major position table
+  const float* kv_in;    // partial KV states of the layer being finished
+  const float* ks_in;    //   [ntiles][8192] / [ntiles][256]
+  float* kv_out;         // partial KV states for the next layer
+  float* ks_out;
+  float* dkv_out[2];     // TAIL==1: decoder cross-attn partial states per layer
+  float* dks_out[2];
+  EncLayerDev b;         // layer being finished (phase B), if any
+  EncLayerDev a;         // next layer (phase A), TAIL==0
+  DecKVDev d;            // TAIL==1
+  int b_cross;           // phase-B layer is a cross layer
+};
+
+// has_b: run phase B (finish a layer); tail: 0 = phase A of next encoder layer,
+// 1 = decoder K/V preparation, 2 = nothing.
+hipError_t launch_prep_tokens(const Geom& g, const float* feat1, const float* feat2,
+                              const float* pos1, const float* pos2, float* x,
+                              float* pos_tok, hipStream_t s);
+hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, hipStream_t s);
+
+struct MhaDev {
+  const float *wq_t, *wk_t, *wv_t, *wm_t;  // transposed [in][out]
+  const float *bq, *bk, *bv;
+};
+struct DecLayerDev {
+  MhaDev self_attn, cross;
+  const float *w1_t, *w2_t;  // [256][512], [512][256] transposed
+  const float *n1w, *n1b, *n2w, *n2b, *n3w, *n3b;
+};
+struct DecLaunch {
+  Geom g;
+  DecLayerDev layer[2];
+  const float* qe[2];      // query embeddings per side [256]
+  const float* dkv[2];     // partial states from the encoder tail
+  const float* dks[2];
+  float* hs;               // [2N][256]
+};
+hipError_t launch_decoder(const DecLaunch& p, hipStream_t s);
+
+struct HeadsDev {
+  const f32x4* conv_w;     // 9 taps x fragment-packed [256 out][256 in]
+  const float *conv_b, *gn_w, *gn_b, *out_w, *out_b;
+  const float *tlbr0_t;    // [256 in][256 out] transposed
+  const float *tlbr2_w, *tlbr2_b;  // [4][256], [4]
+};
+struct HeatLaunch {
+  Geom g;
+  HeadsDev w;
+  const float* mem[2];     // per side memory [N][L][256]
+  const float* hs[2];      // per side hs [N][256]
+  float* conv_out;         // [rows][256]
+  float* gn_part;          // [ntiles][32][2]  (mean, M2) per tile & group
+  float* logits;           // [rows]
+  float* cxy[2];           // [N][2] per side
+  int img_h[2];
+};
+hipError_t launch_heat_conv(const HeatLaunch& p, hipStream_t s);
+hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s);
+hipError_t launch_size_regression(const HeadsDev& w, const float* hs1, const float* hs2,
+                                  int n, float* tlbr1, float* tlbr2, hipStream_t s);
+hipError_t launch_boxes(const float* cxy, const float* tlbr, int n, int max_h, int max_w,
+                        float* box, hipStream_t s);
+hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n,
+                                   int L, int S, float* out, hipStream_t s);
+hipError_t launch_full_attention(const float* q, const float* k, const float* v, int n,
+                                 int L, int S, float* out, hipStream_t s);
+
+}  // namespace oetr

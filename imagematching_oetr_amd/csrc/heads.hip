@@ -1,0 +1,260 @@
+// Overlap-regression heads of OETR (gfx950).
+//
+// Reference: OETR.center_estimation (src/model.py:145-186) with heatmap_conv
+// (:65-77) and generate_mesh_grid (:103-107); OETR.size_regression (:188-191,
+// tlbr_reg :59-63); box_tlbr_to_xyxy (src/models/utils.py:16-28).
+//
+//  k_heat_conv : att = memory.hs, 3x3 conv of (memory*att) as an implicit GEMM
+//                (9 taps x [32 tok x 256] . [256 x 256] on f32 MFMA, the tap
+//                tile gathered+scaled on the fly, double-buffered in LDS),
+//                + bias, per-tile GroupNorm partial moments.
+//  k_heat_final: one workgroup per image: combine the GroupNorm moments
+//                (Chan), normalise + ReLU + 1x1 conv -> logits, softmax over
+//                the image's tokens, soft-argmax -> centre (x, y).
+//  k_size_reg  : sigmoid(W2 relu(W1 hs) + b2).
+//  k_boxes     : centre -+ extents, clamped to the image.
+#include "common.h"
+
+namespace oetr {
+
+constexpr int GN_GROUPS = 32;
+constexpr float GN_EPS = 1e-5f;
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TM * LDA];
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int col = lane & 31;
+
+  const int logical = xcd_remap(blockIdx.x, g.ntiles);
+  const int per = g.nt[0] + g.nt[1];
+  const int n = logical / per;
+  const int rem = logical - n * per;
+  const int side = rem >= g.nt[0];
+  const int t_idx = side ? rem - g.nt[0] : rem;
+  const int L = g.L[side], hf = g.hf[side], wf = g.wf[side];
+  const int l0 = t_idx * TM;
+  const int nvalid = min(TM, L - l0);
+  const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
+  const float* mem = p.mem[side] + (size_t)n * L * C;
+  const f32x4 hsv = reinterpret_cast<const f32x4*>(p.hs[side] + (size_t)n * C)[lane];
+
+  // gather + scale one tap tile: rows 8*wave .. 8*wave+7
+  auto stage = [&](int tap, float* S) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = wave * 8 + i;
+      const int l = l0 + r;
+      const int y = l / wf, x = l - y * wf;
+      const int yy = y + dy, xx = x + dx;
+      const bool ok = (l < L) && (yy >= 0) && (yy < hf) && (xx >= 0) && (xx < wf);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = reinterpret_cast<const f32x4*>(mem + (size_t)(yy * wf + xx) * C)[lane];
+      const float att =
+          wave_sum((v[0] * hsv[0] + v[1] * hsv[1]) + (v[2] * hsv[2] + v[3] * hsv[3]));
+      *reinterpret_cast<f32x4*>(S + r * LDA + 4 * lane) = v * att;
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float b = p.w.conv_b[64 * wave + 32 * t + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+  }
+  stage(0, smem);
+  __syncthreads();
+  for (int tap = 0; tap < 9; ++tap) {
+    float* cur = smem + (tap & 1) * TM * LDA;
+    float* nxt = smem + ((tap + 1) & 1) * TM * LDA;
+    if (tap + 1 < 9) stage(tap + 1, nxt);
+    gemm_rows32<C, 2>(cur, LDA, p.w.conv_w + (size_t)tap * (C * C / 4), 2 * wave, lane, acc);
+    __syncthreads();
+  }
+
+  // conv output + per-(tile, group) moments for GroupNorm
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int c = 64 * wave + 32 * t + col;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      if (row < nvalid) {
+        p.conv_out[((size_t)g.row0[side] + (size_t)n * L + l0 + row) * C + c] = acc[t][r];
+        s += acc[t][r];
+      }
+    }
+    // 8 channels of a group = lanes with equal (lane&31)>>3, both halves
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)(nvalid * 8);
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (crow(r, half) < nvalid) { const float d = acc[t][r] - mean; m2 += d * d; }
+    m2 += __shfl_xor(m2, 1, 64);
+    m2 += __shfl_xor(m2, 2, 64);
+    m2 += __shfl_xor(m2, 4, 64);
+    m2 += __shfl_xor(m2, 32, 64);
+    if ((lane & 39) == 0) {  // lane&7 == 0 and half == 0
+      float* dst = p.gn_part + ((size_t)slot * GN_GROUPS + (c >> 3)) * 2;
+      dst[0] = mean;
+      dst[1] = m2;
+    }
+  }
+}
+
+hipError_t launch_heat_conv(const HeatLaunch& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_heat_conv, dim3(p.g.ntiles), dim3(NTHREADS), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+constexpr int FIN_THREADS = 1024;
+
+__device__ __forceinline__ float block_reduce(float v, float* red_s, int tid, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red_s[tid >> 6] = v;
+  __syncthreads();
+  float r = red_s[0];
+#pragma unroll
+  for (int i = 1; i < FIN_THREADS / 64; ++i) r = is_max ? fmaxf(r, red_s[i]) : r + red_s[i];
+  return r;
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
+  __shared__ float logit_s[MAX_TOKENS];
+  __shared__ float gmean_s[GN_GROUPS], grstd_s[GN_GROUPS];
+  __shared__ float red_s[FIN_THREADS / 64];
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = blockIdx.x;
+  const int side = img >= g.N, n = side ? img - g.N : img;
+  const int L = g.L[side], wf = g.wf[side], nts = g.nt[side];
+  const int slot0 = g.tile0[side] + n * nts;
+  const size_t row0 = (size_t)g.row0[side] + (size_t)n * L;
+
+  if (tid < GN_GROUPS) {
+    // Chan et al. parallel combination of (count, mean, M2) over the tiles
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int ti = 0; ti < nts; ++ti) {
+      const float nb = 8.f * (float)min(TM, L - ti * TM);
+      const float* src = p.gn_part + ((size_t)(slot0 + ti) * GN_GROUPS + tid) * 2;
+      const float mb = src[0], m2b = src[1];
+      const float tot = cnt + nb, delta = mb - mean;
+      mean += delta * (nb / tot);
+      m2 += m2b + delta * delta * (cnt * nb / tot);
+      cnt = tot;
+    }
+    gmean_s[tid] = mean;
+    grstd_s[tid] = 1.0f / sqrtf(m2 / cnt + GN_EPS);
+  }
+  __syncthreads();
+
+  {  // logits: one wave per token row
+    const f32x4 gw = reinterpret_cast<const f32x4*>(p.w.gn_w)[lane];
+    const f32x4 gb = reinterpret_cast<const f32x4*>(p.w.gn_b)[lane];
+    const f32x4 ow = reinterpret_cast<const f32x4*>(p.w.out_w)[lane];
+    const float mu = gmean_s[lane >> 1], rs = grstd_s[lane >> 1];
+    const float ob = p.w.out_b[0];
+    for (int l = wave; l < L; l += FIN_THREADS / 64) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(p.conv_out + (row0 + l) * C)[lane];
+      f32x4 y = (v - mu) * rs * gw + gb;
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d += fmaxf(y[j], 0.f) * ow[j];
+      d = wave_sum(d) + ob;
+      if (lane == 0) { logit_s[l] = d; p.logits[row0 + l] = d; }
+    }
+  }
+  __syncthreads();
+
+  // softmax over the image's tokens + soft-argmax (model.py:173-184)
+  float mx = -INFINITY;
+  for (int l = tid; l < L; l += FIN_THREADS) mx = fmaxf(mx, logit_s[l]);
+  mx = block_reduce(mx, red_s, tid, true);
+  float se = 0.f;
+  for (int l = tid; l < L; l += FIN_THREADS) se += expf(logit_s[l] - mx);
+  se = block_reduce(se, red_s, tid, false);
+  const float stride = (float)(p.img_h[side] / g.hf[side]);
+  float sx = 0.f, sy = 0.f;
+  for (int l = tid; l < L; l += FIN_THREADS) {
+    const float pr = expf(logit_s[l] - mx) / se;
+    const int y = l / wf, x = l - y * wf;
+    sx += pr * (((float)x + 0.5f) * stride);
+    sy += pr * (((float)y + 0.5f) * stride);
+  }
+  sx = block_reduce(sx, red_s, tid, false);
+  sy = block_reduce(sy, red_s, tid, false);
+  if (tid == 0) {
+    p.cxy[side][2 * n] = sx;
+    p.cxy[side][2 * n + 1] = sy;
+  }
+}
+
+hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_heat_final, dim3(2 * p.g.N), dim3(FIN_THREADS), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_size_reg(HeadsDev w, const float* __restrict__ hs1,
+                                                  const float* __restrict__ hs2, int n,
+                                                  float* __restrict__ tlbr1,
+                                                  float* __restrict__ tlbr2) {
+  __shared__ float h_s[C], hid_s[C];
+  const int tid = threadIdx.x, img = blockIdx.x;
+  const int side = img >= n, i = side ? img - n : img;
+  const float* hs = (side ? hs2 : hs1) + (size_t)i * C;
+  h_s[tid] = hs[tid];
+  __syncthreads();
+  float a = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < C; ++k) a += w.tlbr0_t[k * C + tid] * h_s[k];
+  hid_s[tid] = fmaxf(a, 0.f);
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;  // wave j -> output j
+  const f32x4 wv = reinterpret_cast<const f32x4*>(w.tlbr2_w + wave * C)[lane];
+  const f32x4 hv = reinterpret_cast<const f32x4*>(hid_s)[lane];
+  float d = wave_sum((wv[0] * hv[0] + wv[1] * hv[1]) + (wv[2] * hv[2] + wv[3] * hv[3]));
+  if (lane == 0) {
+    d += w.tlbr2_b[wave];
+    (side ? tlbr2 : tlbr1)[4 * i + wave] = 1.0f / (1.0f + expf(-d));
+  }
+}
+
+hipError_t launch_size_regression(const HeadsDev& w, const float* hs1, const float* hs2,
+                                  int n, float* tlbr1, float* tlbr2, hipStream_t s) {
+  hipLaunchKernelGGL(k_size_reg, dim3(2 * n), dim3(256), 0, s, w, hs1, hs2, n, tlbr1, tlbr2);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_boxes(const float* __restrict__ cxy, const float* __restrict__ tlbr, int n,
+                        float max_h, float max_w, float* __restrict__ box) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = cxy[2 * i], y = cxy[2 * i + 1];
+  const float t = tlbr[4 * i] * max_h, l = tlbr[4 * i + 1] * max_w;
+  const float b = tlbr[4 * i + 2] * max_h, r = tlbr[4 * i + 3] * max_w;
+  box[4 * i + 0] = fminf(fmaxf(x - l, 0.f), max_w);
+  box[4 * i + 1] = fminf(fmaxf(y - t, 0.f), max_h);
+  box[4 * i + 2] = fminf(fmaxf(x + r, 0.f), max_w);
+  box[4 * i + 3] = fminf(fmaxf(y + b, 0.f), max_h);
+}
+
+hipError_t launch_boxes(const float* cxy, const float* tlbr, int n, int max_h, int max_w,
+                        float* box, hipStream_t s) {
+  hipLaunchKernelGGL(k_boxes, dim3((n + 63) / 64), dim3(64), 0, s, cxy, tlbr, n, (float)max_h,
+                     (float)max_w, box);
+  return hipGetLastError();
+}
+
+}  // namespace oetr
