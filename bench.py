@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Benchmark of the OETR hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path (feature maps -> overlap boxes:
+feature-correlation transformer + centre/size heads, reference
+``src/model.py:239-252``) over one batch of synthetic 640x640 pairs per GPU,
+with the backbone feature maps already resident in HBM.  Workload = BASELINE
+configs[1]: batch of 8 pairs, 640x640 (20x20 = 400 tokens per image), fp32.
+With N > 1 (torchrun, one rank per GPU) every rank runs its own batch of 8
+(weak scaling) and each step ends with the RCCL all-gather of the per-pair
+boxes - the only collective on the path.
+
+Rank 0 prints ONE JSON line (see README/DESIGN.md §6 for the fields).
+``roofline`` describes the dominant kernel (k_encoder<B,A>, 7 of the 13
+launches of a step): durations come from HIP events recorded by the library
+on its launch stream during the timed region.  ``cpu_baseline`` is the oracle
+(torch CPU restatement of the reference) timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+PAIR_GFLOP_640 = 8.365            # BASELINE.md §4, hot path per 640x640 pair
+ENC_FLOP_PER_TOKEN = 16 * 256 * 256 + 4 * 256 * 32   # one B;A launch
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+DOMINANT = 'k_encoder<B,A>'
+
+
+def synthetic_inputs(pairs, size, device):
+    """Random-init weights of the architecture + uniform features with the
+    spread of the real extraction path (std ~0.29).  No oracle involved."""
+    import imagematching_oetr_amd as pkg
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    weights = {k: v.detach().clone() for k, v in model.hot_path_state().items()}
+    hf = size // 32
+    g = torch.Generator().manual_seed(1 + int(os.environ.get('RANK', 0)))
+    feat1 = (torch.rand(pairs, 256, hf, hf, generator=g) - 0.5).to(device)
+    feat2 = (torch.rand(pairs, 256, hf, hf, generator=g) - 0.5).to(device)
+    pos = model.pos_encoding(feat1.cpu()).contiguous().to(device)
+    return model, weights, feat1, feat2, pos, hf
+
+
+def cpu_baseline(weights, feat1, feat2, size, budget_s=12.0):
+    """The oracle timed on the host cores (bounded sample, rank 0 only)."""
+    from oracle import oetr_oracle as orc
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    f1, f2 = feat1.cpu(), feat2.cpu()
+    w = {k: v.cpu() for k, v in weights.items()}
+    for _ in range(2):
+        boxes = orc.hot_path(f1, f2, w, (size, size), (size, size))
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        orc.hot_path(f1, f2, w, (size, size), (size, size))
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or iters >= 200:
+            break
+    return dict(value=round(f1.shape[0] * iters / dt, 2), unit='image-pairs/s',
+                cores=torch.get_num_threads(), kind='port',
+                sample=f'{iters} batches of {f1.shape[0]} pairs @ {size}x{size} '
+                       f'(hot path only, features precomputed) in {dt:.1f} s; '
+                       f'oracle/oetr_oracle.py on torch CPU, {threads} threads'), boxes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--pairs-per-gpu', type=int, default=8)
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true')
+    ap.add_argument('--no-trace', action='store_true',
+                    help='do not record per-kernel events in the timed region')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus and rank == 0:
+        print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with '
+              f'torchrun --nproc-per-node {args.gpus}', file=sys.stderr)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    import imagematching_oetr_amd as pkg
+    from imagematching_oetr_amd.parallel import gather_boxes
+    torch.set_grad_enabled(False)
+    n = args.pairs_per_gpu
+    model, weights, feat1, feat2, pos, hf = synthetic_inputs(n, args.size, device)
+    eng = pkg.HotPathEngine(weights, device=device)
+    hw = (args.size, args.size)
+    n_total = n * world
+
+    def step():
+        b1, b2 = eng.forward(feat1, feat2, pos, pos, hw, hw)
+        if world > 1:
+            # every rank holds the same number of pairs: plain padded all-gather
+            b1, b2 = gather_boxes(b1, b2, n_total)
+        return b1, b2
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        boxes = step()
+    trace = None if args.no_trace else pkg.KernelTrace(
+        eng, max_launches=16 * args.steps + 64)
+    barrier()
+    if trace:
+        trace.__enter__()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        boxes = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if trace:
+        trace.__exit__()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern = trace.summary() if trace else {}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_step = elapsed / args.steps * 1e3
+    value = n_total * args.steps / elapsed
+    out = {
+        'metric': f'image-pairs/sec @{args.size}x{args.size} (OETR hot path: '
+                  'feature correlation + overlap regression, features resident in HBM)',
+        'value': round(value, 1), 'unit': 'image-pairs/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[1]: batch={n} pairs/GPU, '
+                               f'{args.size}x{args.size} -> {hf}x{hf} tokens/image, '
+                               'C=256, 8 enc + 2 dec layers, fp32',
+                   'pairs_per_gpu': n, 'global_pairs': n_total,
+                   'tokens_per_image': hf * hf,
+                   'parallelism': f'pairs sharded over {world} rank(s); '
+                                  'all-gather of boxes only'},
+        'hot_path_tflops': round(value * PAIR_GFLOP_640 * (args.size / 640) ** 2 / 1e3, 2),
+    }
+    if kern and DOMINANT in kern:
+        launches, total_ms = kern[DOMINANT]
+        avg_ms = total_ms / launches
+        flop = ENC_FLOP_PER_TOKEN * 2 * n * hf * hf     # tokens of both sides
+        ach = flop / (avg_ms * 1e-3) / 1e12
+        out['roofline'] = {
+            'kernel': DOMINANT, 'bound': 'mfma', 'achieved': round(ach, 2),
+            'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'avg_launch_us': round(avg_ms * 1e3, 2), 'launches': launches,
+            'flop_per_launch': flop,
+            'share_of_step': round(total_ms / (ms_step * args.steps), 4)}
+        out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
+                             for k, v in kern.items()}
+    if not args.no_cpu_baseline:
+        base, ref_boxes = cpu_baseline(weights, feat1, feat2, args.size)
+        out['cpu_baseline'] = base
+        from oracle import oetr_oracle as orc
+        mine = eng.forward(feat1, feat2, pos, pos, hw, hw)
+        iou = torch.cat([orc.bbox_iou_aligned(mine[0].cpu(), ref_boxes[0]),
+                         orc.bbox_iou_aligned(mine[1].cpu(), ref_boxes[1])])
+        out['iou_vs_cpu_min'] = round(float(iou.min()), 6)
+        out['speedup_vs_cpu'] = round(value / base['value'], 1)
+    if not args.no_e2e:
+        try:     # whole forward_dummy incl. the PyTorch/MIOpen backbone (host code)
+            model = model.to(device)
+            g = torch.Generator().manual_seed(2)
+            im1 = torch.rand(n, args.size, args.size, 3, generator=g).to(device)
+            im2 = torch.rand(n, args.size, args.size, 3, generator=g).to(device)
+            for _ in range(3):
+                model.forward_dummy(im1, im2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                model.forward_dummy(im1, im2)
+            torch.cuda.synchronize()
+            out['end_to_end_pairs_per_s'] = round(n * reps / (time.perf_counter() - t1), 1)
+        except Exception as e:  # host-side extras must never break the bench line
+            out['end_to_end_error'] = repr(e)[:200]
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -70,7 +70,21 @@ struct Packer {
 
 }  // namespace
 
+enum KernelId { K_PREP, K_ENC_A, K_ENC_BA, K_ENC_BDEC, K_ENC_B, K_DECODER, K_HEAT_CONV,
+                K_HEAT_FINAL, K_SIZE_REG, K_BOXES, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {
+    "k_prep_tokens", "k_encoder<A>", "k_encoder<B,A>", "k_encoder<B,dec>", "k_encoder<B>",
+    "k_decoder", "k_heat_conv", "k_heat_final", "k_size_reg", "k_boxes"};
+
+struct oetr_trace {
+  std::vector<hipEvent_t> ev;  // 2 per launch
+  std::vector<int> kid;
+  int used = 0;                // launches recorded
+  int dropped = 0;
+};
+
 struct oetr_ctx {
+  oetr_trace* trace = nullptr;
   int device = 0;
   float* dev = nullptr;  // all repacked weights
   size_t dev_floats = 0;
@@ -157,18 +171,36 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   return p;
 }
 
+// Brackets one kernel launch with two events when a trace is attached.
+struct Scoped {
+  oetr_trace* t; hipStream_t s; int slot;
+  Scoped(oetr_ctx* h, hipStream_t s_, int kid) : t(h ? h->trace : nullptr), s(s_), slot(-1) {
+    if (!t) return;
+    if (2 * (t->used + 1) > (int)t->ev.size()) { t->dropped++; t = nullptr; return; }
+    slot = t->used++;
+    t->kid[slot] = kid;
+    (void)hipEventRecord(t->ev[2 * slot], s);
+  }
+  ~Scoped() { if (t) (void)hipEventRecord(t->ev[2 * slot + 1], s); }
+};
+#define TRACED(h, s, kid, expr)            \
+  do {                                     \
+    Scoped sc__(h, s, kid);                \
+    HIP_TRY(expr);                         \
+  } while (0)
+
 // Encoder (+ decoder) shared by forward and feature_correlation.
 oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, const float* feat1,
                             const float* feat2, const float* pos1, const float* pos2,
                             int enc_layers, hipStream_t s) {
-  HIP_TRY(launch_prep_tokens(g, feat1, feat2, pos1, pos2, w.x, w.pos, s));
+  TRACED(h, s, K_PREP, launch_prep_tokens(g, feat1, feat2, pos1, pos2, w.x, w.pos, s));
   EncLaunch p;
   memset(&p, 0, sizeof(p));
   p.g = g;
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
   p.a = h->enc[0];
   p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];
-  HIP_TRY(launch_encoder(p, false, 0, s));
+  TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, s));
   for (int l = 0; l < enc_layers; ++l) {
     p.b = h->enc[l];
     p.b_cross = l & 1;
@@ -185,7 +217,8 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
     } else {
       tail = 2;
     }
-    HIP_TRY(launch_encoder(p, true, tail, s));
+    TRACED(h, s, tail == 0 ? K_ENC_BA : tail == 1 ? K_ENC_BDEC : K_ENC_B,
+           launch_encoder(p, true, tail, s));
   }
   if (enc_layers == OETR_N_ENC) {
     DecLaunch d;
@@ -197,7 +230,7 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
       d.dks[i] = w.dks[i];
     }
     d.hs = w.hs;
-    HIP_TRY(launch_decoder(d, s));
+    TRACED(h, s, K_DECODER, launch_decoder(d, s));
   }
   return OETR_OK;
 }
@@ -288,14 +321,14 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
                t2b = pk.copy(w->tlbr2_b, 4);
 
   int prev = 0;
-  hipGetDevice(&prev);
+  (void)hipGetDevice(&prev);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc(&h->dev, pk.buf.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(h->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
-  hipSetDevice(prev);
+  (void)hipSetDevice(prev);
   if (e != hipSuccess) {
-    if (h->dev) hipFree(h->dev);
+    if (h->dev) (void)hipFree(h->dev);
     delete h;
     return hip_fail(e, "oetr_create: uploading weights");
   }
@@ -338,10 +371,10 @@ void oetr_destroy(oetr_handle h) {
   if (!h) return;
   if (h->dev) {
     int prev = 0;
-    hipGetDevice(&prev);
-    hipSetDevice(h->device);
-    hipFree(h->dev);
-    hipSetDevice(prev);
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->dev);
+    (void)hipSetDevice(prev);
   }
   delete h;
 }
@@ -399,11 +432,11 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
   float* tl1 = w.tlbr;
   float* tl2 = w.tlbr + 4 * g.N;
   HeatLaunch hp = heat_launch(h, g, w, w.x, w.x + r1 * C, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
-  HIP_TRY(launch_heat_conv(hp, s));
-  HIP_TRY(launch_heat_final(hp, s));
-  HIP_TRY(launch_size_regression(h->heads, hs1, hs2, g.N, tl1, tl2, s));
-  HIP_TRY(launch_boxes(cxy1, tl1, g.N, img_h1, img_w1, box1, s));
-  HIP_TRY(launch_boxes(cxy2, tl2, g.N, img_h2, img_w2, box2, s));
+  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, s));
+  TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));
+  TRACED(h, s, K_SIZE_REG, launch_size_regression(h->heads, hs1, hs2, g.N, tl1, tl2, s));
+  TRACED(h, s, K_BOXES, launch_boxes(cxy1, tl1, g.N, img_h1, img_w1, box1, s));
+  TRACED(h, s, K_BOXES, launch_boxes(cxy2, tl2, g.N, img_h2, img_w2, box2, s));
   if (st) {
     if ((rc = copy_out(st->hs1, hs1, (size_t)g.N * C, s))) return rc;
     if ((rc = copy_out(st->hs2, hs2, (size_t)g.N * C, s))) return rc;
@@ -466,8 +499,8 @@ oetr_status oetr_center_estimation(oetr_handle h, const float* hs1, const float*
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HeatLaunch hp = heat_launch(h, g, w, memory1, memory2, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
-  HIP_TRY(launch_heat_conv(hp, s));
-  HIP_TRY(launch_heat_final(hp, s));
+  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, s));
+  TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));
   return OETR_OK;
 }
 
@@ -501,6 +534,54 @@ oetr_status oetr_full_attention(const float* q, const float* k, const float* v, 
   if (!q || !k || !v || !out || n <= 0 || L <= 0 || S <= 0)
     return fail(OETR_ERR_BAD_ARG, "oetr_full_attention: bad argument");
   HIP_TRY(launch_full_attention(q, k, v, n, L, S, out, static_cast<hipStream_t>(stream)));
+  return OETR_OK;
+}
+
+oetr_status oetr_trace_create(int max_launches, oetr_trace_handle* out) {
+  if (!out || max_launches <= 0) return fail(OETR_ERR_BAD_ARG, "oetr_trace_create: bad argument");
+  oetr_trace* t = new oetr_trace();
+  t->ev.resize(2 * (size_t)max_launches);
+  t->kid.resize(max_launches);
+  for (auto& e : t->ev) {
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) { delete t; return hip_fail(rc, "hipEventCreate"); }
+  }
+  *out = t;
+  return OETR_OK;
+}
+
+void oetr_trace_destroy(oetr_trace_handle t) {
+  if (!t) return;
+  for (auto& e : t->ev) (void)hipEventDestroy(e);
+  delete t;
+}
+
+oetr_status oetr_set_trace(oetr_handle h, oetr_trace_handle t) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_trace: NULL handle");
+  h->trace = t;
+  return OETR_OK;
+}
+
+oetr_status oetr_trace_summary(oetr_trace_handle t, int* n_kernels,
+                               const char* names[OETR_TRACE_MAX_KERNELS],
+                               int launches[OETR_TRACE_MAX_KERNELS],
+                               float total_ms[OETR_TRACE_MAX_KERNELS]) {
+  if (!t || !n_kernels || !names || !launches || !total_ms)
+    return fail(OETR_ERR_BAD_ARG, "oetr_trace_summary: NULL argument");
+  static_assert(K_COUNT <= OETR_TRACE_MAX_KERNELS, "raise OETR_TRACE_MAX_KERNELS");
+  for (int i = 0; i < K_COUNT; ++i) { names[i] = kKernelNames[i]; launches[i] = 0; total_ms[i] = 0.f; }
+  for (int i = 0; i < t->used; ++i) {
+    HIP_TRY(hipEventSynchronize(t->ev[2 * i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev[2 * i], t->ev[2 * i + 1]));
+    launches[t->kid[i]]++;
+    total_ms[t->kid[i]] += ms;
+  }
+  *n_kernels = K_COUNT;
+  const int dropped = t->dropped;
+  t->used = 0;
+  t->dropped = 0;
+  if (dropped) return fail(OETR_ERR_BAD_ARG, std::to_string(dropped) + " launches not traced: pool too small");
   return OETR_OK;
 }
 

@@ -80,7 +80,7 @@ hipError_t launch_linear_attention(const float* q, const float* k, const float* 
   // The stand-alone test entry keeps a small device scratch (n*8 states of 1056 floats).
   const size_t need = (size_t)n * NH * (HD * HD + HD);
   if (need > g_lin_state_floats) {
-    if (g_lin_state) hipFree(g_lin_state);
+    if (g_lin_state) (void)hipFree(g_lin_state);
     hipError_t e = hipMalloc(&g_lin_state, need * sizeof(float));
     if (e != hipSuccess) { g_lin_state = nullptr; g_lin_state_floats = 0; return e; }
     g_lin_state_floats = need;

@@ -58,7 +58,8 @@ EXPORTS = (
     'oetr_workspace_bytes', 'oetr_forward', 'oetr_forward_stages',
     'oetr_feature_correlation', 'oetr_center_estimation',
     'oetr_size_regression', 'oetr_box_tlbr_to_xyxy', 'oetr_linear_attention',
-    'oetr_full_attention')
+    'oetr_full_attention', 'oetr_trace_create', 'oetr_trace_destroy',
+    'oetr_set_trace', 'oetr_trace_summary')
 
 
 def hot_path_keys():
@@ -137,6 +138,15 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.restype = i
         fn.argtypes = [vp, vp, vp, i, i, i, vp, vp]
+    lib.oetr_trace_create.restype = i
+    lib.oetr_trace_create.argtypes = [i, C.POINTER(vp)]
+    lib.oetr_trace_destroy.restype = None
+    lib.oetr_trace_destroy.argtypes = [vp]
+    lib.oetr_set_trace.restype = i
+    lib.oetr_set_trace.argtypes = [vp, vp]
+    lib.oetr_trace_summary.restype = i
+    lib.oetr_trace_summary.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_char_p),
+                                       C.POINTER(i), C.POINTER(C.c_float)]
     if lib.oetr_abi_version() != ABI_VERSION:
         raise RuntimeError(f'{p}: ABI version {lib.oetr_abi_version()} != '
                            f'{ABI_VERSION}')
@@ -361,6 +371,48 @@ class HotPathEngine:
                 self._h, hs1.data_ptr(), hs2.data_ptr(), n, t1.data_ptr(),
                 t2.data_ptr(), _stream()), 'oetr_size_regression')
         return t1, t2
+
+
+class KernelTrace:
+    """Measurement hook (bench/profiling): per-kernel GPU durations from HIP
+    events recorded on the launch stream (``oetr_trace_*`` in the header)."""
+
+    MAX_KERNELS = 16
+
+    def __init__(self, engine, max_launches=4096):
+        self.lib, self.engine = engine.lib, engine
+        self._t = C.c_void_p()
+        _check(self.lib, self.lib.oetr_trace_create(int(max_launches),
+                                                    C.byref(self._t)),
+               'oetr_trace_create')
+
+    def __enter__(self):
+        _check(self.lib, self.lib.oetr_set_trace(self.engine._h, self._t),
+               'oetr_set_trace')
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.oetr_set_trace(self.engine._h, None)
+
+    def summary(self):
+        """{kernel name: (launches, total_ms)} since the last call."""
+        n = C.c_int()
+        names = (C.c_char_p * self.MAX_KERNELS)()
+        launches = (C.c_int * self.MAX_KERNELS)()
+        ms = (C.c_float * self.MAX_KERNELS)()
+        _check(self.lib, self.lib.oetr_trace_summary(self._t, C.byref(n), names,
+                                                     launches, ms),
+               'oetr_trace_summary')
+        return {names[k].decode(): (launches[k], ms[k]) for k in range(n.value)
+                if launches[k]}
+
+    def __del__(self):
+        t, self._t = getattr(self, '_t', None), None
+        if t:
+            try:
+                self.lib.oetr_trace_destroy(t)
+            except Exception:
+                pass
 
 
 def box_tlbr_to_xyxy(cxy, tlbr, max_h, max_w):

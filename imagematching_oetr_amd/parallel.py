@@ -1,0 +1,77 @@
+"""Multi-GPU use of the hot path: one process per GPU, image pairs sharded
+contiguously over ranks, weights replicated, and ONE collective per batch -
+the all-gather of the per-pair boxes (32 B per pair) over RCCL/xGMI.
+
+The reference has no inference-time multi-GPU code (its only distributed code
+is training DDP, ``train.py:59-74``); pairs are independent (no cross-pair
+term anywhere in reference ``src/model.py:229-252``), so there is no exchange
+inside the forward.  The gather is latency-bound (N=64 pairs
+-> 2 KiB in total): one padded ``all_gather_into_tensor`` call, no bucketing.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_pairs, rank, world_size):
+    """Contiguous [lo, hi) slice of ``n_pairs`` owned by ``rank``; the first
+    ``n_pairs % world_size`` ranks hold one extra pair."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f'rank {rank} outside world of {world_size}')
+    base, extra = divmod(n_pairs, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def bucket_by_shape(shapes):
+    """Group pair indices by (image1 shape, image2 shape) so that every rank
+    runs equal work on mixed-scale batches (BASELINE configs[4]).  Returns
+    {shape_key: [indices]} in first-seen order."""
+    buckets = {}
+    for i, key in enumerate(shapes):
+        buckets.setdefault(tuple(key), []).append(i)
+    return buckets
+
+
+def gather_boxes(box1, box2, n_pairs, group=None):
+    """All-gather this rank's ``[n_local,4]`` boxes into the full
+    ``([n_pairs,4], [n_pairs,4])`` in shard order.  Works on any backend
+    (RCCL on GPUs, gloo on CPU tensors in tests)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return box1, box2
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(n_pairs, rank, world)
+    if box1.shape[0] != hi - lo or box2.shape[0] != hi - lo:
+        raise ValueError(f'rank {rank} holds {box1.shape[0]} pairs, expected '
+                         f'{hi - lo} of {n_pairs}')
+    cap = -(-n_pairs // world)                       # ceil: padded shard size
+    mine = torch.zeros(cap, 2, 4, dtype=box1.dtype, device=box1.device)
+    mine[:hi - lo, 0] = box1
+    mine[:hi - lo, 1] = box2
+    everyone = torch.empty(world * cap, 2, 4, dtype=box1.dtype,
+                           device=box1.device)
+    if dist.get_backend(group) == 'gloo':
+        parts = list(everyone.view(world, cap, 2, 4).unbind(0))
+        dist.all_gather(parts, mine, group=group)
+        everyone = torch.stack(parts).view(world * cap, 2, 4)
+    else:
+        dist.all_gather_into_tensor(everyone, mine, group=group)
+    keep = torch.cat([
+        torch.arange(r * cap, r * cap + (shard_bounds(n_pairs, r, world)[1]
+                                         - shard_bounds(n_pairs, r, world)[0]))
+        for r in range(world)]).to(everyone.device)
+    full = everyone.index_select(0, keep)
+    return full[:, 0].contiguous(), full[:, 1].contiguous()
+
+
+@torch.no_grad()
+def forward_sharded(model, image1, image2, group=None):
+    """``model.forward_dummy`` on this rank's contiguous shard of the batch,
+    then the box all-gather: every rank returns boxes for ALL pairs."""
+    n = image1.shape[0]
+    if dist.is_available() and dist.is_initialized():
+        lo, hi = shard_bounds(n, dist.get_rank(group), dist.get_world_size(group))
+    else:
+        lo, hi = 0, n
+    b1, b2 = model.forward_dummy(image1[lo:hi], image2[lo:hi])
+    return gather_boxes(b1, b2, n, group)

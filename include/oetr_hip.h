@@ -186,7 +186,8 @@ oetr_status oetr_box_tlbr_to_xyxy(const float *cxy, const float *tlbr, int n,
 /* Replaces: LinearAttention.forward (reference
  * src/models/linear_attention.py:22-50), masks None.  Stand-alone entry for
  * parity tests of the attention core.  q [N][L][8][32], k,v [N][S][8][32],
- * out [N][L][8][32]. */
+ * out [N][L][8][32].  (Unlike the forward entry points this test entry keeps
+ * a lazily grown internal scratch of n*8 states: not graph-capturable.) */
 oetr_status oetr_linear_attention(const float *q, const float *k,
                                   const float *v, int n, int L, int S,
                                   float *out, void *stream);
@@ -196,6 +197,25 @@ oetr_status oetr_linear_attention(const float *q, const float *k,
  * "all-pairs QK^T volume" variant, never materialised in HBM.  Same shapes. */
 oetr_status oetr_full_attention(const float *q, const float *k, const float *v,
                                 int n, int L, int S, float *out, void *stream);
+
+/* ---- measurement hook (bench.py / profiling only) -------------------------
+ * A trace owns a pool of HIP events.  While attached to a handle, every
+ * kernel launched by the forward entry points is bracketed by two events
+ * recorded on the SAME stream the kernel is launched on (so the durations are
+ * GPU-side, independent of torch's current stream).  Attaching mutates the
+ * handle: do it from one thread, outside concurrent forward calls.
+ * oetr_trace_summary synchronises on the recorded events and returns, per
+ * kernel id, its name, number of launches and summed duration; it then resets
+ * the pool.  Nothing like this exists in the reference. */
+typedef struct oetr_trace *oetr_trace_handle;
+#define OETR_TRACE_MAX_KERNELS 16
+oetr_status oetr_trace_create(int max_launches, oetr_trace_handle *out);
+void oetr_trace_destroy(oetr_trace_handle t);
+oetr_status oetr_set_trace(oetr_handle h, oetr_trace_handle t /* NULL detaches */);
+oetr_status oetr_trace_summary(oetr_trace_handle t, int *n_kernels,
+                               const char *names[OETR_TRACE_MAX_KERNELS],
+                               int launches[OETR_TRACE_MAX_KERNELS],
+                               float total_ms[OETR_TRACE_MAX_KERNELS]);
 
 #ifdef __cplusplus
 }

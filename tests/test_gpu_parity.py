@@ -1,0 +1,260 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle and the
+golden vectors captured from the reference.  Run with `-m gpu` on an MI355X.
+
+Tolerances (fp32, north_star: boxes within 1e-3 IoU):
+  the oracle's own fp32-vs-fp64 drift is ~8e-6 on memory (|x|<=13), 1.5e-4 px
+  on cxy (tests/test_oracle_golden.py::test_fp64_mode_bounds_fp32_drift); a
+  different-but-valid fp32 summation order lands within a few of those, so
+    memory / encoder outputs : 2e-4 abs (values up to ~13)
+    hs                       : 1e-4 abs
+    logits                   : 1e-3 abs
+    cxy                      : 1e-2 px
+    tlbr                     : 1e-5
+    boxes                    : 2e-2 px and IoU >= 1 - 1e-3
+"""
+import glob
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oetr_oracle as orc
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+TOL = dict(memory=2e-4, hs=1e-4, logits=1e-3, cxy=1e-2, tlbr=1e-5, box=2e-2)
+HOT = sorted(glob.glob(str(Path(__file__).parent / 'golden' / 'hot_*.npz')))
+
+
+def maxerr(a, b):
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(a).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(b).double()
+    return float((a - b).abs().max())
+
+
+def check_stages(out, ref, note=''):
+    for s in ('1', '2'):
+        for key in ('memory', 'hs', 'logits', 'cxy', 'tlbr', 'box'):
+            e = maxerr(out[key + s].reshape(ref[key + s].shape), ref[key + s])
+            assert e <= TOL[key], f'{note} {key}{s}: max err {e:.3e} > {TOL[key]:.1e}'
+        b_hip, b_ref = out['box' + s].cpu(), ref['box' + s]
+        area = (b_ref[:, 2] - b_ref[:, 0]) * (b_ref[:, 3] - b_ref[:, 1])
+        iou = orc.bbox_iou_aligned(b_hip, b_ref)
+        assert (iou[area > 1] >= 1 - 1e-3).all(), f'{note} IoU {iou}'
+
+
+@pytest.fixture(scope='module')
+def engines(gpu):
+    from imagematching_oetr_amd import HotPathEngine
+    cache = {}
+
+    def get(seed, sharpen):
+        key = (seed, sharpen)
+        if key not in cache:
+            cache[key] = HotPathEngine(orc.make_hot_weights(seed, sharpen=sharpen),
+                                       device=gpu)
+        return cache[key]
+    return get
+
+
+def test_extension_is_loaded_from_the_tree(gpu):
+    from imagematching_oetr_amd import hip_engine
+    hip_engine.load_library()
+    maps = Path('/proc/self/maps').read_text()
+    assert 'imagematching_oetr_amd/csrc/liboetr_hip.so' in maps
+
+
+@pytest.mark.parametrize('path', HOT, ids=lambda p: p.split('hot_')[-1][:-4])
+def test_hot_path_vs_reference_golden_and_oracle(path, gpu, engines):
+    from tests.test_oracle_golden import load_hot_case
+    g, w, f1, f2 = load_hot_case(path)
+    im1, im2 = tuple(int(v) for v in g['img1']), tuple(int(v) for v in g['img2'])
+    p1 = orc.position_table(*g['grid1'])
+    p2 = orc.position_table(*g['grid2'])
+    eng = engines(int(g['weight_seed']), bool(g['sharpen']))
+    dev = [t.to(gpu) for t in (f1, f2, p1, p2)]
+    out = eng.forward(*dev, im1, im2, stages=True)
+    ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
+    check_stages(out, ref, 'vs oracle')
+    # ... and directly against what the reference itself produced
+    for s in ('1', '2'):
+        step = int(g[f'memory{s}_step'])
+        assert maxerr(out['memory' + s][:, ::step], g['memory' + s]) <= TOL['memory']
+        assert maxerr(out['hs' + s], g['hs' + s]) <= TOL['hs']
+        assert maxerr(out['logits' + s], g['logits' + s]) <= TOL['logits']
+        assert maxerr(out['cxy' + s], g['cxy' + s]) <= TOL['cxy']
+        assert maxerr(out['tlbr' + s], g['tlbr' + s]) <= TOL['tlbr']
+        assert maxerr(out['box' + s], g['box' + s]) <= TOL['box']
+    # encoder prefixes: after layer 0 (self) and layer 1 (cross)
+    for li in (0, 1):
+        pre = eng.forward(*dev, im1, im2, stages=True, enc_layers=li + 1)
+        for s in ('1', '2'):
+            step = int(g[f'enc{li}_x{s}_step'])
+            e = maxerr(pre['memory' + s][:, ::step], g[f'enc{li}_x{s}'])
+            assert e <= TOL['memory'], f'enc{li} x{s}: {e:.3e}'
+    # plain forward == staged forward, bit for bit; and repeatable
+    b1, b2 = eng.forward(*dev, im1, im2)
+    assert torch.equal(b1, out['box1']) and torch.equal(b2, out['box2'])
+    b1b, _ = eng.forward(*dev, im1, im2)
+    assert torch.equal(b1, b1b)
+
+
+def test_full_forward_golden_boxes(gpu, engines, golden_dir):
+    """Boxes the reference's forward_dummy produced from 640x640 images."""
+    g = np.load(golden_dir / 'full_640.npz')
+    eng = engines(int(g['weight_seed']), True)
+    t = [torch.from_numpy(g[k]).to(gpu) for k in ('feat1', 'feat2', 'pos1', 'pos2')]
+    b1, b2 = eng.forward(*t, (640, 640), (640, 640))
+    assert maxerr(b1, g['box1']) <= TOL['box'] and maxerr(b2, g['box2']) <= TOL['box']
+    iou = orc.bbox_iou_aligned(torch.cat([b1, b2]).cpu(),
+                               torch.from_numpy(np.concatenate([g['box1'], g['box2']])))
+    assert (iou >= 1 - 1e-3).all()
+
+
+def test_inner_seams_match_the_fused_forward(gpu, engines):
+    """feature_correlation / center_estimation / size_regression /
+    box_tlbr_to_xyxy entry points (reference src/model.py:132-191)."""
+    from imagematching_oetr_amd import box_tlbr_to_xyxy
+    w = orc.make_hot_weights(1, sharpen=True)
+    eng = engines(1, True)
+    f1, f2 = orc.make_features(21, 3, 12, 17), orc.make_features(22, 3, 9, 30)
+    p1, p2 = orc.position_table(12, 17), orc.position_table(9, 30)
+    im1, im2 = (384, 544), (288, 960)
+    dev = [t.to(gpu) for t in (f1, f2, p1, p2)]
+    ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
+    hs1, hs2, m1, m2 = eng.feature_correlation(*dev)
+    assert hs1.shape == (3, 1, 256) and m2.shape == (3, 270, 256)
+    assert maxerr(m1, ref['memory1']) <= TOL['memory']
+    assert maxerr(hs2, ref['hs2']) <= TOL['hs']
+    c1, c2 = eng.center_estimation(hs1, hs2, m1, m2, 12, 17, 9, 30, im1[0], im2[0])
+    t1, t2 = eng.size_regression(hs1, hs2)
+    assert maxerr(c1, ref['cxy1']) <= TOL['cxy'] and maxerr(c2, ref['cxy2']) <= TOL['cxy']
+    assert maxerr(t1, ref['tlbr1']) <= TOL['tlbr']
+    b2 = box_tlbr_to_xyxy(c2, t2, *im2)
+    assert maxerr(b2, ref['box2']) <= TOL['box']
+    # heads fed with the ORACLE's hs/memory isolate the head kernels
+    c1o, _ = eng.center_estimation(ref['hs1'].to(gpu), ref['hs2'].to(gpu),
+                                   ref['memory1'].to(gpu), ref['memory2'].to(gpu),
+                                   12, 17, 9, 30, im1[0], im2[0])
+    assert maxerr(c1o, ref['cxy1']) <= 2e-3
+
+
+def test_box_kernel_matches_reference_vectors(gpu, golden_dir):
+    from imagematching_oetr_amd import box_tlbr_to_xyxy
+    g = np.load(golden_dir / 'misc.npz')
+    b = box_tlbr_to_xyxy(torch.from_numpy(g['cxy']).to(gpu),
+                         torch.from_numpy(g['tlbr']).to(gpu), 480, 640)
+    assert maxerr(b, g['boxes_480x640']) <= 1e-4
+
+
+def test_attention_cores_vs_reference_golden(gpu, golden_dir):
+    from imagematching_oetr_amd import full_attention, linear_attention
+    g = np.load(golden_dir / 'attention.npz')
+    for (L, S) in g['cases']:
+        tag = f'L{L}_S{S}'
+        gen = torch.Generator().manual_seed(int(g[tag + '_seed']))
+        q = (torch.rand(2, L, 8, 32, generator=gen) - 0.5) * 4
+        k = (torch.rand(2, S, 8, 32, generator=gen) - 0.5) * 4
+        v = (torch.rand(2, S, 8, 32, generator=gen) - 0.5) * 2
+        step = int(g[tag + '_step'])
+        lin = linear_attention(q.to(gpu), k.to(gpu), v.to(gpu)).reshape(2, L, 256)
+        full = full_attention(q.to(gpu), k.to(gpu), v.to(gpu)).reshape(2, L, 256)
+        assert maxerr(lin[:, ::step], g[tag + '_lin']) <= 2e-6, tag
+        assert maxerr(full[:, ::step], g[tag + '_full']) <= 5e-6, tag
+
+
+@pytest.mark.parametrize('n,g1,g2', [
+    (1, (1, 1), (1, 1)),          # single token per image
+    (1, (1, 7), (33, 1)),         # degenerate grids, tile tail of 1
+    (5, (4, 8), (8, 4)),          # exactly one full tile
+    (2, (7, 11), (50, 50)),       # 77 vs 2500 tokens
+    (1, (100, 100), (3, 3)),      # maximum grid (NECK.MAX_SHAPE)
+])
+def test_edge_shapes(n, g1, g2, gpu, engines):
+    w = orc.make_hot_weights(0)
+    eng = engines(0, False)
+    f1, f2 = orc.make_features(31, n, *g1), orc.make_features(32, n, *g2)
+    p1, p2 = orc.position_table(*g1), orc.position_table(*g2)
+    im1, im2 = (g1[0] * 32, g1[1] * 32), (g2[0] * 32, g2[1] * 32)
+    out = eng.forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p2.to(gpu), im1, im2,
+                      stages=True)
+    ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
+    check_stages(out, ref, f'{n} {g1} {g2}')
+
+
+def test_error_paths(gpu, engines):
+    from imagematching_oetr_amd import OetrError
+    eng = engines(0, False)
+    f = orc.make_features(1, 1, 4, 4).to(gpu)
+    p = orc.position_table(4, 4).to(gpu)
+    with pytest.raises(OetrError, match='GPU'):
+        eng.forward(f.cpu(), f, p, p, (128, 128), (128, 128))
+    with pytest.raises(ValueError):
+        eng.forward(f, f, orc.position_table(4, 5).to(gpu), p, (128, 128), (128, 128))
+    with pytest.raises(ValueError):
+        eng.forward(f.double(), f, p, p, (128, 128), (128, 128))
+    big = torch.zeros(1, 256, 101, 100, device=gpu)
+    with pytest.raises(ValueError, match='invalid shape'):
+        eng.forward(big, f, torch.zeros(1, 256, 101, 100, device=gpu), p,
+                    (3232, 3200), (128, 128))
+
+
+def test_properties_at_bench_size(gpu, engines):
+    """N=8, 640x640 (BASELINE configs[1]): size-independent properties.
+    Pairs are independent, so permuting / slicing the batch permutes / slices
+    the boxes bit-exactly; swapping the two sides with the query embeddings
+    untouched is NOT symmetric, so only per-side checks are made."""
+    eng = engines(3, True)
+    n = 8
+    f1, f2 = orc.make_features(41, n, 20, 20).to(gpu), orc.make_features(42, n, 20, 20).to(gpu)
+    p = orc.position_table(20, 20).to(gpu)
+    b1, b2 = eng.forward(f1, f2, p, p, (640, 640), (640, 640))
+    perm = torch.tensor([3, 7, 0, 5, 1, 6, 2, 4], device=gpu)
+    c1, c2 = eng.forward(f1[perm], f2[perm], p, p, (640, 640), (640, 640))
+    assert torch.equal(c1, b1[perm]) and torch.equal(c2, b2[perm])
+    d1, d2 = eng.forward(f1[2:5], f2[2:5], p, p, (640, 640), (640, 640))
+    assert torch.equal(d1, b1[2:5]) and torch.equal(d2, b2[2:5])
+    for b in (b1, b2):
+        assert torch.isfinite(b).all()
+        assert (b >= 0).all() and (b <= 640).all()
+        assert (b[:, 2] >= b[:, 0]).all() and (b[:, 3] >= b[:, 1]).all()
+    # and the oracle agrees at this size too
+    w = orc.make_hot_weights(3, sharpen=True)
+    r1, r2 = orc.hot_path(f1.cpu(), f2.cpu(), w, (640, 640), (640, 640))
+    assert (orc.bbox_iou_aligned(b1.cpu(), r1) >= 1 - 1e-3).all()
+    assert (orc.bbox_iou_aligned(b2.cpu(), r2) >= 1 - 1e-3).all()
+
+
+def test_drop_in_module_forward_dummy(gpu):
+    """OETR.forward_dummy on images: host backbone (torch/MIOpen) + HIP hot
+    path, vs the same backbone features pushed through the oracle."""
+    import imagematching_oetr_amd as pkg
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    sd = model.state_dict()
+    w = orc.make_hot_weights(5, sharpen=True)
+    sd.update(w)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    g = torch.Generator().manual_seed(6)
+    im1 = torch.rand(2, 256, 320, 3, generator=g).to(gpu)
+    im2 = torch.rand(2, 320, 256, 3, generator=g).to(gpu)
+    b1, b2 = model.forward_dummy(im1, im2)
+    f1, f2, p1, p2, *_ = model.feature_extraction(im1, im2)
+    r1, r2 = orc.hot_path(f1.cpu(), f2.cpu(), w, (256, 320), (320, 256),
+                          pos1=p1.cpu(), pos2=p2.cpu())
+    assert b1.shape == (2, 4) and b1.device.type == 'cuda'
+    assert maxerr(b1, r1) <= TOL['box'] and maxerr(b2, r2) <= TOL['box']
+    # reference seams on the module
+    hs1, hs2, m1, m2 = model.feature_correlation(f1, f2, p1, p2, None, None)
+    c1, c2 = model.center_estimation(hs1, hs2, m1, m2, 8, 10, 10, 8, None, None)
+    t1, t2 = model.size_regression(hs1, hs2)
+    bb = pkg.box_tlbr_to_xyxy(c1, t1, 256, 320)
+    assert maxerr(bb, b1) <= 1e-3
+    # in-place weight edits are picked up (engine rebuilt)
+    with torch.no_grad():
+        model.tlbr_reg[2].bias.add_(1.0)
+    b1n, _ = model.forward_dummy(im1, im2)
+    assert not torch.equal(b1n, b1)

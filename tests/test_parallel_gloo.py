@@ -1,0 +1,81 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the pair sharding
+and the box all-gather (the only collective on the path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from imagematching_oetr_amd.parallel import (bucket_by_shape, gather_boxes,
+                                             shard_bounds)
+
+
+def test_shard_bounds_cover_every_pair_once():
+    for n in (0, 1, 5, 8, 64, 67):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = shard_bounds(n, r, world)
+                assert 0 <= lo <= hi <= n
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+            sizes = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0]
+                     for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def test_bucket_by_shape_groups_mixed_scale_pairs():
+    shapes = [((640, 640), (640, 640)), ((640, 640), (1280, 1280)),
+              ((640, 640), (640, 640)), ((640, 640), (1280, 1280))]
+    b = bucket_by_shape(shapes)
+    assert list(b.values()) == [[0, 2], [1, 3]]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_pairs, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(n_pairs, rank, world)
+        idx = torch.arange(lo, hi, dtype=torch.float32)
+        box1 = torch.stack([idx, idx + 0.25, idx + 0.5, idx + 0.75], 1)
+        box2 = -box1
+        g1, g2 = gather_boxes(box1, box2, n_pairs)
+        q.put((rank, g1.tolist(), g2.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_pairs', [5, 8])
+def test_gather_boxes_world2_gloo(n_pairs):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    idx = torch.arange(n_pairs, dtype=torch.float32)
+    expect1 = torch.stack([idx, idx + 0.25, idx + 0.5, idx + 0.75], 1)
+    for rank, g1, g2 in results:
+        assert torch.equal(torch.tensor(g1), expect1), rank
+        assert torch.equal(torch.tensor(g2), -expect1), rank
+
+
+def test_gather_is_identity_without_process_group():
+    b1, b2 = torch.rand(3, 4), torch.rand(3, 4)
+    g1, g2 = gather_boxes(b1, b2, 3)
+    assert g1 is b1 and g2 is b2
