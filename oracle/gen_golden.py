@@ -81,7 +81,7 @@ def sub(t, max_rows=48):
 
 
 def fp(t):
-    return np.asarray(orc.checksum(t), dtype=np.float64)
+    return np.asarray(orc.checksum(t), dtype=np.int64)
 
 
 def gen_attention(out_dir):

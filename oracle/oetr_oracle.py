@@ -120,11 +120,15 @@ def make_features(seed, n, hf, wf, scale=1.0):
 
 
 def checksum(t):
-    """Order-independent float64 fingerprint used to verify that seeded
-    tensors regenerate identically on another machine."""
-    t = t.detach().double().flatten()
-    idx = torch.arange(1, t.numel() + 1, dtype=torch.float64)
-    return [float(t.sum()), float((t * t).sum()), float((t * (idx % 97)).sum())]
+    """Exact, machine-independent fingerprint of an fp32 tensor: integer sums
+    over the IEEE bit patterns (int64 wrap-around arithmetic is associative,
+    so thread count / reduction order cannot change it, unlike a float sum).
+    Used to verify that seeded tensors regenerate bit-identically elsewhere."""
+    bits = t.detach().to(torch.float32).contiguous().flatten().view(torch.int32)
+    bits = bits.to(torch.int64)
+    idx = torch.arange(1, bits.numel() + 1, dtype=torch.int64)
+    return [int(bits.sum()), int((bits * (idx % 97)).sum()),
+            int((bits * (idx % 8191)).sum())]
 
 
 # --------------------------------------------------------------------------

@@ -34,7 +34,7 @@ def test_position_table_matches_reference(golden_dir):
     pe = orc.position_table(40, 40)
     assert np.array_equal(pe[0].numpy(), g['pe_40x40'])
     full = orc.position_table(100, 100)
-    assert np.allclose(orc.checksum(full), g['pe_full_fp'], rtol=0, atol=0)
+    assert np.array_equal(orc.checksum(full), g['pe_full_fp'])
     # the documented quirk: div_term = exp(-k), k = 0,2,4..; channel 4 is sin(x*e^-2)
     x = torch.arange(1, 41).float()
     assert torch.equal(pe[0, 4, 0], torch.sin(x * torch.exp(torch.tensor(-2.0))))
