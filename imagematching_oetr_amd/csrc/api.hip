@@ -1,6 +1,7 @@
 // C ABI of liboetr_hip.so (declared in include/oetr_hip.h): weight repacking,
 // workspace layout and launch orchestration.  No torch types, no hidden
 // allocation or synchronisation inside forward calls.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -197,6 +198,9 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   EncLaunch p;
   memset(&p, 0, sizeof(p));
   p.g = g;
+#ifdef OETR_ABLATE
+  { const char* e = getenv("OETR_ABLATE"); p.dbg = e ? atoi(e) : 0; }
+#endif
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
   p.a = h->enc[0];
   p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];

@@ -19,6 +19,15 @@ constexpr float LN_EPS = 1e-5f;
 constexpr float ATTN_EPS = 1e-6f;
 constexpr int MAX_TOKENS = 10000;  // NECK.MAX_SHAPE 100x100 (reference default.py:25-28)
 
+// Ablation switches for timing attribution (tools/ablate.sh builds a second
+// library with -DOETR_ABLATE; the shipped build compiles them out).
+#ifdef OETR_ABLATE
+#define ABL(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define ABL(flags, bit) false
+#endif
+enum { ABL_KVREDUCE = 1, ABL_GELU = 2, ABL_ELU = 4, ABL_LN = 8, ABL_GEMM = 16, ABL_STORE = 32 };
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -54,9 +63,27 @@ __device__ __forceinline__ int crow(int r, int half) {
   return (r & 3) + 8 * (r >> 2) + 4 * half;
 }
 
-// phi(x) = elu(x) + 1, computed as torch does: expm1(x) + 1 for x <= 0.
+// phi(x) = elu(x) + 1.  torch evaluates expm1(x) + 1 for x <= 0, which is
+// exp(x) to within one rounding of the final add (<= 6e-8 absolute); exp is
+// used directly (branch-free, ~1/3 of the instructions of expm1).
 __device__ __forceinline__ float elu1(float x) {
-  return x > 0.f ? x + 1.0f : expm1f(x) + 1.0f;
+  return x > 0.f ? x + 1.0f : expf(x);
+}
+
+// DPP lane exchange inside a row of 16 lanes (no LDS traffic, unlike
+// __shfl_xor which lowers to ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// Sum over the 8 lanes sharing lane>>3: quad_perm [1,0,3,2], [2,3,0,1], then
+// row_half_mirror (lane i <-> 7-i, i.e. the other quad).
+__device__ __forceinline__ float sum8(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  return v;
 }
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -75,48 +102,64 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //       float4 index ((ntile * K/8 + ks) * 64 + lane) holds, for output column
 //       n = 32*ntile + (lane & 31), inputs k = 8*ks + 4*(lane >> 5) + {0..3}.
 //   Each wave streams its own weight fragments straight into registers with
-//   fully coalesced 1-KiB loads (prefetched one chunk of U k-steps ahead);
-//   the activation fragment is one ds_read_b128 per k-step.
+//   fully coalesced 1-KiB loads; activations are one ds_read_b128 per k-step.
+//   Both operands are double-buffered in registers one chunk (U k-steps =
+//   8*U*NT MFMAs) ahead.  The sched_barriers pin "issue the next chunk's loads,
+//   THEN run this chunk's MFMAs": without them hipcc sinks the prefetch loads
+//   to the end of the chunk and waits on them at once (vmcnt(0) per chunk).
+template <int NT, int U>
+struct GemmRegs {
+  f32x4 b[U][NT];
+  f32x4 a[U];
+};
+
+template <int NT, int U>
+__device__ __forceinline__ void gemm_fetch(GemmRegs<NT, U>& r, const float* a_ptr,
+                                           const f32x4* const (&w_ptr)[NT], int chunk) {
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r.b[u][t] = w_ptr[t][(chunk * U + u) * 64];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    r.a[u] = *reinterpret_cast<const f32x4*>(a_ptr + (chunk * U + u) * 8);
+}
+
+template <int NT, int U>
+__device__ __forceinline__ void gemm_mma(const GemmRegs<NT, U>& r, f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r.a[u][j], r.b[u][t][j], acc[t], 0, 0, 0);
+}
+
 template <int K, int NT, int U = 4>
 __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda,
                                             const f32x4* __restrict__ Wp, int nt0,
-                                            int lane, f32x16 (&acc)[NT]) {
+                                            int lane, f32x16 (&acc)[NT], int dbg = 0) {
+  if (ABL(dbg, ABL_GEMM)) return;
   constexpr int KS = K / 8;
   constexpr int NCH = KS / U;
-  static_assert(KS % U == 0, "K must be a multiple of 8*U");
-  const int half = lane >> 5;
-  const float* a_ptr = A + (lane & 31) * lda + 4 * half;
+  static_assert(KS % (2 * U) == 0, "K must be a multiple of 16*U");
+  const float* a_ptr = A + (lane & 31) * lda + 4 * (lane >> 5);
   const f32x4* w_ptr[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) w_ptr[t] = Wp + (size_t)(nt0 + t) * KS * 64 + lane;
 
-  f32x4 bc[U][NT], bn[U][NT];
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bc[u][t] = w_ptr[t][u * 64];
-
-#pragma unroll 2
-  for (int c = 0; c < NCH; ++c) {
-    if (c + 1 < NCH) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bn[u][t] = w_ptr[t][((c + 1) * U + u) * 64];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(a_ptr + (c * U + u) * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bc[u][t][j], acc[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bc[u][t] = bn[u][t];
+  GemmRegs<NT, U> r0, r1;
+  gemm_fetch<NT, U>(r0, a_ptr, w_ptr, 0);
+  for (int c = 0; c < NCH; c += 2) {
+    gemm_fetch<NT, U>(r1, a_ptr, w_ptr, c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_mma<NT, U>(r0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 < NCH) gemm_fetch<NT, U>(r0, a_ptr, w_ptr, c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_mma<NT, U>(r1, acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -161,6 +204,7 @@ struct EncLaunch {
   EncLayerDev a;         // next layer (phase A), TAIL==0
   DecKVDev d;            // TAIL==1
   int b_cross;           // phase-B layer is a cross layer
+  int dbg;               // ablation flags (OETR_ABLATE builds only)
 };
 
 // has_b: run phase B (finish a layer); tail: 0 = phase A of next encoder layer,

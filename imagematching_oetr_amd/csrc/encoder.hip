@@ -93,19 +93,36 @@ constexpr int KSUM_OFF = H_OFF + TM * LDH;
 constexpr int Z_OFF = KSUM_OFF + C;
 constexpr int SMEM_FLOATS = Z_OFF + TM * NH;
 
-// LayerNorm statistics of one 256-wide LDS row held as one float4 per lane.
-__device__ __forceinline__ void row_stats(const f32x4& v, float& mean, float& rstd, f32x4& d) {
-  mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / C);
-  d = v - mean;
-  const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) *
-                    (1.0f / C);
-  rstd = 1.0f / sqrtf(var + LN_EPS);
+// LayerNorm over a [TM][256] LDS tile with 8 threads per row: thread tid owns
+// row tid>>3 and the float4 columns i*8 + (tid&7), i < 8 (so the 8 threads of a
+// row read 128 contiguous bytes per step).  Row sums need only three DPP
+// exchanges inside an 8-lane group.  Returns the normalised values
+// (x - mean) * rstd in registers; the caller applies its affine(s).
+__device__ __forceinline__ void ln_rows8(const float* S, int tid, f32x4 (&xn)[8], int dbg) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(S + (tid >> 3) * LDA) + (tid & 7);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    xn[i] = src[i * 8];
+    s += (xn[i][0] + xn[i][1]) + (xn[i][2] + xn[i][3]);
+  }
+  if (ABL(dbg, ABL_LN)) return;
+  const float mean = sum8(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    xn[i] -= mean;
+    q += (xn[i][0] * xn[i][0] + xn[i][1] * xn[i][1]) + (xn[i][2] * xn[i][2] + xn[i][3] * xn[i][3]);
+  }
+  const float rstd = 1.0f / sqrtf(sum8(q) * (1.0f / C) + LN_EPS);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xn[i] *= rstd;
 }
 
 // phi(K)^T (V/S) for this wave's two heads from the K and V accumulators, plus
 // sum_s phi(K); stores the per-tile partial states.
 __device__ __forceinline__ void kv_state_store(f32x16 (&accK)[2], f32x16 (&accV)[2],
-                                               float inv_len_is_div, int S_len, int nvalid,
+                                               float inv_len_is_div /* ablation: skip phi */, int S_len, int nvalid,
                                                int lane, int wave, float* __restrict__ kv_out,
                                                float* __restrict__ ks_out, int slot) {
   const int half = lane >> 5;
@@ -115,7 +132,7 @@ __device__ __forceinline__ void kv_state_store(f32x16 (&accK)[2], f32x16 (&accV)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = crow(r, half) < nvalid;
-      const float kf = ok ? elu1(accK[t][r]) : 0.f;
+      const float kf = ok ? (inv_len_is_div != 0.f ? accK[t][r] : elu1(accK[t][r])) : 0.f;
       const float vf = ok ? accV[t][r] / (float)S_len : 0.f;
       accK[t][r] = kf;
       accV[t][r] = vf;
@@ -135,7 +152,6 @@ __device__ __forceinline__ void kv_state_store(f32x16 (&accK)[2], f32x16 (&accV)
     ksum += __shfl_xor(ksum, 32, 64);
     if (half == 0) ks_out[(size_t)slot * C + h * HD + lane] = ksum;
   }
-  (void)inv_len_is_div;
 }
 
 template <bool HAS_B, int TAIL>
@@ -171,16 +187,19 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
     // ================= phase B: finish layer l =================
     const int ss = p.b_cross ? 1 - side : side;
     const int S_len = g.L[ss];
-    const int nts = g.nt[ss];
-    const int src_slot0 = g.tile0[ss] + n * nts;
+    const int nts = ABL(p.dbg, ABL_KVREDUCE) ? 1 : g.nt[ss];
+    const int src_slot0 = g.tile0[ss] + n * g.nt[ss];
 
+    // Loads below never branch on row validity: rows past the end of the image
+    // re-read the last valid row (finite values that are never stored), because a
+    // guarded load costs a branch plus a full vmcnt(0) round trip per element.
     // phi(Q) tile -> S0 (coalesced float4 rows)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = tid + NTHREADS * i;
       const int r = idx >> 6, c4 = idx & 63;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < nvalid) v = reinterpret_cast<const f32x4*>(p.qp + (row_base + r) * C)[c4];
+      const f32x4 v =
+          reinterpret_cast<const f32x4*>(p.qp + (row_base + min(r, nvalid - 1)) * C)[c4];
       *reinterpret_cast<f32x4*>(S0 + r * LDA + 4 * c4) = v;
     }
     // residual x in accumulator layout
@@ -188,28 +207,40 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = crow(r, half);
-        xacc[t][r] = row < nvalid ? p.x[(row_base + row) * C + 64 * wave + 32 * t + col] : 0.f;
+        const int row = min(crow(r, half), nvalid - 1);
+        xacc[t][r] = p.x[(row_base + row) * C + 64 * wave + 32 * t + col];
       }
     // reduce the source image's partial KV states (fixed order -> deterministic);
-    // the result is already in B-operand register order.
+    // the result is already in B-operand register order.  Four tiles (32 float4
+    // loads per lane) are in flight per round trip.
     f32x4 kvB[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) kvB[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      const f32x4* kvp = reinterpret_cast<const f32x4*>(p.kv_in);
-      for (int ti = 0; ti < nts; ++ti) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const f32x4* src = kvp + ((size_t)(src_slot0 + ti) * NH + 2 * wave + t) * 4 * 64 + lane;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) kvB[t][q] += src[q * 64];
-        }
-      }
+      const f32x4* kvp =
+          reinterpret_cast<const f32x4*>(p.kv_in) + ((size_t)src_slot0 * NH + 2 * wave) * 256 + lane;
+      const float* ksp = p.ks_in + (size_t)src_slot0 * C + tid;
       float ks = 0.f;
-      for (int ti = 0; ti < nts; ++ti) ks += p.ks_in[(size_t)(src_slot0 + ti) * C + tid];
+      for (int ti0 = 0; ti0 < nts; ti0 += 4) {
+        f32x4 tmp[4][8];
+        float kt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ti = min(ti0 + u, nts - 1);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tmp[u][e] = kvp[(size_t)ti * (NH * 256) + e * 64];
+          kt[u] = ksp[(size_t)ti * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ti0 + u < nts) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kvB[e >> 2][e & 3] += tmp[u][e];
+            ks += kt[u];
+          }
+      }
       ksum_s[tid] = ks;
     }
     __syncthreads();
@@ -230,42 +261,45 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
     __syncthreads();
 
     // message = (phi(Q) . KV) * Z * S  for this wave's two heads -> S1
+    {
+      float zr[2][16];  // read before any S1 store: LDS stores would otherwise
+#pragma unroll          // serialise these reads one by one (may-alias)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int h = 2 * wave + t;
-      f32x16 acc = {0};
-      const float* a_ptr = S0 + col * LDA + h * HD + 4 * half;
+        for (int r = 0; r < 16; ++r) zr[t][r] = z_s[crow(r, half) * NH + 2 * wave + t];
+      f32x16 macc[2] = {{0}, {0}};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(a_ptr + ks * 8);
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[t][ks][j], acc, 0, 0, 0);
-      }
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(S0 + col * LDA + (2 * wave + t) * HD +
+                                                          4 * half + ks * 8);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = crow(r, half);
-        S1[row * LDA + h * HD + col] = acc[r] * z_s[row * NH + h] * (float)S_len;
-      }
+          for (int j = 0; j < 4; ++j)
+            macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[t][ks][j], macc[t], 0, 0, 0);
+        }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          S1[crow(r, half) * LDA + (2 * wave + t) * HD + col] = macc[t][r] * zr[t][r] * (float)S_len;
     }
     __syncthreads();
 
     // x1 = x + message . Wmerge^T
-    gemm_rows32<C, 2>(S1, LDA, p.b.wmerge, 2 * wave, lane, xacc);
+    gemm_rows32<C, 2>(S1, LDA, p.b.wmerge, 2 * wave, lane, xacc, p.dbg);
     acc_to_lds<2>(S0, LDA, 64 * wave, lane, xacc);
     __syncthreads();
 
     // LN2(x1) -> S1
+    {
+      f32x4 xn[8];
+      ln_rows8(S0, tid, xn, p.dbg);
+      const f32x4* gw = reinterpret_cast<const f32x4*>(p.b.ln2_w) + (tid & 7);
+      const f32x4* gb = reinterpret_cast<const f32x4*>(p.b.ln2_b) + (tid & 7);
+      f32x4* dst = reinterpret_cast<f32x4*>(S1 + (tid >> 3) * LDA) + (tid & 7);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(S0 + r * LDA + 4 * lane);
-      float mean, rstd;
-      f32x4 d;
-      row_stats(v, mean, rstd, d);
-      const f32x4 gw = reinterpret_cast<const f32x4*>(p.b.ln2_w)[lane];
-      const f32x4 gb = reinterpret_cast<const f32x4*>(p.b.ln2_b)[lane];
-      *reinterpret_cast<f32x4*>(S1 + r * LDA + 4 * lane) = d * rstd * gw + gb;
+      for (int i = 0; i < 8; ++i) dst[i * 8] = xn[i] * gw[i * 8] + gb[i * 8];
     }
     __syncthreads();
 
@@ -273,17 +307,17 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
 #pragma unroll
     for (int cpart = 0; cpart < 2; ++cpart) {
       f32x16 hacc[2] = {{0}, {0}};
-      gemm_rows32<C, 2>(S1, LDA, p.b.w1, 4 * wave + 2 * cpart, lane, hacc);
+      gemm_rows32<C, 2>(S1, LDA, p.b.w1, 4 * wave + 2 * cpart, lane, hacc, p.dbg);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[t][r] = gelu_erf(hacc[t][r]);
+        for (int r = 0; r < 16; ++r) hacc[t][r] = ABL(p.dbg, ABL_GELU) ? hacc[t][r] : gelu_erf(hacc[t][r]);
       acc_to_lds<2>(Hh, LDH, 128 * wave + 64 * cpart, lane, hacc);
     }
     __syncthreads();
 
     // x2 = x1 + hidden . W2^T ; write back
-    gemm_rows32<FF, 2>(Hh, LDH, p.b.w2, 2 * wave, lane, xacc);
+    gemm_rows32<FF, 2>(Hh, LDH, p.b.w2, 2 * wave, lane, xacc, p.dbg);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -299,8 +333,7 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
     for (int i = 0; i < 8; ++i) {
       const int idx = tid + NTHREADS * i;
       const int r = idx >> 6, c4 = idx & 63;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < nvalid) v = reinterpret_cast<const f32x4*>(p.x + (row_base + r) * C)[c4];
+      const f32x4 v = reinterpret_cast<const f32x4*>(p.x + (row_base + min(r, nvalid - 1)) * C)[c4];
       *reinterpret_cast<f32x4*>(S0 + r * LDA + 4 * c4) = v;
     }
     __syncthreads();
@@ -309,53 +342,54 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
   if (TAIL == 0) {
     // ================= phase A: start layer l+1 =================
     // q_in = LN_q(x)+pos -> S1 ; kv_in = LN_kv(x)+pos -> S2 (one set of row stats)
+    {
+      f32x4 xn[8];
+      ln_rows8(S0, tid, xn, p.dbg);
+      const int r = tid >> 3, part = tid & 7;
+      const f32x4* pos = reinterpret_cast<const f32x4*>(
+                             p.pos + (size_t)(g.prow0[side] + l0 + min(r, nvalid - 1)) * C) + part;
+      const f32x4* qw = reinterpret_cast<const f32x4*>(p.a.lnq_w) + part;
+      const f32x4* qb = reinterpret_cast<const f32x4*>(p.a.lnq_b) + part;
+      const f32x4* kw = reinterpret_cast<const f32x4*>(p.a.lnkv_w) + part;
+      const f32x4* kb = reinterpret_cast<const f32x4*>(p.a.lnkv_b) + part;
+      f32x4* dq = reinterpret_cast<f32x4*>(S1 + r * LDA) + part;
+      f32x4* dk = reinterpret_cast<f32x4*>(S2 + r * LDA) + part;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(S0 + r * LDA + 4 * lane);
-      float mean, rstd;
-      f32x4 d;
-      row_stats(v, mean, rstd, d);
-      f32x4 pos = {0.f, 0.f, 0.f, 0.f};
-      if (r < nvalid)
-        pos = reinterpret_cast<const f32x4*>(p.pos + (size_t)(g.prow0[side] + l0 + r) * C)[lane];
-      const f32x4 xn = d * rstd;
-      const f32x4 qw = reinterpret_cast<const f32x4*>(p.a.lnq_w)[lane];
-      const f32x4 qb = reinterpret_cast<const f32x4*>(p.a.lnq_b)[lane];
-      const f32x4 kw = reinterpret_cast<const f32x4*>(p.a.lnkv_w)[lane];
-      const f32x4 kb = reinterpret_cast<const f32x4*>(p.a.lnkv_b)[lane];
-      *reinterpret_cast<f32x4*>(S1 + r * LDA + 4 * lane) = (xn * qw + qb) + pos;
-      *reinterpret_cast<f32x4*>(S2 + r * LDA + 4 * lane) = (xn * kw + kb) + pos;
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 ps = pos[i * 8];
+        dq[i * 8] = (xn[i] * qw[i * 8] + qb[i * 8]) + ps;
+        dk[i * 8] = (xn[i] * kw[i * 8] + kb[i * 8]) + ps;
+      }
     }
     __syncthreads();
 
     {  // phi(Q) -> HBM
       f32x16 acc[2] = {{0}, {0}};
-      gemm_rows32<C, 2>(S1, LDA, p.a.wq, 2 * wave, lane, acc);
+      gemm_rows32<C, 2>(S1, LDA, p.a.wq, 2 * wave, lane, acc, p.dbg);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
           if (row < nvalid)
-            p.qp[(row_base + row) * C + 64 * wave + 32 * t + col] = elu1(acc[t][r]);
+            p.qp[(row_base + row) * C + 64 * wave + 32 * t + col] = ABL(p.dbg, ABL_ELU) ? acc[t][r] : elu1(acc[t][r]);
         }
     }
     f32x16 accK[2] = {{0}, {0}}, accV[2] = {{0}, {0}};
-    gemm_rows32<C, 2>(S2, LDA, p.a.wk, 2 * wave, lane, accK);
-    gemm_rows32<C, 2>(S2, LDA, p.a.wv, 2 * wave, lane, accV);
-    kv_state_store(accK, accV, 0.f, L, nvalid, lane, wave, p.kv_out, p.ks_out, slot);
+    gemm_rows32<C, 2>(S2, LDA, p.a.wk, 2 * wave, lane, accK, p.dbg);
+    gemm_rows32<C, 2>(S2, LDA, p.a.wv, 2 * wave, lane, accV, p.dbg);
+    kv_state_store(accK, accV, ABL(p.dbg, ABL_ELU) ? 1.f : 0.f, L, nvalid, lane, wave, p.kv_out, p.ks_out, slot);
   } else if (TAIL == 1) {
     // ============ decoder preparation (transformer.py:240-246) ============
     // k = (memory + pos) Wk^T + bk ; v = memory Wv^T + bv  (no norm, no pos on v)
+    {
+      const int r = tid >> 3, part = tid & 7;
+      const f32x4* pos = reinterpret_cast<const f32x4*>(
+                             p.pos + (size_t)(g.prow0[side] + l0 + min(r, nvalid - 1)) * C) + part;
+      const f32x4* src = reinterpret_cast<const f32x4*>(S0 + r * LDA) + part;
+      f32x4* dst = reinterpret_cast<f32x4*>(S1 + r * LDA) + part;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(S0 + r * LDA + 4 * lane);
-      f32x4 pos = {0.f, 0.f, 0.f, 0.f};
-      if (r < nvalid)
-        pos = reinterpret_cast<const f32x4*>(p.pos + (size_t)(g.prow0[side] + l0 + r) * C)[lane];
-      *reinterpret_cast<f32x4*>(S1 + r * LDA + 4 * lane) = v + pos;
+      for (int i = 0; i < 8; ++i) dst[i * 8] = src[i * 8] + pos[i * 8];
     }
     __syncthreads();
 #pragma unroll
@@ -368,9 +402,9 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accK[t][r] = bk; accV[t][r] = bv; }
       }
-      gemm_rows32<C, 2>(S1, LDA, p.d.wk[dl], 2 * wave, lane, accK);
-      gemm_rows32<C, 2>(S0, LDA, p.d.wv[dl], 2 * wave, lane, accV);
-      kv_state_store(accK, accV, 0.f, L, nvalid, lane, wave, p.dkv_out[dl], p.dks_out[dl], slot);
+      gemm_rows32<C, 2>(S1, LDA, p.d.wk[dl], 2 * wave, lane, accK, p.dbg);
+      gemm_rows32<C, 2>(S0, LDA, p.d.wv[dl], 2 * wave, lane, accV, p.dbg);
+      kv_state_store(accK, accV, ABL(p.dbg, ABL_ELU) ? 1.f : 0.f, L, nvalid, lane, wave, p.dkv_out[dl], p.dks_out[dl], slot);
     }
   }
 }

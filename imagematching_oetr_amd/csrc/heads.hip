@@ -50,8 +50,11 @@ __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
       const int y = l / wf, x = l - y * wf;
       const int yy = y + dy, xx = x + dx;
       const bool ok = (l < L) && (yy >= 0) && (yy < hf) && (xx >= 0) && (xx < wf);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = reinterpret_cast<const f32x4*>(mem + (size_t)(yy * wf + xx) * C)[lane];
+      // unconditional load from a clamped row + select: a guarded load would cost
+      // a branch and a vmcnt(0) round trip per row
+      const int src_row = ok ? yy * wf + xx : 0;
+      f32x4 v = reinterpret_cast<const f32x4*>(mem + (size_t)src_row * C)[lane];
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       const float att =
           wave_sum((v[0] * hsv[0] + v[1] * hsv[1]) + (v[2] * hsv[2] + v[3] * hsv[3]));
       *reinterpret_cast<f32x4*>(S + r * LDA + 4 * lane) = v * att;
