@@ -85,8 +85,43 @@ __device__ __forceinline__ float sum8(float v) {
   v += dpp_mov<0x141>(v);
   return v;
 }
+// Branch-free fp32 erf (coefficients and error analysis: tools/fit_erf.py;
+// max 1.3 ulp / 7.7e-8 abs vs double-precision erf).  Both branches are
+// evaluated and selected, so a wave never diverges; ocml's erff costs ~3x the
+// issue slots in the GELU epilogue because of its divergent range split.
+//   |x| <= 0.92 : x + x*P(x^2)
+//   |x| >  0.92 : sign(x) * (1 - 2^(t*R(t))),  t = min(|x|, 4)
+__device__ __forceinline__ float erf_f32(float x) {
+  const float ax = fabsf(x);
+  const float t = fminf(ax, 4.0f);
+  const float s = x * x;
+  float p = 8.404849575e-05f;
+  p = fmaf(p, s, -8.151340561e-04f);
+  p = fmaf(p, s, 5.201837672e-03f);
+  p = fmaf(p, s, -2.685974483e-02f);
+  p = fmaf(p, s, 1.128370225e-01f);
+  p = fmaf(p, s, -3.761263422e-01f);
+  p = fmaf(p, s, 1.283791667e-01f);
+  const float small_v = fmaf(x, p, x);
+  float r = 4.358980029e-07f;
+  r = fmaf(r, t, -7.196586003e-06f);
+  r = fmaf(r, t, 2.439359676e-05f);
+  r = fmaf(r, t, 3.708157171e-04f);
+  r = fmaf(r, t, -5.214545892e-03f);
+  r = fmaf(r, t, 3.451753623e-02f);
+  r = fmaf(r, t, -1.537478043e-01f);
+  r = fmaf(r, t, -9.159608808e-01f);
+  r = fmaf(r, t, -1.628399401e+00f);
+  const float large_v = copysignf(1.0f - __builtin_amdgcn_exp2f(t * r), x);
+  return ax <= 0.92f ? small_v : large_v;
+}
+// Exact-erf GELU (torch nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)).
 __device__ __forceinline__ float gelu_erf(float x) {
+#ifdef OETR_OCML_ERF
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+#else
+  return 0.5f * x * (1.0f + erf_f32(x * 0.70710678118654752440f));
+#endif
 }
 
 // XCD-aware bijective remap: hardware block b runs on XCD b % 8; give each
@@ -136,7 +171,12 @@ __device__ __forceinline__ void gemm_mma(const GemmRegs<NT, U>& r, f32x16 (&acc)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(r.a[u][j], r.b[u][t][j], acc[t], 0, 0, 0);
 }
 
-template <int K, int NT, int U = 4>
+#ifndef OETR_GEMM_U
+#define OETR_GEMM_U 4
+#endif
+// (Fetching a GEMM's first weight chunk one phase early was measured and is a
+// loss: +7 us per encoder launch - tools/variants A/B - so every GEMM starts cold.)
+template <int K, int NT, int U = OETR_GEMM_U>
 __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda,
                                             const f32x4* __restrict__ Wp, int nt0,
                                             int lane, f32x16 (&acc)[NT], int dbg = 0) {
