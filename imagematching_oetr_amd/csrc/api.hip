@@ -93,14 +93,15 @@ struct oetr_ctx {
   DecKVDev dkv;
   DecLayerDev dec[OETR_N_DEC];
   const float* qe[2];
+  const float *dec_tgt1, *dec_q0, *dec_qkv1;  // create-time decoder constants
   HeadsDev heads;
 };
 
 namespace {
 
 struct Workspace {
-  float *x, *qp, *pos, *kvp[2], *ksp[2], *dkv[2], *dks[2], *conv_out, *gn_part, *hs, *logits,
-      *cxy, *tlbr;
+  float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
+      *logits, *cxy, *tlbr;
   size_t bytes;
 };
 
@@ -134,7 +135,8 @@ Workspace carve(const Geom& g, void* base) {
   w.qp = take(rows * C);
   w.pos = take((size_t)(g.L[0] + g.L[1]) * C);
   for (int i = 0; i < 2; ++i) { w.kvp[i] = take(nt * KV_FLOATS); w.ksp[i] = take(nt * C); }
-  for (int i = 0; i < 2; ++i) { w.dkv[i] = take(nt * KV_FLOATS); w.dks[i] = take(nt * C); }
+  w.att0 = take(nt * C); w.z0 = take(nt * NH);
+  w.dkv1 = take(nt * KV_FLOATS); w.dks1 = take(nt * C);
   w.conv_out = take(rows * C);
   w.gn_part = take(nt * 32 * 2);
   w.hs = take((size_t)2 * g.N * C);
@@ -169,6 +171,9 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.logits = w.logits;
   p.cxy[0] = cxy1; p.cxy[1] = cxy2;
   p.img_h[0] = img_h1; p.img_h[1] = img_h2;
+  p.tlbr[0] = p.tlbr[1] = nullptr;   // stand-alone centre estimation: no fused tail
+  p.box[0] = p.box[1] = nullptr;
+  p.img_w[0] = p.img_w[1] = 0;
   return p;
 }
 
@@ -213,7 +218,8 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
     if (l + 1 == OETR_N_ENC) {
       tail = 1;
       p.d = h->dkv;
-      for (int i = 0; i < 2; ++i) { p.dkv_out[i] = w.dkv[i]; p.dks_out[i] = w.dks[i]; }
+      p.att0_out = w.att0; p.z0_out = w.z0; p.dkv1_out = w.dkv1; p.dks1_out = w.dks1;
+      p.dec_q0 = h->dec_q0;
     } else if (l + 1 < enc_layers) {
       tail = 0;
       p.a = h->enc[l + 1];
@@ -227,12 +233,9 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   if (enc_layers == OETR_N_ENC) {
     DecLaunch d;
     d.g = g;
-    for (int i = 0; i < 2; ++i) {
-      d.layer[i] = h->dec[i];
-      d.qe[i] = h->qe[i];
-      d.dkv[i] = w.dkv[i];
-      d.dks[i] = w.dks[i];
-    }
+    for (int i = 0; i < 2; ++i) { d.layer[i] = h->dec[i]; d.qe[i] = h->qe[i]; }
+    d.tgt1 = h->dec_tgt1; d.qkv1 = h->dec_qkv1;
+    d.att0_part = w.att0; d.z0_part = w.z0; d.dkv1 = w.dkv1; d.dks1 = w.dks1;
     d.hs = w.hs;
     TRACED(h, s, K_DECODER, launch_decoder(d, s));
   }
@@ -321,6 +324,7 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   const size_t conv_b = pk.copy(w->heat_conv_b, C), gn_w = pk.copy(w->heat_gn_w, C),
                gn_b = pk.copy(w->heat_gn_b, C), out_w = pk.copy(w->heat_out_w, C),
                out_b = pk.copy(w->heat_out_b, 1);
+  const size_t dconst = pk.reserve_aligned(2 * C + 2 * C + 2 * 3 * C);  // tgt1 | q0 | qkv1
   const size_t t0 = pk.transposed(w->tlbr0_w, C, C), t2w = pk.copy(w->tlbr2_w, 4 * C),
                t2b = pk.copy(w->tlbr2_b, 4);
 
@@ -363,6 +367,21 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
     d.n2b = B + dof[l].n[3]; d.n3w = B + dof[l].n[4]; d.n3b = B + dof[l].n[5];
   }
   h->qe[0] = B + qe1; h->qe[1] = B + qe2;
+  h->dec_tgt1 = B + dconst; h->dec_q0 = B + dconst + 2 * C; h->dec_qkv1 = B + dconst + 4 * C;
+  {  // fold the image-independent part of the decoder once (decoder.hip)
+    DecConstLaunch dc;
+    for (int i = 0; i < 2; ++i) { dc.layer[i] = h->dec[i]; dc.qe[i] = h->qe[i]; }
+    dc.tgt1 = h->dev + dconst; dc.q0 = h->dev + dconst + 2 * C; dc.qkv1 = h->dev + dconst + 4 * C;
+    (void)hipSetDevice(device);
+    hipError_t ce = launch_decoder_consts(dc, nullptr);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(nullptr);
+    (void)hipSetDevice(prev);
+    if (ce != hipSuccess) {
+      (void)hipFree(h->dev);
+      delete h;
+      return hip_fail(ce, "oetr_create: decoder constant folding");
+    }
+  }
   h->heads.conv_w = F4(conv_off);
   h->heads.conv_b = B + conv_b; h->heads.gn_w = B + gn_w; h->heads.gn_b = B + gn_b;
   h->heads.out_w = B + out_w; h->heads.out_b = B + out_b;
@@ -436,11 +455,11 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
   float* tl1 = w.tlbr;
   float* tl2 = w.tlbr + 4 * g.N;
   HeatLaunch hp = heat_launch(h, g, w, w.x, w.x + r1 * C, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
+  hp.tlbr[0] = tl1; hp.tlbr[1] = tl2;
+  hp.box[0] = box1; hp.box[1] = box2;
+  hp.img_w[0] = img_w1; hp.img_w[1] = img_w2;
   TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, s));
-  TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));
-  TRACED(h, s, K_SIZE_REG, launch_size_regression(h->heads, hs1, hs2, g.N, tl1, tl2, s));
-  TRACED(h, s, K_BOXES, launch_boxes(cxy1, tl1, g.N, img_h1, img_w1, box1, s));
-  TRACED(h, s, K_BOXES, launch_boxes(cxy2, tl2, g.N, img_h2, img_w2, box2, s));
+  TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));  // + size regression + boxes
   if (st) {
     if ((rc = copy_out(st->hs1, hs1, (size_t)g.N * C, s))) return rc;
     if ((rc = copy_out(st->hs2, hs2, (size_t)g.N * C, s))) return rc;

@@ -238,8 +238,12 @@ struct EncLaunch {
   const float* ks_in;    //   [ntiles][8192] / [ntiles][256]
   float* kv_out;         // partial KV states for the next layer
   float* ks_out;
-  float* dkv_out[2];     // TAIL==1: decoder cross-attn partial states per layer
-  float* dks_out[2];
+  // TAIL==1 (decoder preparation) outputs, per token tile:
+  float* att0_out;       //  [ntiles][256] partial message of decoder layer 0's cross-attn
+  float* z0_out;         //  [ntiles][8]   partial normaliser  (query is a create-time constant)
+  float* dkv1_out;       //  [ntiles][8192] partial KV state for decoder layer 1
+  float* dks1_out;       //  [ntiles][256]
+  const float* dec_q0;   //  [2][256] phi(Q) of decoder layer 0's cross-attn, per side
   EncLayerDev b;         // layer being finished (phase B), if any
   EncLayerDev a;         // next layer (phase A), TAIL==0
   DecKVDev d;            // TAIL==1
@@ -267,10 +271,20 @@ struct DecLaunch {
   Geom g;
   DecLayerDev layer[2];
   const float* qe[2];      // query embeddings per side [256]
-  const float* dkv[2];     // partial states from the encoder tail
-  const float* dks[2];
+  const float* tgt1;       // [2][256]   create-time constants (k_decoder_consts)
+  const float* qkv1;       // [2][768]
+  const float* att0_part;  // [ntiles][256] from the encoder tail
+  const float* z0_part;    // [ntiles][8]
+  const float* dkv1;       // [ntiles][8192]
+  const float* dks1;       // [ntiles][256]
   float* hs;               // [2N][256]
 };
+struct DecConstLaunch {
+  DecLayerDev layer[2];
+  const float* qe[2];
+  float *tgt1, *q0, *qkv1;
+};
+hipError_t launch_decoder_consts(const DecConstLaunch& p, hipStream_t s);
 hipError_t launch_decoder(const DecLaunch& p, hipStream_t s);
 
 struct HeadsDev {
@@ -289,6 +303,10 @@ struct HeatLaunch {
   float* logits;           // [rows]
   float* cxy[2];           // [N][2] per side
   int img_h[2];
+  // fused tail (forward path): size regression + boxes in the same launch
+  float* tlbr[2];          // [N][4] per side, or NULL
+  float* box[2];           // [N][4] per side, or NULL
+  int img_w[2];
 };
 hipError_t launch_heat_conv(const HeatLaunch& p, hipStream_t s);
 hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s);

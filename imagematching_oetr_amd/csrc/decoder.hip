@@ -5,30 +5,38 @@
 // LinearAttention (src/models/linear_attention.py:22-50); tgt starts at zero,
 // tgt_pos = query embedding, memory = encoder output (transformer.py:361-381).
 //
-// There is ONE query token per image, so every projection is a 256-wide
-// GEMV; the only token-parallel work (K/V projections of the memory and the
-// per-head phi(K)^T V states) was already done by the encoder's tail launch.
-// One workgroup of 16 waves handles one image: the chain of GEMVs is latency
-// bound, each GEMV puts a whole 256x256 matrix in flight at once (16 k-chunks
-// x 64 float4 columns), weights are stored transposed [in][out] so every
-// wave-load is a contiguous 1 KiB.
+// There is ONE query token per image, so every projection is a 256-wide GEMV
+// and the chain is latency bound.  What keeps it short:
+//  * everything that does not depend on the images is folded at create time by
+//    k_decoder_consts: layer 0's self-attention block acts on tgt = 0, so its
+//    output, the following LN2 and the phi(Q) of layer 0's cross-attention are
+//    per-side constants; layer 1's self-attention q/k projections see
+//    LN1(tgt)+query_embed, so W.query_embed + b is a constant bias and q, k, v
+//    come from ONE fused [256 -> 768] pass over LN1(tgt);
+//  * layer 0's cross-attention is linear in the memory state and its query is
+//    a constant, so the encoder's tail launch already reduced each token tile
+//    to a 256-float partial message (+8 partial normalisers) instead of an
+//    8192-float state;
+//  * one workgroup of 16 waves per image; each GEMV puts a whole matrix in
+//    flight (weights stored transposed [in][out]: every wave-load is 1 KiB
+//    contiguous, 16 independent float4 loads per thread).
 #include "common.h"
 
 namespace oetr {
 
 constexpr int DEC_THREADS = 1024;
 
-// out[NOUT] = x[K] . Wt[K][NOUT] (+ bias), all 1024 threads.
+// part[kc][NOUT] = sum over this thread's k-chunk of x[k] * Wt[k][NOUT]; the
+// caller syncs and then sums the KCH partials.
 template <int K, int NOUT>
-__device__ __forceinline__ void gemv(const float* __restrict__ Wt, const float* x_s,
-                                     const float* __restrict__ bias, float* out_s,
-                                     float* part_s, int tid, bool relu = false) {
+__device__ __forceinline__ void gemv_partial(const float* __restrict__ Wt, const float* x_s,
+                                             float* part_s, int tid) {
   constexpr int NO4 = NOUT / 4;
   constexpr int KCH = DEC_THREADS / NO4;
   constexpr int KPER = K / KCH;
+  constexpr int BATCH = KPER < 16 ? KPER : 16;  // float4 loads in flight per thread
   const int kc = tid / NO4, o4 = tid % NO4;
   const f32x4* w = reinterpret_cast<const f32x4*>(Wt) + (size_t)kc * KPER * NO4 + o4;
-  constexpr int BATCH = KPER < 8 ? KPER : 8;  // float4 loads in flight per thread
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i0 = 0; i0 < KPER; i0 += BATCH) {
@@ -39,18 +47,31 @@ __device__ __forceinline__ void gemv(const float* __restrict__ Wt, const float* 
     for (int i = 0; i < BATCH; ++i) acc += wv[i] * x_s[kc * KPER + i0 + i];
   }
   *reinterpret_cast<f32x4*>(part_s + kc * NOUT + 4 * o4) = acc;
+}
+template <int K, int NOUT>
+__device__ __forceinline__ float gemv_collect(const float* part_s, int o) {
+  constexpr int KCH = DEC_THREADS / (NOUT / 4);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < KCH; ++c) s += part_s[c * NOUT + o];
+  return s;
+}
+// out[NOUT] = act(x . Wt + bias); two barriers.
+template <int K, int NOUT>
+__device__ __forceinline__ void gemv(const float* __restrict__ Wt, const float* x_s,
+                                     const float* __restrict__ bias, float* out_s,
+                                     float* part_s, int tid, bool relu = false) {
+  gemv_partial<K, NOUT>(Wt, x_s, part_s, tid);
   __syncthreads();
   for (int o = tid; o < NOUT; o += DEC_THREADS) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < KCH; ++c) s += part_s[c * NOUT + o];
+    float s = gemv_collect<K, NOUT>(part_s, o);
     if (bias) s += bias[o];
     out_s[o] = relu ? fmaxf(s, 0.f) : s;
   }
   __syncthreads();
 }
 
-// LayerNorm of one 256-vector (wave 0), optional second output y + add.
+// LayerNorm of one 256-vector (wave 0); optional second output y + add.
 __device__ __forceinline__ void ln_vec(const float* in_s, const float* __restrict__ w,
                                        const float* __restrict__ b, float* out_s,
                                        const float* add_s, float* out_add_s, int tid) {
@@ -70,21 +91,73 @@ __device__ __forceinline__ void ln_vec(const float* in_s, const float* __restric
   __syncthreads();
 }
 
-__global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
-  __shared__ __attribute__((aligned(16))) float kv_s[KV_FLOATS];  // [h][d][v]
+// Linear attention of one query against one key/value token (L = S = 1):
+// the decoder's self-attention (values / v_length with v_length = 1).
+__device__ __forceinline__ float self_attn_1x1(const float* q_s, const float* k_s, float v,
+                                               int tid) {
+  const int h = tid >> 5;
+  float z = 0.f, s = 0.f;
+  const float vval = v / 1.0f;
+#pragma unroll 4
+  for (int d = 0; d < HD; ++d) {
+    const float fq = elu1(q_s[h * HD + d]), fk = elu1(k_s[h * HD + d]);
+    z += fq * fk;
+    s += fq * (fk * vval);
+  }
+  return s * (1.0f / (z + ATTN_EPS)) * 1.0f;
+}
+
+// ---------------------------------------------------------------------------
+// Create-time constants, one block per side (launched once from oetr_create).
+//   tgt1[side]  : tgt after layer 0's self-attention block (tgt0 = 0)
+//   q0[side]    : phi(Wq (LN2(tgt1) + qe) + bq) of layer 0's cross-attention
+//   qkv1[side]  : [Wq.qe + bq | Wk.qe + bk | bv] of layer 1's self-attention
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS) void k_decoder_consts(DecConstLaunch p) {
   __shared__ __attribute__((aligned(16))) float part_s[4096];
-  __shared__ __attribute__((aligned(16))) float vec_s[10][C];
+  __shared__ __attribute__((aligned(16))) float vec_s[8][C];
+  float *tgt = vec_s[0], *t2 = vec_s[1], *qk = vec_s[2], *vq = vec_s[3], *vk = vec_s[4],
+        *vv = vec_s[5], *att = vec_s[6], *qe = vec_s[7];
+  const int tid = threadIdx.x, side = blockIdx.x;
+  const DecLayerDev& w0 = p.layer[0];
+  const DecLayerDev& w1 = p.layer[1];
+  if (tid < C) { tgt[tid] = 0.f; qe[tid] = p.qe[side][tid]; }
+  __syncthreads();
+  ln_vec(tgt, w0.n1w, w0.n1b, t2, qe, qk, tid);
+  gemv<C, C>(w0.self_attn.wq_t, qk, w0.self_attn.bq, vq, part_s, tid);
+  gemv<C, C>(w0.self_attn.wk_t, qk, w0.self_attn.bk, vk, part_s, tid);
+  gemv<C, C>(w0.self_attn.wv_t, t2, w0.self_attn.bv, vv, part_s, tid);
+  if (tid < C) att[tid] = self_attn_1x1(vq, vk, vv[tid], tid);
+  __syncthreads();
+  gemv<C, C>(w0.self_attn.wm_t, att, nullptr, tgt, part_s, tid);  // tgt1 = 0 + msg
+  if (tid < C) p.tgt1[side * C + tid] = tgt[tid];
+  ln_vec(tgt, w0.n2w, w0.n2b, t2, qe, qk, tid);
+  gemv<C, C>(w0.cross.wq_t, qk, w0.cross.bq, vq, part_s, tid);
+  if (tid < C) p.q0[side * C + tid] = elu1(vq[tid]);
+  // layer 1 self-attention bias constants
+  gemv<C, C>(w1.self_attn.wq_t, qe, w1.self_attn.bq, vq, part_s, tid);
+  gemv<C, C>(w1.self_attn.wk_t, qe, w1.self_attn.bk, vk, part_s, tid);
+  if (tid < C) {
+    p.qkv1[side * 3 * C + tid] = vq[tid];
+    p.qkv1[side * 3 * C + C + tid] = vk[tid];
+    p.qkv1[side * 3 * C + 2 * C + tid] = w1.self_attn.bv[tid];
+  }
+}
+
+hipError_t launch_decoder_consts(const DecConstLaunch& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_decoder_consts, dim3(2), dim3(DEC_THREADS), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
+  __shared__ __attribute__((aligned(16))) float kv_s[KV_FLOATS];  // [h][d][v], layer 1
+  __shared__ __attribute__((aligned(16))) float part_s[3 * 4096];
+  __shared__ __attribute__((aligned(16))) float vec_s[8][C];
+  __shared__ __attribute__((aligned(16))) float qkv_s[3 * C];
   __shared__ __attribute__((aligned(16))) float hdn_s[FF];
-  float* tgt = vec_s[0];
-  float* t2 = vec_s[1];
-  float* qk = vec_s[2];
-  float* vq = vec_s[3];
-  float* vk = vec_s[4];
-  float* vv = vec_s[5];
-  float* att = vec_s[6];
-  float* msg = vec_s[7];
-  float* qe = vec_s[8];
-  float* ksum = vec_s[9];
+  float *tgt = vec_s[0], *t2 = vec_s[1], *qk = vec_s[2], *vq = vec_s[3], *att = vec_s[4],
+        *msg = vec_s[5], *qe = vec_s[6], *ksum = vec_s[7];
 
   const Geom& g = p.g;
   const int tid = threadIdx.x;
@@ -92,80 +165,109 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   const int side = img >= g.N, n = side ? img - g.N : img;
   const int L = g.L[side], nts = g.nt[side];
   const int slot0 = g.tile0[side] + n * nts;
+  const DecLayerDev& w0 = p.layer[0];
+  const DecLayerDev& w1 = p.layer[1];
 
-  if (tid < C) { tgt[tid] = 0.f; qe[tid] = p.qe[side][tid]; }
+  // ---- layer 1 memory state: reduce the tile partials into LDS (4 tiles in flight)
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.dkv1) + (size_t)slot0 * (KV_FLOATS / 4) + tid;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    float ks = 0.f;
+    for (int ti0 = 0; ti0 < nts; ti0 += 4) {
+      f32x4 a[4], b[4];
+      float kt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t ti = min(ti0 + u, nts - 1);
+        a[u] = src[ti * (KV_FLOATS / 4)];
+        b[u] = src[ti * (KV_FLOATS / 4) + DEC_THREADS];
+        kt[u] = p.dks1[(slot0 + ti) * C + (tid & (C - 1))];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ti0 + u < nts) { s0 += a[u]; s1 += b[u]; ks += kt[u]; }
+    }
+#pragma unroll
+    for (int e2 = 0; e2 < 2; ++e2) {
+      const int e = tid + DEC_THREADS * e2;  // ((h*4+q)*64 + lane)
+      const f32x4 s = e2 ? s1 : s0;
+      const int ln = e & 63, q = (e >> 6) & 3, h = e >> 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kv_s[(h * HD + (j + 8 * q + 4 * (ln >> 5))) * HD + (ln & 31)] = s[j];
+    }
+    if (tid < C) ksum[tid] = ks;
+  }
+  // ---- layer 0 cross-attention: partial messages from the encoder tail
+  if (tid < C) {
+    float a = 0.f, z = 0.f;
+    const int h = tid >> 5;
+    for (int ti0 = 0; ti0 < nts; ti0 += 4) {
+      float av[4], zv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t ti = slot0 + min(ti0 + u, nts - 1);
+        av[u] = p.att0_part[ti * C + tid];
+        zv[u] = p.z0_part[ti * NH + h];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ti0 + u < nts) { a += av[u]; z += zv[u]; }
+    }
+    att[tid] = a * (1.0f / (z + ATTN_EPS)) * (float)L;
+    tgt[tid] = p.tgt1[side * C + tid];
+    qe[tid] = p.qe[side][tid];
+  }
+  __syncthreads();
+  gemv<C, C>(w0.cross.wm_t, att, nullptr, msg, part_s, tid);
+  if (tid < C) tgt[tid] += msg[tid];
+  __syncthreads();
+  ln_vec(tgt, w0.n3w, w0.n3b, t2, nullptr, nullptr, tid);
+  gemv<C, FF>(w0.w1_t, t2, nullptr, hdn_s, part_s, tid, true);
+  gemv<FF, C>(w0.w2_t, hdn_s, nullptr, msg, part_s, tid);
+  if (tid < C) tgt[tid] += msg[tid];
   __syncthreads();
 
-  for (int dl = 0; dl < 2; ++dl) {
-    const DecLayerDev& w = p.layer[dl];
-    // reduce this image's cross-attention states for layer dl into LDS
-    {
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.dkv[dl]) + (size_t)slot0 * (KV_FLOATS / 4);
-#pragma unroll
-      for (int e2 = 0; e2 < 2; ++e2) {
-        const int e = tid + DEC_THREADS * e2;  // ((h*4+q)*64 + lane)
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int ti = 0; ti < nts; ++ti) s += src[(size_t)ti * (KV_FLOATS / 4) + e];
-        const int ln = e & 63, q = (e >> 6) & 3, h = e >> 8;
-        const int v = ln & 31, hf = ln >> 5;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) kv_s[(h * HD + (j + 8 * q + 4 * hf)) * HD + v] = s[j];
-      }
-      if (tid < C) {
-        float s = 0.f;
-        for (int ti = 0; ti < nts; ++ti) s += p.dks[dl][(size_t)(slot0 + ti) * C + tid];
-        ksum[tid] = s;
-      }
-    }
-    // ---- self attention on the single query (L = S = 1) ----
-    ln_vec(tgt, w.n1w, w.n1b, t2, qe, qk, tid);
-    gemv<C, C>(w.self_attn.wq_t, qk, w.self_attn.bq, vq, part_s, tid);
-    gemv<C, C>(w.self_attn.wk_t, qk, w.self_attn.bk, vk, part_s, tid);
-    gemv<C, C>(w.self_attn.wv_t, t2, w.self_attn.bv, vv, part_s, tid);
-    if (tid < C) {
-      const int h = tid >> 5;
-      float z = 0.f, s = 0.f;
-      const float vval = vv[tid] / 1.0f;  // values / v_length, v_length = 1
-#pragma unroll 4
-      for (int d = 0; d < HD; ++d) {
-        const float fq = elu1(vq[h * HD + d]), fk = elu1(vk[h * HD + d]);
-        z += fq * fk;
-        s += fq * (fk * vval);
-      }
-      att[tid] = s * (1.0f / (z + ATTN_EPS)) * 1.0f;
-    }
-    __syncthreads();
-    gemv<C, C>(w.self_attn.wm_t, att, nullptr, msg, part_s, tid);
-    if (tid < C) tgt[tid] += msg[tid];
-    __syncthreads();
-    // ---- cross attention against the memory states ----
-    ln_vec(tgt, w.n2w, w.n2b, t2, qe, qk, tid);
-    gemv<C, C>(w.cross.wq_t, qk, w.cross.bq, vq, part_s, tid);
-    if (tid < C) vq[tid] = elu1(vq[tid]);
-    __syncthreads();
-    if (tid < C) {
-      const int h = tid >> 5, v = tid & 31;
-      float z = 0.f, s = 0.f;
-#pragma unroll 4
-      for (int d = 0; d < HD; ++d) {
-        const float fq = vq[h * HD + d];
-        z += fq * ksum[h * HD + d];
-        s += fq * kv_s[(h * HD + d) * HD + v];
-      }
-      att[tid] = s * (1.0f / (z + ATTN_EPS)) * (float)L;
-    }
-    __syncthreads();
-    gemv<C, C>(w.cross.wm_t, att, nullptr, msg, part_s, tid);
-    if (tid < C) tgt[tid] += msg[tid];
-    __syncthreads();
-    // ---- ReLU MLP ----
-    ln_vec(tgt, w.n3w, w.n3b, t2, nullptr, nullptr, tid);
-    gemv<C, FF>(w.w1_t, t2, nullptr, hdn_s, part_s, tid, true);
-    gemv<FF, C>(w.w2_t, hdn_s, nullptr, msg, part_s, tid);
-    if (tid < C) tgt[tid] += msg[tid];
-    __syncthreads();
+  // ---- layer 1 self-attention: fused q|k|v from LN1(tgt)
+  ln_vec(tgt, w1.n1w, w1.n1b, t2, nullptr, nullptr, tid);
+  gemv_partial<C, C>(w1.self_attn.wq_t, t2, part_s, tid);
+  gemv_partial<C, C>(w1.self_attn.wk_t, t2, part_s + 4096, tid);
+  gemv_partial<C, C>(w1.self_attn.wv_t, t2, part_s + 8192, tid);
+  __syncthreads();
+  if (tid < 3 * C) {
+    const int m = tid >> 8, o = tid & (C - 1);
+    qkv_s[tid] = gemv_collect<C, C>(part_s + 4096 * m, o) + p.qkv1[side * 3 * C + tid];
   }
-  if (tid < C) p.hs[(size_t)img * C + tid] = tgt[tid];
+  __syncthreads();
+  if (tid < C) att[tid] = self_attn_1x1(qkv_s, qkv_s + C, qkv_s[2 * C + tid], tid);
+  __syncthreads();
+  gemv<C, C>(w1.self_attn.wm_t, att, nullptr, msg, part_s, tid);
+  if (tid < C) tgt[tid] += msg[tid];
+  __syncthreads();
+  // ---- layer 1 cross-attention against the memory state
+  ln_vec(tgt, w1.n2w, w1.n2b, t2, qe, qk, tid);
+  gemv<C, C>(w1.cross.wq_t, qk, w1.cross.bq, vq, part_s, tid);
+  if (tid < C) vq[tid] = elu1(vq[tid]);
+  __syncthreads();
+  if (tid < C) {
+    const int h = tid >> 5, v = tid & 31;
+    float z = 0.f, s = 0.f;
+#pragma unroll 4
+    for (int d = 0; d < HD; ++d) {
+      const float fq = vq[h * HD + d];
+      z += fq * ksum[h * HD + d];
+      s += fq * kv_s[(h * HD + d) * HD + v];
+    }
+    att[tid] = s * (1.0f / (z + ATTN_EPS)) * (float)L;
+  }
+  __syncthreads();
+  gemv<C, C>(w1.cross.wm_t, att, nullptr, msg, part_s, tid);
+  if (tid < C) tgt[tid] += msg[tid];
+  __syncthreads();
+  // ---- ReLU MLP
+  ln_vec(tgt, w1.n3w, w1.n3b, t2, nullptr, nullptr, tid);
+  gemv<C, FF>(w1.w1_t, t2, nullptr, hdn_s, part_s, tid, true);
+  gemv<FF, C>(w1.w2_t, hdn_s, nullptr, msg, part_s, tid);
+  if (tid < C) p.hs[(size_t)img * C + tid] = tgt[tid] + msg[tid];
 }
 
 hipError_t launch_decoder(const DecLaunch& p, hipStream_t s) {

@@ -404,7 +404,45 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
       }
       gemm_rows32<C, 2>(S1, LDA, p.d.wk[dl], 2 * wave, lane, accK, p.dbg);
       gemm_rows32<C, 2>(S0, LDA, p.d.wv[dl], 2 * wave, lane, accV, p.dbg);
-      kv_state_store(accK, accV, ABL(p.dbg, ABL_ELU) ? 1.f : 0.f, L, nvalid, lane, wave, p.dkv_out[dl], p.dks_out[dl], slot);
+      if (dl == 1) {
+        kv_state_store(accK, accV, ABL(p.dbg, ABL_ELU) ? 1.f : 0.f, L, nvalid, lane, wave,
+                       p.dkv1_out, p.dks1_out, slot);
+      } else {
+        // Decoder layer 0's query is a create-time constant q0 (decoder.hip), and
+        // its cross-attention is linear in the state, so this tile contributes
+        //   att0[h,v] += sum_d q0[h,d] * KV_tile[h][d][v],  z0[h] += q0[h,:].Ksum_tile[h,:]
+        // instead of a full 8192-float state.
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int h = 2 * wave + t;
+          float ksum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = crow(r, half) < nvalid;
+            accK[t][r] = ok ? elu1(accK[t][r]) : 0.f;
+            accV[t][r] = ok ? accV[t][r] / (float)L : 0.f;
+            ksum += accK[t][r];
+          }
+          f32x16 kv = {0};
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(accK[t][r], accV[t][r], kv, 0, 0, 0);
+          const float* q0 = p.dec_q0 + side * C + h * HD;
+          float a = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a += q0[crow(r, half)] * kv[r];
+          a += __shfl_xor(a, 32, 64);
+          ksum += __shfl_xor(ksum, 32, 64);
+          float z = q0[col] * ksum;  // lanes col and col+32 hold the same value
+          z += __shfl_xor(z, 1, 64);
+          z += __shfl_xor(z, 2, 64);
+          z += __shfl_xor(z, 4, 64);
+          z += __shfl_xor(z, 8, 64);
+          z += __shfl_xor(z, 16, 64);
+          if (half == 0) p.att0_out[(size_t)slot * C + h * HD + col] = a;
+          if (lane == 0) p.z0_out[(size_t)slot * NH + h] = z;
+        }
+      }
     }
   }
 }

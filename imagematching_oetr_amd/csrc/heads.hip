@@ -200,6 +200,42 @@ __global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
     p.cxy[side][2 * n] = sx;
     p.cxy[side][2 * n + 1] = sy;
   }
+  if (!p.box[side]) return;
+
+  // ---- fused tail of the forward path: size regression + box (model.py:188-191,
+  // models/utils.py:16-28) for this image, saving two launches.
+  __shared__ float h_s[C], hid_part[4][C], hid_s[C], tl_s[4];
+  if (tid < C) h_s[tid] = p.hs[side][(size_t)n * C + tid];
+  __syncthreads();
+  {
+    const int kc = tid >> 8, o = tid & (C - 1);
+    float a = 0.f;
+#pragma unroll 16
+    for (int k = kc * 64; k < kc * 64 + 64; ++k) a += p.w.tlbr0_t[k * C + o] * h_s[k];
+    hid_part[kc][o] = a;
+  }
+  __syncthreads();
+  if (tid < C)
+    hid_s[tid] = fmaxf((hid_part[0][tid] + hid_part[1][tid]) + (hid_part[2][tid] + hid_part[3][tid]), 0.f);
+  __syncthreads();
+  if (wave < 4) {
+    const f32x4 wv = reinterpret_cast<const f32x4*>(p.w.tlbr2_w + wave * C)[lane];
+    const f32x4 hv = reinterpret_cast<const f32x4*>(hid_s)[lane];
+    float d = wave_sum((wv[0] * hv[0] + wv[1] * hv[1]) + (wv[2] * hv[2] + wv[3] * hv[3]));
+    if (lane == 0) tl_s[wave] = 1.0f / (1.0f + expf(-(d + p.w.tlbr2_b[wave])));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float mh = (float)p.img_h[side], mw = (float)p.img_w[side];
+    const float t = tl_s[0] * mh, l = tl_s[1] * mw, b = tl_s[2] * mh, r = tl_s[3] * mw;
+    float* box = p.box[side] + 4 * n;
+    box[0] = fminf(fmaxf(sx - l, 0.f), mw);
+    box[1] = fminf(fmaxf(sy - t, 0.f), mh);
+    box[2] = fminf(fmaxf(sx + r, 0.f), mw);
+    box[3] = fminf(fmaxf(sy + b, 0.f), mh);
+    if (p.tlbr[side])
+      for (int j = 0; j < 4; ++j) p.tlbr[side][4 * n + j] = tl_s[j];
+  }
 }
 
 hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s) {
