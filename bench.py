@@ -33,6 +33,7 @@ sys.path.insert(0, str(REPO))
 PAIR_GFLOP_640 = 8.365            # BASELINE.md §4, hot path per 640x640 pair
 ENC_FLOP_PER_TOKEN = 16 * 256 * 256 + 4 * 256 * 32   # one B;A launch
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 DOMINANT = 'k_encoder<B,A>'
 
 
@@ -119,6 +120,8 @@ def main():
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true')
+    ap.add_argument('--precision', default='f32_split_f16', choices=['f32_split_f16', 'f32'],
+                    help='GEMM arithmetic: 3 f16 MFMAs per fp32 product (default) or exact f32 MFMA')
     ap.add_argument('--no-trace', action='store_true',
                     help='do not record per-kernel events in the timed region')
     args = ap.parse_args()
@@ -142,7 +145,7 @@ def main():
     torch.set_grad_enabled(False)
     n = args.pairs_per_gpu
     model, weights, feat1, feat2, pos, hf = synthetic_inputs(n, args.size, device)
-    eng = pkg.HotPathEngine(weights, device=device)
+    eng = pkg.HotPathEngine(weights, device=device, precision=args.precision)
     hw = (args.size, args.size)
     n_total = n * world
 
@@ -197,6 +200,8 @@ def main():
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'gemm_mode': ('fp32-class products from 3 f16 MFMAs (a=ah+al/2^11 split), fp32 accumulate'
+                      if args.precision == 'f32_split_f16' else 'exact fp32 MFMA'),
         'data': 'synthetic',
         'config': {'workload': f'BASELINE configs[1]: batch={n} pairs/GPU, '
                                f'{args.size}x{args.size} -> {hf}x{hf} tokens/image, '
@@ -210,12 +215,18 @@ def main():
     if kern and DOMINANT in kern:
         launches, total_ms = kern[DOMINANT]
         avg_ms = total_ms / launches
-        flop = ENC_FLOP_PER_TOKEN * 2 * n * hf * hf     # tokens of both sides
-        ach = flop / (avg_ms * 1e-3) / 1e12
+        flop = ENC_FLOP_PER_TOKEN * 2 * n * hf * hf     # tokens of both sides (algorithmic)
+        split = args.precision == 'f32_split_f16'
+        # split mode executes 3 f16 MFMA products per algorithmic product
+        executed = flop * (3 if split else 1)
+        peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
+        ach = executed / (avg_ms * 1e-3) / 1e12
         out['roofline'] = {
             'kernel': DOMINANT, 'bound': 'mfma', 'achieved': round(ach, 2),
-            'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+            'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'mfma_dtype': 'f16 (3 products per fp32 product)' if split else 'f32',
+            'achieved_algorithmic_tflops': round(flop / (avg_ms * 1e-3) / 1e12, 2),
+            'frac_of_f32_mfma_peak': round(flop / (avg_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
             'traffic': pmc_traffic_bytes('k_encoderILb1ELi0E') if (n, args.size) == (8, 640) else None,
             'avg_launch_us': round(avg_ms * 1e3, 2), 'launches': launches,
             'flop_per_launch': flop,

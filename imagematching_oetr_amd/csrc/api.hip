@@ -54,6 +54,36 @@ struct Packer {
           }
     return off;
   }
+  // W [nout][k] -> two f16 planes (hi, lo*2^11) in f16 MFMA B-fragment order
+  // (common.h: gemm_rows32_h); returns offsets (in floats) of both planes.
+  void frag_h(const float* W, int nout, int k, size_t* hi_off, size_t* lo_off, int ld = -1,
+              int stride_k = 1) {
+    if (ld < 0) ld = k;
+    const int ks_n = k / 16;
+    const size_t plane_floats = (size_t)nout * k / 2;
+    *hi_off = reserve_aligned(plane_floats);
+    *lo_off = reserve_aligned(plane_floats);
+    _Float16* hi = reinterpret_cast<_Float16*>(buf.data() + *hi_off);
+    _Float16* lo = reinterpret_cast<_Float16*>(buf.data() + *lo_off);
+    for (int nt = 0; nt < nout / 32; ++nt)
+      for (int ks = 0; ks < ks_n; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int n = nt * 32 + (lane & 31);
+            const int kk = ks * 16 + 8 * (lane >> 5) + j;
+            const float w = W[(size_t)n * ld + (size_t)kk * stride_k];
+            const _Float16 h = (_Float16)w;
+            const size_t idx = (((size_t)nt * ks_n + ks) * 64 + lane) * 8 + j;
+            hi[idx] = h;
+            lo[idx] = (_Float16)((w - (float)h) * SPLIT_SCALE);
+          }
+  }
+  // one GEMM weight in the representation of the chosen mode
+  void gemm_weight(bool split, const float* W, int nout, int k, size_t* a, size_t* b, int ld = -1,
+                   int stride_k = 1) {
+    if (split) frag_h(W, nout, k, a, b, ld, stride_k);
+    else { *a = frag(W, nout, k, ld, stride_k); *b = *a; }
+  }
   // W [nout][k] -> transposed [k][nout]
   size_t transposed(const float* W, int nout, int k) {
     size_t off = reserve_aligned((size_t)nout * k);
@@ -87,6 +117,7 @@ struct oetr_trace {
 struct oetr_ctx {
   oetr_trace* trace = nullptr;
   int device = 0;
+  bool split = false;  // OETR_DTYPE_F32_SPLIT_F16
   float* dev = nullptr;  // all repacked weights
   size_t dev_floats = 0;
   EncLayerDev enc[OETR_N_ENC];
@@ -209,7 +240,7 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
   p.a = h->enc[0];
   p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];
-  TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, s));
+  TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, h->split, s));
   for (int l = 0; l < enc_layers; ++l) {
     p.b = h->enc[l];
     p.b_cross = l & 1;
@@ -228,7 +259,7 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
       tail = 2;
     }
     TRACED(h, s, tail == 0 ? K_ENC_BA : tail == 1 ? K_ENC_BDEC : K_ENC_B,
-           launch_encoder(p, true, tail, s));
+           launch_encoder(p, true, tail, h->split, s));
   }
   if (enc_layers == OETR_N_ENC) {
     DecLaunch d;
@@ -259,7 +290,9 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   if (!w || !out) return fail(OETR_ERR_BAD_ARG, "oetr_create: NULL argument");
   if (w->struct_size != sizeof(oetr_weights) || w->abi_version != OETR_ABI_VERSION)
     return fail(OETR_ERR_BAD_ARG, "oetr_create: oetr_weights size/ABI mismatch");
-  if (dtype != OETR_DTYPE_F32) return fail(OETR_ERR_UNSUPPORTED, "only OETR_DTYPE_F32 is built");
+  if (dtype != OETR_DTYPE_F32 && dtype != OETR_DTYPE_F32_SPLIT_F16)
+    return fail(OETR_ERR_UNSUPPORTED, "dtype must be OETR_DTYPE_F32 or OETR_DTYPE_F32_SPLIT_F16");
+  const bool split = dtype == OETR_DTYPE_F32_SPLIT_F16;
   {  // every pointer must be set
     const float* const* p = reinterpret_cast<const float* const*>(&w->enc[0]);
     const size_t n = (sizeof(oetr_weights) - offsetof(oetr_weights, enc)) / sizeof(float*);
@@ -278,25 +311,26 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
 
   oetr_ctx* h = new oetr_ctx();
   h->device = device;
+  h->split = split;
   Packer pk;
-  struct EncOff { size_t wq, wk, wv, wm, w1, w2, v[6]; } eo[OETR_N_ENC];
+  struct EncOff { size_t wq, wk, wv, wm, w1, w2, wq_l, wk_l, wv_l, wm_l, w1_l, w2_l, v[6]; } eo[OETR_N_ENC];
   for (int l = 0; l < OETR_N_ENC; ++l) {
     const oetr_encoder_layer_weights& e = w->enc[l];
-    eo[l].wq = pk.frag(e.q_proj, C, C);
-    eo[l].wk = pk.frag(e.k_proj, C, C);
-    eo[l].wv = pk.frag(e.v_proj, C, C);
-    eo[l].wm = pk.frag(e.merge, C, C);
-    eo[l].w1 = pk.frag(e.mlp0, FF, C);
-    eo[l].w2 = pk.frag(e.mlp2, C, FF);
+    pk.gemm_weight(split, e.q_proj, C, C, &eo[l].wq, &eo[l].wq_l);
+    pk.gemm_weight(split, e.k_proj, C, C, &eo[l].wk, &eo[l].wk_l);
+    pk.gemm_weight(split, e.v_proj, C, C, &eo[l].wv, &eo[l].wv_l);
+    pk.gemm_weight(split, e.merge, C, C, &eo[l].wm, &eo[l].wm_l);
+    pk.gemm_weight(split, e.mlp0, FF, C, &eo[l].w1, &eo[l].w1_l);
+    pk.gemm_weight(split, e.mlp2, C, FF, &eo[l].w2, &eo[l].w2_l);
     const float* vecs[6] = {e.pre_norm_q_w, e.pre_norm_q_b, e.pre_norm_kv_w,
                             e.pre_norm_kv_b, e.norm2_w, e.norm2_b};
     for (int i = 0; i < 6; ++i) eo[l].v[i] = pk.copy(vecs[i], C);
   }
-  struct DecOff { size_t ck, cv, cbk, cbv, m[2][7], w1, w2, n[6]; } dof[OETR_N_DEC];
+  struct DecOff { size_t ck, cv, ck_l, cv_l, cbk, cbv, m[2][7], w1, w2, n[6]; } dof[OETR_N_DEC];
   for (int l = 0; l < OETR_N_DEC; ++l) {
     const oetr_decoder_layer_weights& d = w->dec[l];
-    dof[l].ck = pk.frag(d.multihead_attn.k_proj_w, C, C);
-    dof[l].cv = pk.frag(d.multihead_attn.v_proj_w, C, C);
+    pk.gemm_weight(split, d.multihead_attn.k_proj_w, C, C, &dof[l].ck, &dof[l].ck_l);
+    pk.gemm_weight(split, d.multihead_attn.v_proj_w, C, C, &dof[l].cv, &dof[l].cv_l);
     dof[l].cbk = pk.copy(d.multihead_attn.k_proj_b, C);
     dof[l].cbv = pk.copy(d.multihead_attn.v_proj_b, C);
     const oetr_mha_weights* mh[2] = {&d.self_attn, &d.multihead_attn};
@@ -316,10 +350,26 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   }
   const size_t qe1 = pk.copy(w->query_embed1, C), qe2 = pk.copy(w->query_embed2, C);
   // conv weight [o][i][ky][kx] -> 9 fragment-packed [o][i] matrices, tap = ky*3+kx
-  size_t conv_off = 0;
-  for (int tap = 0; tap < 9; ++tap) {
-    const size_t o = pk.frag(w->heat_conv_w + tap, C, C, /*ld=*/C * 9, /*stride_k=*/9);
-    if (tap == 0) conv_off = o;
+  // (taps are consecutive: f32 mode one array of 9 matrices; split mode all 9 hi
+  //  planes then all 9 lo planes)
+  size_t conv_off = 0, conv_off_l = 0;
+  if (!split) {
+    for (int tap = 0; tap < 9; ++tap) {
+      const size_t o = pk.frag(w->heat_conv_w + tap, C, C, /*ld=*/C * 9, /*stride_k=*/9);
+      if (tap == 0) conv_off = o;
+    }
+    conv_off_l = conv_off;
+  } else {
+    std::vector<size_t> hi(9), lo(9);
+    Packer tmp;  // pack per tap, then lay the planes out contiguously per kind
+    for (int tap = 0; tap < 9; ++tap) tmp.frag_h(w->heat_conv_w + tap, C, C, &hi[tap], &lo[tap], C * 9, 9);
+    const size_t plane = (size_t)C * C / 2;
+    conv_off = pk.reserve_aligned(9 * plane);
+    conv_off_l = pk.reserve_aligned(9 * plane);
+    for (int tap = 0; tap < 9; ++tap) {
+      memcpy(pk.buf.data() + conv_off + tap * plane, tmp.buf.data() + hi[tap], plane * sizeof(float));
+      memcpy(pk.buf.data() + conv_off_l + tap * plane, tmp.buf.data() + lo[tap], plane * sizeof(float));
+    }
   }
   const size_t conv_b = pk.copy(w->heat_conv_b, C), gn_w = pk.copy(w->heat_gn_w, C),
                gn_b = pk.copy(w->heat_gn_b, C), out_w = pk.copy(w->heat_out_w, C),
@@ -347,12 +397,15 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
     EncLayerDev& d = h->enc[l];
     d.wq = F4(eo[l].wq); d.wk = F4(eo[l].wk); d.wv = F4(eo[l].wv); d.wmerge = F4(eo[l].wm);
     d.w1 = F4(eo[l].w1); d.w2 = F4(eo[l].w2);
+    d.wq_l = F4(eo[l].wq_l); d.wk_l = F4(eo[l].wk_l); d.wv_l = F4(eo[l].wv_l);
+    d.wmerge_l = F4(eo[l].wm_l); d.w1_l = F4(eo[l].w1_l); d.w2_l = F4(eo[l].w2_l);
     d.lnq_w = B + eo[l].v[0]; d.lnq_b = B + eo[l].v[1];
     d.lnkv_w = B + eo[l].v[2]; d.lnkv_b = B + eo[l].v[3];
     d.ln2_w = B + eo[l].v[4]; d.ln2_b = B + eo[l].v[5];
   }
   for (int l = 0; l < OETR_N_DEC; ++l) {
     h->dkv.wk[l] = F4(dof[l].ck); h->dkv.wv[l] = F4(dof[l].cv);
+    h->dkv.wk_l[l] = F4(dof[l].ck_l); h->dkv.wv_l[l] = F4(dof[l].cv_l);
     h->dkv.bk[l] = B + dof[l].cbk; h->dkv.bv[l] = B + dof[l].cbv;
     DecLayerDev& d = h->dec[l];
     MhaDev* mh[2] = {&d.self_attn, &d.cross};
@@ -383,6 +436,7 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
     }
   }
   h->heads.conv_w = F4(conv_off);
+  h->heads.conv_w_l = F4(conv_off_l);
   h->heads.conv_b = B + conv_b; h->heads.gn_w = B + gn_w; h->heads.gn_b = B + gn_b;
   h->heads.out_w = B + out_w; h->heads.out_b = B + out_b;
   h->heads.tlbr0_t = B + t0; h->heads.tlbr2_w = B + t2w; h->heads.tlbr2_b = B + t2b;
@@ -458,7 +512,7 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
   hp.tlbr[0] = tl1; hp.tlbr[1] = tl2;
   hp.box[0] = box1; hp.box[1] = box2;
   hp.img_w[0] = img_w1; hp.img_w[1] = img_w2;
-  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, s));
+  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, h->split, s));
   TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));  // + size regression + boxes
   if (st) {
     if ((rc = copy_out(st->hs1, hs1, (size_t)g.N * C, s))) return rc;
@@ -522,7 +576,7 @@ oetr_status oetr_center_estimation(oetr_handle h, const float* hs1, const float*
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HeatLaunch hp = heat_launch(h, g, w, memory1, memory2, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
-  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, s));
+  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, h->split, s));
   TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));
   return OETR_OK;
 }

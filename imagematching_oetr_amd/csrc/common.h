@@ -30,6 +30,20 @@ enum { ABL_KVREDUCE = 1, ABL_GELU = 2, ABL_ELU = 4, ABL_LN = 8, ABL_GEMM = 16, A
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// "f32 via split f16" GEMM mode: a = ah + al/2^11 with ah = f16(a),
+// al = f16((a - ah) * 2^11); a*b ~= ah*bh + (ah*bl + al*bh)/2^11 on
+// v_mfma_f32_32x32x16_f16 (3 MFMAs, 16x the f32 MFMA rate each) with f32
+// accumulation.  Dropped al*bl term and the rounding of al are ~2^-22 relative:
+// fp32-class results (measured against fp64: same error as torch fp32, see
+// DESIGN.md §3.6).  Inputs must stay below the f16 range (65504).
+constexpr float SPLIT_SCALE = 2048.0f;
+constexpr float SPLIT_INV = 1.0f / 2048.0f;
+constexpr int LDAH = C + 8;    // row stride (halves) of a [TM][256] f16 plane: 528 B = conflict-free b128
+constexpr int LDHH = FF + 8;   // row stride (halves) of a [TM][512] f16 plane
 
 // Token geometry of one forward call. "side" 0/1 = image1/image2 batch.
 struct Geom {
@@ -203,6 +217,123 @@ __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda
   }
 }
 
+// ---- split-f16 GEMM core -------------------------------------------------
+// hi/lo halves of two floats: (hi0,hi1) and (lo0,lo1) packed as f16x2.
+__device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
+  // round-to-nearest conversions (v_cvt_f16_f32); a - (float)hi is exact in f32
+  hi = f16x2{(_Float16)a, (_Float16)b};
+  lo = f16x2{(_Float16)((a - (float)hi[0]) * SPLIT_SCALE),
+             (_Float16)((b - (float)hi[1]) * SPLIT_SCALE)};
+}
+// Store 4 consecutive floats of a row as 4 hi halves + 4 lo halves (8-byte stores).
+__device__ __forceinline__ void store_split4(_Float16* hi_row, _Float16* lo_row, int c,
+                                             const f32x4& v) {
+  f16x2 h0, l0, h1, l1;
+  split2(v[0], v[1], h0, l0);
+  split2(v[2], v[3], h1, l1);
+  *reinterpret_cast<f16x4*>(hi_row + c) = f16x4{h0[0], h0[1], h1[0], h1[1]};
+  *reinterpret_cast<f16x4*>(lo_row + c) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+template <int NT, int U>
+struct GemmRegsH {
+  f32x4 bh[U][NT], bl[U][NT];  // 8 halves each (raw 16-byte fragments)
+  f32x4 ah[U], al[U];
+};
+
+// acc[t] += A[32 x K] * W_tile(nt0 + t) with both operands split (see above).
+//   Ahi/Alo: LDS f16 planes, row stride lda halves.
+//   Whi/Wlo: weights in f16 fragment order: 16-byte unit ((ntile*K/16 + ks)*64 + lane)
+//            holds, for output column n = 32*ntile + (lane&31), inputs
+//            k = 16*ks + 8*(lane>>5) + {0..7}.
+//   acc = main + cross/2^11 is formed at the end; `acc` enters as the initial main part.
+template <int K, int NT, int U = 4>
+__device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
+                                              const _Float16* __restrict__ Alo, int lda,
+                                              const f32x4* __restrict__ Whi,
+                                              const f32x4* __restrict__ Wlo, int nt0, int lane,
+                                              f32x16 (&acc)[NT]) {
+  constexpr int KS = K / 16;
+  constexpr int NCH = KS / U;
+  static_assert(KS % (2 * U) == 0, "K must be a multiple of 32*U");
+  const int a_off = (lane & 31) * lda + 8 * (lane >> 5);
+  const _Float16* ah_ptr = Ahi + a_off;
+  const _Float16* al_ptr = Alo + a_off;
+  const f32x4* wh_ptr[NT];
+  const f32x4* wl_ptr[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    wh_ptr[t] = Whi + (size_t)(nt0 + t) * KS * 64 + lane;
+    wl_ptr[t] = Wlo + (size_t)(nt0 + t) * KS * 64 + lane;
+  }
+  f32x16 cross[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) cross[t] = f32x16{0};
+
+  auto fetch = [&](GemmRegsH<NT, U>& r, int chunk) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        r.bh[u][t] = wh_ptr[t][(chunk * U + u) * 64];
+        r.bl[u][t] = wl_ptr[t][(chunk * U + u) * 64];
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      r.ah[u] = *reinterpret_cast<const f32x4*>(ah_ptr + (chunk * U + u) * 16);
+      r.al[u] = *reinterpret_cast<const f32x4*>(al_ptr + (chunk * U + u) * 16);
+    }
+  };
+  auto mma = [&](const GemmRegsH<NT, U>& r) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f16x8 ah = __builtin_bit_cast(f16x8, r.ah[u]), al = __builtin_bit_cast(f16x8, r.al[u]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, r.bh[u][t]);
+        const f16x8 bl = __builtin_bit_cast(f16x8, r.bl[u][t]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+        cross[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cross[t], 0, 0, 0);
+        cross[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cross[t], 0, 0, 0);
+      }
+    }
+  };
+
+  GemmRegsH<NT, U> r0, r1;
+  fetch(r0, 0);
+  for (int c = 0; c < NCH; c += 2) {
+    fetch(r1, c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(r0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 < NCH) fetch(r0, c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(r1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(cross[t][r], SPLIT_INV, acc[t][r]);
+}
+
+// Accumulator tiles -> split f16 planes (columns col0 + 32*t + lane&31).
+template <int NT>
+__device__ __forceinline__ void acc_to_lds_split(_Float16* Shi, _Float16* Slo, int lds, int col0,
+                                                 int lane, const f32x16 (&acc)[NT]) {
+  const int half = lane >> 5, c = col0 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f16x2 hi, lo;
+      split2(acc[t][r], acc[t][r + 1], hi, lo);
+      const int o0 = crow(r, half) * lds + c + 32 * t, o1 = crow(r + 1, half) * lds + c + 32 * t;
+      Shi[o0] = hi[0]; Shi[o1] = hi[1];
+      Slo[o0] = lo[0]; Slo[o1] = lo[1];
+    }
+}
+
 // Write a wave's two 32x32 accumulator tiles (columns col0 + 32*t + lane&31)
 // into a row-major LDS tile.
 template <int NT>
@@ -215,17 +346,52 @@ __device__ __forceinline__ void acc_to_lds(float* S, int lds, int col0, int lane
     for (int r = 0; r < 16; ++r) S[crow(r, half) * lds + c + 32 * t] = acc[t][r];
 }
 
+// LDS region sizes (floats) that fit either representation of an A tile.
+constexpr int TILE_FLOATS = (2 * TM * LDAH * 2 + 3) / 4;    // 8448 >= TM*LDA = 8320
+constexpr int HID_FLOATS = (2 * TM * LDHH * 2 + 3) / 4;     // 16640 >= TM*LDH = 16512
+static_assert(TILE_FLOATS >= TM * LDA && HID_FLOATS >= TM * LDH, "region sizes");
+
+// A GEMM A-operand tile in LDS, in either representation.
+template <bool SPLIT>
+struct ATile {
+  float* f;        // f32 mode
+  _Float16 *h, *l; // split mode planes
+  int ldf, ldh;
+  __device__ __forceinline__ ATile(float* base, int ldf_, int ldh_)
+      : f(base), h(reinterpret_cast<_Float16*>(base)),
+        l(reinterpret_cast<_Float16*>(base) + TM * ldh_), ldf(ldf_), ldh(ldh_) {}
+  // 4 consecutive values of one row
+  __device__ __forceinline__ void put4(int row, int c, const f32x4& v) const {
+    if (SPLIT) store_split4(h + row * ldh, l + row * ldh, c, v);
+    else *reinterpret_cast<f32x4*>(f + row * ldf + c) = v;
+  }
+  template <int NT>
+  __device__ __forceinline__ void put_acc(int col0, int lane, const f32x16 (&acc)[NT]) const {
+    if (SPLIT) acc_to_lds_split<NT>(h, l, ldh, col0, lane, acc);
+    else acc_to_lds<NT>(f, ldf, col0, lane, acc);
+  }
+  template <int K, int NT>
+  __device__ __forceinline__ void gemm(const f32x4* w, const f32x4* w_lo, int nt0, int lane,
+                                       f32x16 (&acc)[NT], int dbg) const {
+    if (SPLIT) gemm_rows32_h<K, NT>(h, l, ldh, w, w_lo, nt0, lane, acc);
+    else gemm_rows32<K, NT>(f, ldf, w, nt0, lane, acc, dbg);
+  }
+};
+
 #endif  // __HIPCC__
 
 // ------------------------------------------------------------------ host
 // Repacked weights of one encoder layer (device pointers).
 struct EncLayerDev {
-  const f32x4 *wq, *wk, *wv, *wmerge, *w1, *w2;  // fragment-packed
+  const f32x4 *wq, *wk, *wv, *wmerge, *w1, *w2;  // fragment-packed (f32 mode: values;
+                                                 //  split mode: f16 hi plane)
+  const f32x4 *wq_l, *wk_l, *wv_l, *wmerge_l, *w1_l, *w2_l;  // split mode: f16 lo plane
   const float *lnq_w, *lnq_b, *lnkv_w, *lnkv_b, *ln2_w, *ln2_b;
 };
 // Decoder cross-attention K/V projections applied to the encoder memory.
 struct DecKVDev {
   const f32x4 *wk[2], *wv[2];
+  const f32x4 *wk_l[2], *wv_l[2];  // split mode lo planes
   const float *bk[2], *bv[2];
 };
 
@@ -256,7 +422,7 @@ struct EncLaunch {
 hipError_t launch_prep_tokens(const Geom& g, const float* feat1, const float* feat2,
                               const float* pos1, const float* pos2, float* x,
                               float* pos_tok, hipStream_t s);
-hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, hipStream_t s);
+hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, bool split, hipStream_t s);
 
 struct MhaDev {
   const float *wq_t, *wk_t, *wv_t, *wm_t;  // transposed [in][out]
@@ -289,6 +455,7 @@ hipError_t launch_decoder(const DecLaunch& p, hipStream_t s);
 
 struct HeadsDev {
   const f32x4* conv_w;     // 9 taps x fragment-packed [256 out][256 in]
+  const f32x4* conv_w_l;   // split mode lo plane
   const float *conv_b, *gn_w, *gn_b, *out_w, *out_b;
   const float *tlbr0_t;    // [256 in][256 out] transposed
   const float *tlbr2_w, *tlbr2_b;  // [4][256], [4]
@@ -308,7 +475,7 @@ struct HeatLaunch {
   float* box[2];           // [N][4] per side, or NULL
   int img_w[2];
 };
-hipError_t launch_heat_conv(const HeatLaunch& p, hipStream_t s);
+hipError_t launch_heat_conv(const HeatLaunch& p, bool split, hipStream_t s);
 hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s);
 hipError_t launch_size_regression(const HeadsDev& w, const float* hs1, const float* hs2,
                                   int n, float* tlbr1, float* tlbr2, hipStream_t s);

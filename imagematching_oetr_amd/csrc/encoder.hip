@@ -86,10 +86,13 @@ hipError_t launch_prep_tokens(const Geom& g, const float* feat1, const float* fe
 // ---------------------------------------------------------------------------
 // Fused  B(l) ; A(l+1)  kernel.
 // ---------------------------------------------------------------------------
-constexpr int S0_OFF = 0;
+// LDS regions (floats).  S1/S2/H hold a GEMM A operand: an f32 tile [32][260]
+// (resp. [32][516]) in f32 mode, or two f16 planes (hi, lo) [32][264] (resp.
+// [32][520]) in split mode - nearly the same bytes.
+constexpr int S0_OFF = 0;                                   // f32 tile (LN input, phi(Q))
 constexpr int S1_OFF = S0_OFF + TM * LDA;
-constexpr int H_OFF = S1_OFF + TM * LDA;  // hidden tile; S2 aliases its start
-constexpr int KSUM_OFF = H_OFF + TM * LDH;
+constexpr int H_OFF = S1_OFF + TILE_FLOATS;  // hidden tile; S2 aliases its start
+constexpr int KSUM_OFF = H_OFF + HID_FLOATS;
 constexpr int Z_OFF = KSUM_OFF + C;
 constexpr int SMEM_FLOATS = Z_OFF + TM * NH;
 
@@ -154,13 +157,13 @@ __device__ __forceinline__ void kv_state_store(f32x16 (&accK)[2], f32x16 (&accV)
   }
 }
 
-template <bool HAS_B, int TAIL>
+template <bool HAS_B, int TAIL, bool SPLIT>
 __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* S0 = smem + S0_OFF;
-  float* S1 = smem + S1_OFF;
-  float* Hh = smem + H_OFF;
-  float* S2 = Hh;
+  const ATile<SPLIT> S1(smem + S1_OFF, LDA, LDAH);
+  const ATile<SPLIT> S2(smem + H_OFF, LDA, LDAH);
+  const ATile<SPLIT> Hh(smem + H_OFF, LDH, LDHH);
   float* ksum_s = smem + KSUM_OFF;
   float* z_s = smem + Z_OFF;
 
@@ -281,13 +284,13 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          S1[crow(r, half) * LDA + (2 * wave + t) * HD + col] = macc[t][r] * zr[t][r] * (float)S_len;
+        for (int r = 0; r < 16; ++r) macc[t][r] = macc[t][r] * zr[t][r] * (float)S_len;
+      S1.template put_acc<2>(64 * wave, lane, macc);
     }
     __syncthreads();
 
     // x1 = x + message . Wmerge^T
-    gemm_rows32<C, 2>(S1, LDA, p.b.wmerge, 2 * wave, lane, xacc, p.dbg);
+    S1.template gemm<C, 2>(p.b.wmerge, p.b.wmerge_l, 2 * wave, lane, xacc, p.dbg);
     acc_to_lds<2>(S0, LDA, 64 * wave, lane, xacc);
     __syncthreads();
 
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
       ln_rows8(S0, tid, xn, p.dbg);
       const f32x4* gw = reinterpret_cast<const f32x4*>(p.b.ln2_w) + (tid & 7);
       const f32x4* gb = reinterpret_cast<const f32x4*>(p.b.ln2_b) + (tid & 7);
-      f32x4* dst = reinterpret_cast<f32x4*>(S1 + (tid >> 3) * LDA) + (tid & 7);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dst[i * 8] = xn[i] * gw[i * 8] + gb[i * 8];
+      for (int i = 0; i < 8; ++i)
+        S1.put4(tid >> 3, 4 * (i * 8 + (tid & 7)), xn[i] * gw[i * 8] + gb[i * 8]);
     }
     __syncthreads();
 
@@ -307,17 +310,17 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
 #pragma unroll
     for (int cpart = 0; cpart < 2; ++cpart) {
       f32x16 hacc[2] = {{0}, {0}};
-      gemm_rows32<C, 2>(S1, LDA, p.b.w1, 4 * wave + 2 * cpart, lane, hacc, p.dbg);
+      S1.template gemm<C, 2>(p.b.w1, p.b.w1_l, 4 * wave + 2 * cpart, lane, hacc, p.dbg);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[t][r] = ABL(p.dbg, ABL_GELU) ? hacc[t][r] : gelu_erf(hacc[t][r]);
-      acc_to_lds<2>(Hh, LDH, 128 * wave + 64 * cpart, lane, hacc);
+      Hh.template put_acc<2>(128 * wave + 64 * cpart, lane, hacc);
     }
     __syncthreads();
 
     // x2 = x1 + hidden . W2^T ; write back
-    gemm_rows32<FF, 2>(Hh, LDH, p.b.w2, 2 * wave, lane, xacc, p.dbg);
+    Hh.template gemm<FF, 2>(p.b.w2, p.b.w2_l, 2 * wave, lane, xacc, p.dbg);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -352,20 +355,18 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
       const f32x4* qb = reinterpret_cast<const f32x4*>(p.a.lnq_b) + part;
       const f32x4* kw = reinterpret_cast<const f32x4*>(p.a.lnkv_w) + part;
       const f32x4* kb = reinterpret_cast<const f32x4*>(p.a.lnkv_b) + part;
-      f32x4* dq = reinterpret_cast<f32x4*>(S1 + r * LDA) + part;
-      f32x4* dk = reinterpret_cast<f32x4*>(S2 + r * LDA) + part;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const f32x4 ps = pos[i * 8];
-        dq[i * 8] = (xn[i] * qw[i * 8] + qb[i * 8]) + ps;
-        dk[i * 8] = (xn[i] * kw[i * 8] + kb[i * 8]) + ps;
+        S1.put4(r, 4 * (i * 8 + part), (xn[i] * qw[i * 8] + qb[i * 8]) + ps);
+        S2.put4(r, 4 * (i * 8 + part), (xn[i] * kw[i * 8] + kb[i * 8]) + ps);
       }
     }
     __syncthreads();
 
     {  // phi(Q) -> HBM
       f32x16 acc[2] = {{0}, {0}};
-      gemm_rows32<C, 2>(S1, LDA, p.a.wq, 2 * wave, lane, acc, p.dbg);
+      S1.template gemm<C, 2>(p.a.wq, p.a.wq_l, 2 * wave, lane, acc, p.dbg);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -376,8 +377,8 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
         }
     }
     f32x16 accK[2] = {{0}, {0}}, accV[2] = {{0}, {0}};
-    gemm_rows32<C, 2>(S2, LDA, p.a.wk, 2 * wave, lane, accK, p.dbg);
-    gemm_rows32<C, 2>(S2, LDA, p.a.wv, 2 * wave, lane, accV, p.dbg);
+    S2.template gemm<C, 2>(p.a.wk, p.a.wk_l, 2 * wave, lane, accK, p.dbg);
+    S2.template gemm<C, 2>(p.a.wv, p.a.wv_l, 2 * wave, lane, accV, p.dbg);
     kv_state_store(accK, accV, ABL(p.dbg, ABL_ELU) ? 1.f : 0.f, L, nvalid, lane, wave, p.kv_out, p.ks_out, slot);
   } else if (TAIL == 1) {
     // ============ decoder preparation (transformer.py:240-246) ============
@@ -387,9 +388,12 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
       const f32x4* pos = reinterpret_cast<const f32x4*>(
                              p.pos + (size_t)(g.prow0[side] + l0 + min(r, nvalid - 1)) * C) + part;
       const f32x4* src = reinterpret_cast<const f32x4*>(S0 + r * LDA) + part;
-      f32x4* dst = reinterpret_cast<f32x4*>(S1 + r * LDA) + part;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dst[i * 8] = src[i * 8] + pos[i * 8];
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 xv = src[i * 8];
+        S1.put4(r, 4 * (i * 8 + part), xv + pos[i * 8]);   // k input: memory + pos
+        if (SPLIT) S2.put4(r, 4 * (i * 8 + part), xv);     // v input: memory (f32 mode reads S0)
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -402,8 +406,9 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accK[t][r] = bk; accV[t][r] = bv; }
       }
-      gemm_rows32<C, 2>(S1, LDA, p.d.wk[dl], 2 * wave, lane, accK, p.dbg);
-      gemm_rows32<C, 2>(S0, LDA, p.d.wv[dl], 2 * wave, lane, accV, p.dbg);
+      S1.template gemm<C, 2>(p.d.wk[dl], p.d.wk_l[dl], 2 * wave, lane, accK, p.dbg);
+      if (SPLIT) S2.template gemm<C, 2>(p.d.wv[dl], p.d.wv_l[dl], 2 * wave, lane, accV, p.dbg);
+      else gemm_rows32<C, 2>(S0, LDA, p.d.wv[dl], 2 * wave, lane, accV, p.dbg);
       if (dl == 1) {
         kv_state_store(accK, accV, ABL(p.dbg, ABL_ELU) ? 1.f : 0.f, L, nvalid, lane, wave,
                        p.dkv1_out, p.dks1_out, slot);
@@ -447,9 +452,13 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
   }
 }
 
-hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, hipStream_t s) {
+hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, bool split, hipStream_t s) {
   const dim3 grid(p.g.ntiles), block(NTHREADS);
-#define OETR_LAUNCH(B, T) hipLaunchKernelGGL((k_encoder<B, T>), grid, block, 0, s, p)
+#define OETR_LAUNCH(B, T)                                                           \
+  do {                                                                              \
+    if (split) hipLaunchKernelGGL((k_encoder<B, T, true>), grid, block, 0, s, p);   \
+    else hipLaunchKernelGGL((k_encoder<B, T, false>), grid, block, 0, s, p);        \
+  } while (0)
   if (has_b) {
     if (tail == 0) OETR_LAUNCH(true, 0);
     else if (tail == 1) OETR_LAUNCH(true, 1);

@@ -21,8 +21,9 @@ constexpr int GN_GROUPS = 32;
 constexpr float GN_EPS = 1e-5f;
 
 // ---------------------------------------------------------------------------
+template <bool SPLIT>
 __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * TM * LDA];
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int col = lane & 31;
@@ -38,27 +39,46 @@ __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
   const int nvalid = min(TM, L - l0);
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
   const float* mem = p.mem[side] + (size_t)n * L * C;
-  const f32x4 hsv = reinterpret_cast<const f32x4*>(p.hs[side] + (size_t)n * C)[lane];
-
-  // gather + scale one tap tile: rows 8*wave .. 8*wave+7
-  auto stage = [&](int tap, float* S) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  // att[l'] = memory[l'] . hs for the halo rows l0-wf-1 .. l0+TM+wf of this tile,
+  // once (not per tap): 8 threads per row, DPP row sums.
+  __shared__ float att_s[TM + 2 * (100 + 1) + 6];
+  const int halo0 = l0 - wf - 1, nhalo = TM + 2 * (wf + 1);
+  const int hrow = tid >> 3, hpart = tid & 7;
+  {
+    const f32x4* hsp = reinterpret_cast<const f32x4*>(p.hs[side] + (size_t)n * C) + hpart;
+    f32x4 hv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
-      const int l = l0 + r;
-      const int y = l / wf, x = l - y * wf;
-      const int yy = y + dy, xx = x + dx;
-      const bool ok = (l < L) && (yy >= 0) && (yy < hf) && (xx >= 0) && (xx < wf);
-      // unconditional load from a clamped row + select: a guarded load would cost
-      // a branch and a vmcnt(0) round trip per row
-      const int src_row = ok ? yy * wf + xx : 0;
-      f32x4 v = reinterpret_cast<const f32x4*>(mem + (size_t)src_row * C)[lane];
-      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float att =
-          wave_sum((v[0] * hsv[0] + v[1] * hsv[1]) + (v[2] * hsv[2] + v[3] * hsv[3]));
-      *reinterpret_cast<f32x4*>(S + r * LDA + 4 * lane) = v * att;
+    for (int i = 0; i < 8; ++i) hv[i] = hsp[i * 8];
+    for (int r0 = 0; r0 < nhalo; r0 += TM) {
+      const int hr = r0 + hrow;
+      const int l = min(max(halo0 + hr, 0), L - 1);  // clamped: out-of-image rows are masked below
+      const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)l * C) + hpart;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 v = mp[i * 8];
+        d += (v[0] * hv[i][0] + v[1] * hv[i][1]) + (v[2] * hv[i][2] + v[3] * hv[i][3]);
+      }
+      d = sum8(d);
+      if (hpart == 0 && hr < nhalo) att_s[hr] = d;
     }
+  }
+  __syncthreads();
+
+  // gather + scale one tap tile (8 threads per row, float4 columns i*8 + part)
+  auto stage = [&](int tap, const ATile<SPLIT>& S) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int l = l0 + hrow;
+    const int y = l / wf, x = l - y * wf;
+    const int yy = y + dy, xx = x + dx;
+    const bool ok = (l < L) && (yy >= 0) && (yy < hf) && (xx >= 0) && (xx < wf);
+    // unconditional load from a clamped row + select: a guarded load would cost
+    // a branch and a vmcnt(0) round trip per row
+    const int src_row = ok ? yy * wf + xx : 0;
+    const float att = ok ? att_s[src_row - halo0] : 0.f;
+    const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)src_row * C) + hpart;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) S.put4(hrow, 4 * (i * 8 + hpart), mp[i * 8] * att);
   };
 
   f32x16 acc[2];
@@ -68,13 +88,17 @@ __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = b;
   }
-  stage(0, smem);
+  const ATile<SPLIT> buf[2] = {ATile<SPLIT>(smem, LDA, LDAH),
+                              ATile<SPLIT>(smem + TILE_FLOATS, LDA, LDAH)};
+  // f32 mode: tap t = [256 out][256 in] of 4-byte values -> C*C/4 float4 units;
+  // split mode: f16 values -> C*C/8 16-byte units per plane.
+  constexpr size_t TAP_UNITS = SPLIT ? (size_t)C * C / 8 : (size_t)C * C / 4;
+  stage(0, buf[0]);
   __syncthreads();
   for (int tap = 0; tap < 9; ++tap) {
-    float* cur = smem + (tap & 1) * TM * LDA;
-    float* nxt = smem + ((tap + 1) & 1) * TM * LDA;
-    if (tap + 1 < 9) stage(tap + 1, nxt);
-    gemm_rows32<C, 2>(cur, LDA, p.w.conv_w + (size_t)tap * (C * C / 4), 2 * wave, lane, acc);
+    if (tap + 1 < 9) stage(tap + 1, buf[(tap + 1) & 1]);
+    buf[tap & 1].template gemm<C, 2>(p.w.conv_w + tap * TAP_UNITS, p.w.conv_w_l + tap * TAP_UNITS,
+                                     2 * wave, lane, acc, 0);
     __syncthreads();
   }
 
@@ -113,8 +137,9 @@ __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
   }
 }
 
-hipError_t launch_heat_conv(const HeatLaunch& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_heat_conv, dim3(p.g.ntiles), dim3(NTHREADS), 0, s, p);
+hipError_t launch_heat_conv(const HeatLaunch& p, bool split, hipStream_t s) {
+  if (split) hipLaunchKernelGGL(k_heat_conv<true>, dim3(p.g.ntiles), dim3(NTHREADS), 0, s, p);
+  else hipLaunchKernelGGL(k_heat_conv<false>, dim3(p.g.ntiles), dim3(NTHREADS), 0, s, p);
   return hipGetLastError();
 }
 

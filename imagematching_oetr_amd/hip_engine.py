@@ -183,8 +183,17 @@ class HotPathEngine:
     """Owns one ``oetr_handle`` (repacked weights on one GPU) and a growable
     workspace tensor."""
 
-    def __init__(self, weights, device=None):
+    #: GEMM arithmetic modes (oetr_dtype in the header)
+    PRECISIONS = {'f32': 0, 'f32_split_f16': 1}
+
+    def __init__(self, weights, device=None, precision='f32_split_f16'):
+        """``precision``: 'f32' = exact fp32 MFMA products; 'f32_split_f16' =
+        fp32-class results from 3 f16 MFMAs per product (default; same parity
+        tolerances, ~2x faster)."""
         self.lib = load_library()
+        if precision not in self.PRECISIONS:
+            raise ValueError(f'precision must be one of {sorted(self.PRECISIONS)}')
+        self.precision = precision
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         device = torch.device(device)
@@ -238,7 +247,7 @@ class HotPathEngine:
         w.heat_out_w, w.heat_out_b = ptr('heatmap_conv.3.weight'), ptr('heatmap_conv.3.bias')
 
         handle = C.c_void_p()
-        _check(self.lib, self.lib.oetr_create(C.byref(w), 0, device.index,
+        _check(self.lib, self.lib.oetr_create(C.byref(w), self.PRECISIONS[precision], device.index,
                                               C.byref(handle)), 'oetr_create')
         self._h = handle
         self._ws = None

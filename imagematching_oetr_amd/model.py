@@ -112,6 +112,8 @@ class OETR(nn.Module):
         self.max_shape = cfg.NECK.MAX_SHAPE
         self.cycle = cfg.LOSS.CYCLE_OVERLAP
         self.softmax_temperature = 1
+        #: GEMM arithmetic of the HIP hot path: 'f32_split_f16' (default) or 'f32'
+        self.hip_precision = 'f32_split_f16'
         self._engine = None
         self._engine_key = None
 
@@ -137,14 +139,15 @@ class OETR(nn.Module):
         """HIP engine bound to the current hot-path weights; rebuilt when a
         weight tensor was replaced or written in place."""
         params = [self.get_parameter(k) for k in hot_path_keys()]
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (self.hip_precision,) + tuple((p.data_ptr(), p._version) for p in params)
         if self._engine is None or key != self._engine_key:
             dev = params[0].device
             if dev.type != 'cuda':
                 raise RuntimeError(
                     'OETR hot path needs the model on a GPU (HIP) device; '
                     f'weights are on {dev}. There is no CPU implementation.')
-            self._engine = HotPathEngine(self.hot_path_state(), device=dev)
+            self._engine = HotPathEngine(self.hot_path_state(), device=dev,
+                                         precision=self.hip_precision)
             self._engine_key = key
         return self._engine
 

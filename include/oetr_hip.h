@@ -48,7 +48,12 @@ typedef enum {
   OETR_ERR_NO_DEVICE = 6     /* no gfx950 device visible                   */
 } oetr_status;
 
-typedef enum { OETR_DTYPE_F32 = 0 } oetr_dtype;
+/* Arithmetic of the GEMM-shaped stages (everything else is fp32 in both):
+ *   OETR_DTYPE_F32           exact fp32 products on v_mfma_f32_32x32x2_f32
+ *   OETR_DTYPE_F32_SPLIT_F16 fp32-class results from 3 f16 MFMAs per product
+ *                            (a = ah + al/2^11 split of both operands, fp32
+ *                            accumulation; needs |GEMM inputs| < 65504)      */
+typedef enum { OETR_DTYPE_F32 = 0, OETR_DTYPE_F32_SPLIT_F16 = 1 } oetr_dtype;
 
 /* Encoder layer i - reference src/models/transformer.py:83-102.
  * Linear weights are torch layout [out][in], row-major. */
