@@ -130,6 +130,10 @@ struct oetr_ctx {
 
 namespace {
 
+#ifdef OETR_PHASE_TIMING
+long long* g_tbuf = nullptr;
+#endif
+
 struct Workspace {
   float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
       *logits, *cxy, *tlbr;
@@ -236,6 +240,14 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   p.g = g;
 #ifdef OETR_ABLATE
   { const char* e = getenv("OETR_ABLATE"); p.dbg = e ? atoi(e) : 0; }
+#endif
+#ifdef OETR_PHASE_TIMING
+  {
+    static long long* tb = nullptr;
+    if (!tb) (void)hipMalloc(&tb, sizeof(long long) * 16 * 65536);
+    p.tbuf = tb;
+    g_tbuf = tb;
+  }
 #endif
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
   p.a = h->enc[0];
@@ -661,5 +673,13 @@ oetr_status oetr_trace_summary(oetr_trace_handle t, int* n_kernels,
   if (dropped) return fail(OETR_ERR_BAD_ARG, std::to_string(dropped) + " launches not traced: pool too small");
   return OETR_OK;
 }
+
+#ifdef OETR_PHASE_TIMING
+// debug: copy the phase stamps of the LAST encoder launch sequence to the host
+int oetr_debug_read_tbuf(long long* host, int n_blocks) {
+  if (!g_tbuf) return 1;
+  return hipMemcpy(host, g_tbuf, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost) != hipSuccess;
+}
+#endif
 
 }  // extern "C"

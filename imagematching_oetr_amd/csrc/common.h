@@ -26,6 +26,16 @@ constexpr int MAX_TOKENS = 10000;  // NECK.MAX_SHAPE 100x100 (reference default.
 #else
 #define ABL(flags, bit) false
 #endif
+// Phase timing (tools/phase_timing.py): wave 0 of every workgroup stamps
+// s_memtime at phase boundaries.  Compiled out of the shipped build.
+#ifdef OETR_PHASE_TIMING
+#define PHASE_STAMP(p, idx)                                                              \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && (p).tbuf) (p).tbuf[blockIdx.x * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define PHASE_STAMP(p, idx) do {} while (0)
+#endif
 enum { ABL_KVREDUCE = 1, ABL_GELU = 2, ABL_ELU = 4, ABL_LN = 8, ABL_GEMM = 16, ABL_STORE = 32 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -77,11 +87,23 @@ __device__ __forceinline__ int crow(int r, int half) {
   return (r & 3) + 8 * (r >> 2) + 4 * half;
 }
 
+// exp(x) for x <= 0 on the hardware exp2 unit with a compensated argument:
+// x*log2(e) is formed as t + r (t = fl(x*L2E_HI), r = the rounding residue +
+// x*L2E_LO), exp(x) = 2^t * (1 + r ln2).  Error ~1 ulp of v_exp_f32
+// (tools: 3.6e-13 from the argument handling alone); 6 instructions, no
+// branches, vs ~15 for ocml expf.
+__device__ __forceinline__ float exp_neg(float x) {
+  const float L2E_HI = 1.4426950216293335f, L2E_LO = 1.9259629911266175e-08f;
+  const float t = x * L2E_HI;
+  float r = fmaf(x, L2E_HI, -t);
+  r = fmaf(x, L2E_LO, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.69314718055994531f, e);
+}
 // phi(x) = elu(x) + 1.  torch evaluates expm1(x) + 1 for x <= 0, which is
-// exp(x) to within one rounding of the final add (<= 6e-8 absolute); exp is
-// used directly (branch-free, ~1/3 of the instructions of expm1).
+// exp(x) to within one rounding of the final add (<= 6e-8 absolute).
 __device__ __forceinline__ float elu1(float x) {
-  return x > 0.f ? x + 1.0f : expf(x);
+  return x > 0.f ? x + 1.0f : exp_neg(x);
 }
 
 // DPP lane exchange inside a row of 16 lanes (no LDS traffic, unlike
@@ -220,10 +242,12 @@ __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda
 // ---- split-f16 GEMM core -------------------------------------------------
 // hi/lo halves of two floats: (hi0,hi1) and (lo0,lo1) packed as f16x2.
 __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
-  // round-to-nearest conversions (v_cvt_f16_f32); a - (float)hi is exact in f32
-  hi = f16x2{(_Float16)a, (_Float16)b};
-  lo = f16x2{(_Float16)((a - (float)hi[0]) * SPLIT_SCALE),
-             (_Float16)((b - (float)hi[1]) * SPLIT_SCALE)};
+  // v_cvt_pkrtz converts two floats per instruction.  Truncation of hi is
+  // harmless (a - (float)hi is exact in f32 and lands in lo); truncating lo
+  // costs <= 2^-21 relative, inside the budget (tests: fp32-class vs fp64).
+  hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+  lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((a - (float)hi[0]) * SPLIT_SCALE,
+                                                            (b - (float)hi[1]) * SPLIT_SCALE));
 }
 // Store 4 consecutive floats of a row as 4 hi halves + 4 lo halves (8-byte stores).
 __device__ __forceinline__ void store_split4(_Float16* hi_row, _Float16* lo_row, int c,
@@ -247,7 +271,10 @@ struct GemmRegsH {
 //            holds, for output column n = 32*ntile + (lane&31), inputs
 //            k = 16*ks + 8*(lane>>5) + {0..7}.
 //   acc = main + cross/2^11 is formed at the end; `acc` enters as the initial main part.
-template <int K, int NT, int U = 4>
+#ifndef OETR_SPLIT_U1
+#define OETR_SPLIT_U1 2   // chunk depth (k16 steps) when a wave owns one n-tile (8-wave shape)
+#endif
+template <int K, int NT, int U = (NT == 1 ? OETR_SPLIT_U1 : 4)>
 __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
                                               const _Float16* __restrict__ Alo, int lda,
                                               const f32x4* __restrict__ Whi,
@@ -266,9 +293,11 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
     wh_ptr[t] = Whi + (size_t)(nt0 + t) * KS * 64 + lane;
     wl_ptr[t] = Wlo + (size_t)(nt0 + t) * KS * 64 + lane;
   }
-  f32x16 cross[NT];
+  // two cross accumulators per tile: three independent MFMA chains per k-step
+  // (a single one makes every other MFMA wait on its predecessor's result)
+  f32x16 cross[NT], cross2[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) cross[t] = f32x16{0};
+  for (int t = 0; t < NT; ++t) { cross[t] = f32x16{0}; cross2[t] = f32x16{0}; }
 
   auto fetch = [&](GemmRegsH<NT, U>& r, int chunk) {
 #pragma unroll
@@ -294,7 +323,7 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
         const f16x8 bl = __builtin_bit_cast(f16x8, r.bl[u][t]);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
         cross[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cross[t], 0, 0, 0);
-        cross[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cross[t], 0, 0, 0);
+        cross2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cross2[t], 0, 0, 0);
       }
     }
   };
@@ -314,7 +343,7 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(cross[t][r], SPLIT_INV, acc[t][r]);
+    for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(cross[t][r] + cross2[t][r], SPLIT_INV, acc[t][r]);
 }
 
 // Accumulator tiles -> split f16 planes (columns col0 + 32*t + lane&31).
@@ -415,6 +444,7 @@ struct EncLaunch {
   DecKVDev d;            // TAIL==1
   int b_cross;           // phase-B layer is a cross layer
   int dbg;               // ablation flags (OETR_ABLATE builds only)
+  long long* tbuf;       // per-phase cycle stamps (OETR_PHASE_TIMING builds only)
 };
 
 // has_b: run phase B (finish a layer); tail: 0 = phase A of next encoder layer,

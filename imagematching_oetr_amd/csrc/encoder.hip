@@ -96,56 +96,87 @@ constexpr int KSUM_OFF = H_OFF + HID_FLOATS;
 constexpr int Z_OFF = KSUM_OFF + C;
 constexpr int SMEM_FLOATS = Z_OFF + TM * NH;
 
-// LayerNorm over a [TM][256] LDS tile with 8 threads per row: thread tid owns
-// row tid>>3 and the float4 columns i*8 + (tid&7), i < 8 (so the 8 threads of a
-// row read 128 contiguous bytes per step).  Row sums need only three DPP
-// exchanges inside an 8-lane group.  Returns the normalised values
-// (x - mean) * rstd in registers; the caller applies its affine(s).
-__device__ __forceinline__ void ln_rows8(const float* S, int tid, f32x4 (&xn)[8], int dbg) {
-  const f32x4* src = reinterpret_cast<const f32x4*>(S + (tid >> 3) * LDA) + (tid & 7);
+// Workgroup shape: NW waves.  NW = 4 (one wave per SIMD) for the exact-f32
+// mode, where the MFMA pipe is the bound; NW = 8 (two per SIMD) for the split
+// mode, where it is not: twice the weight bytes in flight per CU and one wave's
+// VALU / LDS phases run under the other's MFMAs.  Wave w owns NT = 8/NW
+// 32-column tiles (= heads) of every 256-wide GEMM.
+template <int NW>
+struct EncCfg {
+  static constexpr int NT = 8 / NW;
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int WC = 32 * NT;        // output columns per wave
+  static constexpr int TPR = THREADS / TM;  // threads per row in row-wise phases (8 / 16)
+  static constexpr int F4 = 64 / TPR;       // float4 per thread per row
+};
+
+// Sum over the TPR (8 or 16) consecutive lanes that share a row.
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v) {
+  v = sum8(v);
+  if (TPR == 16) v += dpp_mov<0x140>(v);  // row_mirror: lane i <-> 15 - i
+  return v;
+}
+
+// LayerNorm over a [TM][256] LDS tile with TPR threads per row: thread tid owns
+// row tid/TPR and the float4 columns i*TPR + tid%TPR (the threads of a row read
+// contiguous 16-byte pieces per step).  Row sums need only 3-4 DPP exchanges.
+// Returns (x - mean) * rstd in registers; the caller applies its affine(s).
+template <int TPR, int F4>
+__device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4], int dbg) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(S + (tid / TPR) * LDA) + (tid % TPR);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    xn[i] = src[i * 8];
+  for (int i = 0; i < F4; ++i) {
+    xn[i] = src[i * TPR];
     s += (xn[i][0] + xn[i][1]) + (xn[i][2] + xn[i][3]);
   }
   if (ABL(dbg, ABL_LN)) return;
-  const float mean = sum8(s) * (1.0f / C);
+  const float mean = row_sum<TPR>(s) * (1.0f / C);
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < F4; ++i) {
     xn[i] -= mean;
     q += (xn[i][0] * xn[i][0] + xn[i][1] * xn[i][1]) + (xn[i][2] * xn[i][2] + xn[i][3] * xn[i][3]);
   }
-  const float rstd = 1.0f / sqrtf(sum8(q) * (1.0f / C) + LN_EPS);
+  const float rstd = 1.0f / sqrtf(row_sum<TPR>(q) * (1.0f / C) + LN_EPS);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) xn[i] *= rstd;
+  for (int i = 0; i < F4; ++i) xn[i] *= rstd;
 }
 
-// phi(K)^T (V/S) for this wave's two heads from the K and V accumulators, plus
-// sum_s phi(K); stores the per-tile partial states.
-__device__ __forceinline__ void kv_state_store(f32x16 (&accK)[2], f32x16 (&accV)[2],
-                                               float inv_len_is_div /* ablation: skip phi */, int S_len, int nvalid,
-                                               int lane, int wave, float* __restrict__ kv_out,
+// phi(K) and V/S in place (rows past the image end zeroed); returns sum_rows phi(K).
+// values / v_length (linear_attention.py:44) is a multiply by the reciprocal:
+// <= 1 ulp from the division, 1 instruction instead of ~10.
+__device__ __forceinline__ float phi_k_scale_v(f32x16& accK, f32x16& accV, bool skip_phi,
+                                               int S_len, int nvalid, int half) {
+  const float inv_len = 1.0f / (float)S_len;
+  float ksum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const bool ok = crow(r, half) < nvalid;
+    accK[r] = ok ? (skip_phi ? accK[r] : elu1(accK[r])) : 0.f;
+    accV[r] = ok ? accV[r] * inv_len : 0.f;
+    ksum += accK[r];
+  }
+  return ksum;
+}
+
+// phi(K)^T (V/S) for this wave's heads straight from the K and V accumulators,
+// plus sum_s phi(K); stores the per-tile partial states.
+template <int NT>
+__device__ __forceinline__ void kv_state_store(f32x16 (&accK)[NT], f32x16 (&accV)[NT],
+                                               bool skip_phi, int S_len, int nvalid, int lane,
+                                               int wave, float* __restrict__ kv_out,
                                                float* __restrict__ ks_out, int slot) {
   const int half = lane >> 5;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    float ksum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool ok = crow(r, half) < nvalid;
-      const float kf = ok ? (inv_len_is_div != 0.f ? accK[t][r] : elu1(accK[t][r])) : 0.f;
-      const float vf = ok ? accV[t][r] / (float)S_len : 0.f;
-      accK[t][r] = kf;
-      accV[t][r] = vf;
-      ksum += kf;
-    }
+  for (int t = 0; t < NT; ++t) {
+    float ksum = phi_k_scale_v(accK[t], accV[t], skip_phi, S_len, nvalid, half);
     f32x16 kv = {0};
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       kv = __builtin_amdgcn_mfma_f32_32x32x2f32(accK[t][r], accV[t][r], kv, 0, 0, 0);
-    const int h = 2 * wave + t;
+    const int h = NT * wave + t;
     f32x4* dst = reinterpret_cast<f32x4*>(kv_out) + ((size_t)slot * NH + h) * 4 * 64 + lane;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -157,8 +188,25 @@ __device__ __forceinline__ void kv_state_store(f32x16 (&accK)[2], f32x16 (&accV)
   }
 }
 
-template <bool HAS_B, int TAIL, bool SPLIT>
-__global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
+// Coalesced [TM][256] tile load HBM -> LDS.  Rows past the image end re-read
+// the last valid row: a guarded load would cost a branch plus a full vmcnt(0)
+// round trip per element, and those rows are never stored anyway.
+template <int THREADS>
+__device__ __forceinline__ void load_tile(float* S, const float* __restrict__ src, int nvalid,
+                                          int tid) {
+#pragma unroll
+  for (int i = 0; i < (TM * C / 4) / THREADS; ++i) {
+    const int idx = tid + THREADS * i;
+    const int r = idx >> 6, c4 = idx & 63;
+    *reinterpret_cast<f32x4*>(S + r * LDA + 4 * c4) =
+        reinterpret_cast<const f32x4*>(src + (size_t)min(r, nvalid - 1) * C)[c4];
+  }
+}
+
+template <bool HAS_B, int TAIL, bool SPLIT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
+  using Cfg = EncCfg<NW>;
+  constexpr int NT = Cfg::NT, THREADS = Cfg::THREADS, WC = Cfg::WC, TPR = Cfg::TPR, F4 = Cfg::F4;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* S0 = smem + S0_OFF;
   const ATile<SPLIT> S1(smem + S1_OFF, LDA, LDAH);
@@ -170,6 +218,8 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int col = lane & 31;
+  const int wcol = WC * wave;               // first of this wave's output columns
+  const int lrow = tid / TPR, lpart = tid % TPR;  // (row, float4 slot) in row-wise phases
 
   // ---- tile identity (pair-major logical order: n, side, tile) ----
   const int logical = xcd_remap(blockIdx.x, g.ntiles);
@@ -184,7 +234,8 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
 
-  f32x16 xacc[2];  // residual stream of this wave's 64 columns (C layout)
+  f32x16 xacc[NT];  // residual stream of this wave's columns (C layout)
+  PHASE_STAMP(p, 0);
 
   if (HAS_B) {
     // ================= phase B: finish layer l =================
@@ -193,63 +244,54 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
     const int nts = ABL(p.dbg, ABL_KVREDUCE) ? 1 : g.nt[ss];
     const int src_slot0 = g.tile0[ss] + n * g.nt[ss];
 
-    // Loads below never branch on row validity: rows past the end of the image
-    // re-read the last valid row (finite values that are never stored), because a
-    // guarded load costs a branch plus a full vmcnt(0) round trip per element.
-    // phi(Q) tile -> S0 (coalesced float4 rows)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + NTHREADS * i;
-      const int r = idx >> 6, c4 = idx & 63;
-      const f32x4 v =
-          reinterpret_cast<const f32x4*>(p.qp + (row_base + min(r, nvalid - 1)) * C)[c4];
-      *reinterpret_cast<f32x4*>(S0 + r * LDA + 4 * c4) = v;
-    }
+    load_tile<THREADS>(S0, p.qp + row_base * C, nvalid, tid);  // phi(Q) tile
     // residual x in accumulator layout
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(crow(r, half), nvalid - 1);
-        xacc[t][r] = p.x[(row_base + row) * C + 64 * wave + 32 * t + col];
+        xacc[t][r] = p.x[(row_base + row) * C + wcol + 32 * t + col];
       }
     // reduce the source image's partial KV states (fixed order -> deterministic);
-    // the result is already in B-operand register order.  Four tiles (32 float4
-    // loads per lane) are in flight per round trip.
-    f32x4 kvB[2][4];
+    // the result is already in B-operand register order.  Several tiles are in
+    // flight per round trip (32 float4 loads per lane).
+    f32x4 kvB[NT][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) kvB[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      const f32x4* kvp =
-          reinterpret_cast<const f32x4*>(p.kv_in) + ((size_t)src_slot0 * NH + 2 * wave) * 256 + lane;
-      const float* ksp = p.ks_in + (size_t)src_slot0 * C + tid;
+      constexpr int KVR = 4;  // tiles per round trip (16*NT float4 loads per lane in flight)
+      const f32x4* kvp = reinterpret_cast<const f32x4*>(p.kv_in) +
+                         ((size_t)src_slot0 * NH + NT * wave) * 256 + lane;
+      const float* ksp = p.ks_in + (size_t)src_slot0 * C + (tid & (C - 1));
       float ks = 0.f;
-      for (int ti0 = 0; ti0 < nts; ti0 += 4) {
-        f32x4 tmp[4][8];
-        float kt[4];
+      for (int ti0 = 0; ti0 < nts; ti0 += KVR) {
+        f32x4 tmp[KVR][4 * NT];
+        float kt[KVR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < KVR; ++u) {
           const int ti = min(ti0 + u, nts - 1);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) tmp[u][e] = kvp[(size_t)ti * (NH * 256) + e * 64];
+          for (int e = 0; e < 4 * NT; ++e) tmp[u][e] = kvp[(size_t)ti * (NH * 256) + e * 64];
           kt[u] = ksp[(size_t)ti * C];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < KVR; ++u)
           if (ti0 + u < nts) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) kvB[e >> 2][e & 3] += tmp[u][e];
+            for (int e = 0; e < 4 * NT; ++e) kvB[e >> 2][e & 3] += tmp[u][e];
             ks += kt[u];
           }
       }
-      ksum_s[tid] = ks;
+      if (THREADS == C || tid < C) ksum_s[tid] = ks;
     }
     __syncthreads();
+    PHASE_STAMP(p, 1);
 
     // Z[row][h] = 1 / (phi(Q)[row,h,:] . Ksum[h,:] + eps)
-    {
+    if (THREADS == TM * NH || tid < TM * NH) {
       const int r = tid >> 3, h = tid & 7;
       const f32x4* qrow = reinterpret_cast<const f32x4*>(S0 + r * LDA + h * HD);
       const f32x4* kk = reinterpret_cast<const f32x4*>(ksum_s + h * HD);
@@ -263,171 +305,170 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
     }
     __syncthreads();
 
-    // message = (phi(Q) . KV) * Z * S  for this wave's two heads -> S1
+    // message = (phi(Q) . KV) * Z * S  for this wave's heads -> S1
     {
-      float zr[2][16];  // read before any S1 store: LDS stores would otherwise
-#pragma unroll          // serialise these reads one by one (may-alias)
-      for (int t = 0; t < 2; ++t)
+      float zr[NT][16];  // read before any S1 store: LDS stores would otherwise
+#pragma unroll           // serialise these reads one by one (may-alias)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zr[t][r] = z_s[crow(r, half) * NH + 2 * wave + t];
-      f32x16 macc[2] = {{0}, {0}};
+        for (int r = 0; r < 16; ++r) zr[t][r] = z_s[crow(r, half) * NH + NT * wave + t];
+      f32x16 macc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) macc[t] = f32x16{0};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(S0 + col * LDA + (2 * wave + t) * HD +
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(S0 + col * LDA + (NT * wave + t) * HD +
                                                           4 * half + ks * 8);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[t][ks][j], macc[t], 0, 0, 0);
         }
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) macc[t][r] = macc[t][r] * zr[t][r] * (float)S_len;
-      S1.template put_acc<2>(64 * wave, lane, macc);
+      S1.template put_acc<NT>(wcol, lane, macc);
     }
     __syncthreads();
+    PHASE_STAMP(p, 2);
 
     // x1 = x + message . Wmerge^T
-    S1.template gemm<C, 2>(p.b.wmerge, p.b.wmerge_l, 2 * wave, lane, xacc, p.dbg);
-    acc_to_lds<2>(S0, LDA, 64 * wave, lane, xacc);
+    S1.template gemm<C, NT>(p.b.wmerge, p.b.wmerge_l, NT * wave, lane, xacc, p.dbg);
+    acc_to_lds<NT>(S0, LDA, wcol, lane, xacc);
     __syncthreads();
+    PHASE_STAMP(p, 3);
 
     // LN2(x1) -> S1
     {
-      f32x4 xn[8];
-      ln_rows8(S0, tid, xn, p.dbg);
-      const f32x4* gw = reinterpret_cast<const f32x4*>(p.b.ln2_w) + (tid & 7);
-      const f32x4* gb = reinterpret_cast<const f32x4*>(p.b.ln2_b) + (tid & 7);
+      f32x4 xn[F4];
+      ln_rows<TPR, F4>(S0, tid, xn, p.dbg);
+      const f32x4* gw = reinterpret_cast<const f32x4*>(p.b.ln2_w) + lpart;
+      const f32x4* gb = reinterpret_cast<const f32x4*>(p.b.ln2_b) + lpart;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        S1.put4(tid >> 3, 4 * (i * 8 + (tid & 7)), xn[i] * gw[i * 8] + gb[i * 8]);
+      for (int i = 0; i < F4; ++i)
+        S1.put4(lrow, 4 * (i * TPR + lpart), xn[i] * gw[i * TPR] + gb[i * TPR]);
     }
     __syncthreads();
+    PHASE_STAMP(p, 4);
 
-    // hidden = gelu(LN2(x1) . W1^T) -> Hh   (wave w: hidden columns [128w, 128w+128))
+    // hidden = gelu(LN2(x1) . W1^T) -> Hh   (wave w: hidden columns [2*WC*w, 2*WC*(w+1)))
 #pragma unroll
     for (int cpart = 0; cpart < 2; ++cpart) {
-      f32x16 hacc[2] = {{0}, {0}};
-      S1.template gemm<C, 2>(p.b.w1, p.b.w1_l, 4 * wave + 2 * cpart, lane, hacc, p.dbg);
+      f32x16 hacc[NT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t) hacc[t] = f32x16{0};
+      S1.template gemm<C, NT>(p.b.w1, p.b.w1_l, 2 * NT * wave + NT * cpart, lane, hacc, p.dbg);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[t][r] = ABL(p.dbg, ABL_GELU) ? hacc[t][r] : gelu_erf(hacc[t][r]);
-      Hh.template put_acc<2>(128 * wave + 64 * cpart, lane, hacc);
+      Hh.template put_acc<NT>(2 * wcol + WC * cpart, lane, hacc);
     }
     __syncthreads();
+    PHASE_STAMP(p, 5);
 
     // x2 = x1 + hidden . W2^T ; write back
-    Hh.template gemm<FF, 2>(p.b.w2, p.b.w2_l, 2 * wave, lane, xacc, p.dbg);
+    Hh.template gemm<FF, NT>(p.b.w2, p.b.w2_l, NT * wave, lane, xacc, p.dbg);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = crow(r, half);
-        if (row < nvalid) p.x[(row_base + row) * C + 64 * wave + 32 * t + col] = xacc[t][r];
+        if (row < nvalid) p.x[(row_base + row) * C + wcol + 32 * t + col] = xacc[t][r];
       }
-    if (TAIL != 2) acc_to_lds<2>(S0, LDA, 64 * wave, lane, xacc);
+    if (TAIL != 2) acc_to_lds<NT>(S0, LDA, wcol, lane, xacc);
     __syncthreads();  // also: every wave is done reading Hh before S2 (alias) is written
+    PHASE_STAMP(p, 6);
   } else {
-    // first launch: x tile straight from HBM
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + NTHREADS * i;
-      const int r = idx >> 6, c4 = idx & 63;
-      const f32x4 v = reinterpret_cast<const f32x4*>(p.x + (row_base + min(r, nvalid - 1)) * C)[c4];
-      *reinterpret_cast<f32x4*>(S0 + r * LDA + 4 * c4) = v;
-    }
+    load_tile<THREADS>(S0, p.x + row_base * C, nvalid, tid);  // first launch: x from HBM
     __syncthreads();
   }
 
+  const f32x4* pos = reinterpret_cast<const f32x4*>(
+                         p.pos + (size_t)(g.prow0[side] + l0 + min(lrow, nvalid - 1)) * C) + lpart;
   if (TAIL == 0) {
     // ================= phase A: start layer l+1 =================
     // q_in = LN_q(x)+pos -> S1 ; kv_in = LN_kv(x)+pos -> S2 (one set of row stats)
     {
-      f32x4 xn[8];
-      ln_rows8(S0, tid, xn, p.dbg);
-      const int r = tid >> 3, part = tid & 7;
-      const f32x4* pos = reinterpret_cast<const f32x4*>(
-                             p.pos + (size_t)(g.prow0[side] + l0 + min(r, nvalid - 1)) * C) + part;
-      const f32x4* qw = reinterpret_cast<const f32x4*>(p.a.lnq_w) + part;
-      const f32x4* qb = reinterpret_cast<const f32x4*>(p.a.lnq_b) + part;
-      const f32x4* kw = reinterpret_cast<const f32x4*>(p.a.lnkv_w) + part;
-      const f32x4* kb = reinterpret_cast<const f32x4*>(p.a.lnkv_b) + part;
+      f32x4 xn[F4];
+      ln_rows<TPR, F4>(S0, tid, xn, p.dbg);
+      const f32x4* qw = reinterpret_cast<const f32x4*>(p.a.lnq_w) + lpart;
+      const f32x4* qb = reinterpret_cast<const f32x4*>(p.a.lnq_b) + lpart;
+      const f32x4* kw = reinterpret_cast<const f32x4*>(p.a.lnkv_w) + lpart;
+      const f32x4* kb = reinterpret_cast<const f32x4*>(p.a.lnkv_b) + lpart;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 ps = pos[i * 8];
-        S1.put4(r, 4 * (i * 8 + part), (xn[i] * qw[i * 8] + qb[i * 8]) + ps);
-        S2.put4(r, 4 * (i * 8 + part), (xn[i] * kw[i * 8] + kb[i * 8]) + ps);
+      for (int i = 0; i < F4; ++i) {
+        const f32x4 ps = pos[i * TPR];
+        S1.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * qw[i * TPR] + qb[i * TPR]) + ps);
+        S2.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * kw[i * TPR] + kb[i * TPR]) + ps);
       }
     }
     __syncthreads();
+    PHASE_STAMP(p, 7);
 
     {  // phi(Q) -> HBM
-      f32x16 acc[2] = {{0}, {0}};
-      S1.template gemm<C, 2>(p.a.wq, p.a.wq_l, 2 * wave, lane, acc, p.dbg);
+      f32x16 acc[NT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+      S1.template gemm<C, NT>(p.a.wq, p.a.wq_l, NT * wave, lane, acc, p.dbg);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
           if (row < nvalid)
-            p.qp[(row_base + row) * C + 64 * wave + 32 * t + col] = ABL(p.dbg, ABL_ELU) ? acc[t][r] : elu1(acc[t][r]);
+            p.qp[(row_base + row) * C + wcol + 32 * t + col] = ABL(p.dbg, ABL_ELU) ? acc[t][r] : elu1(acc[t][r]);
         }
     }
-    f32x16 accK[2] = {{0}, {0}}, accV[2] = {{0}, {0}};
-    S2.template gemm<C, 2>(p.a.wk, p.a.wk_l, 2 * wave, lane, accK, p.dbg);
-    S2.template gemm<C, 2>(p.a.wv, p.a.wv_l, 2 * wave, lane, accV, p.dbg);
-    kv_state_store(accK, accV, ABL(p.dbg, ABL_ELU) ? 1.f : 0.f, L, nvalid, lane, wave, p.kv_out, p.ks_out, slot);
+    PHASE_STAMP(p, 8);
+    f32x16 accK[NT], accV[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { accK[t] = f32x16{0}; accV[t] = f32x16{0}; }
+    S2.template gemm<C, NT>(p.a.wk, p.a.wk_l, NT * wave, lane, accK, p.dbg);
+    S2.template gemm<C, NT>(p.a.wv, p.a.wv_l, NT * wave, lane, accV, p.dbg);
+    PHASE_STAMP(p, 9);
+    kv_state_store<NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.kv_out, p.ks_out, slot);
+    PHASE_STAMP(p, 10);
   } else if (TAIL == 1) {
     // ============ decoder preparation (transformer.py:240-246) ============
     // k = (memory + pos) Wk^T + bk ; v = memory Wv^T + bv  (no norm, no pos on v)
     {
-      const int r = tid >> 3, part = tid & 7;
-      const f32x4* pos = reinterpret_cast<const f32x4*>(
-                             p.pos + (size_t)(g.prow0[side] + l0 + min(r, nvalid - 1)) * C) + part;
-      const f32x4* src = reinterpret_cast<const f32x4*>(S0 + r * LDA) + part;
+      const f32x4* src = reinterpret_cast<const f32x4*>(S0 + lrow * LDA) + lpart;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 xv = src[i * 8];
-        S1.put4(r, 4 * (i * 8 + part), xv + pos[i * 8]);   // k input: memory + pos
-        if (SPLIT) S2.put4(r, 4 * (i * 8 + part), xv);     // v input: memory (f32 mode reads S0)
+      for (int i = 0; i < F4; ++i) {
+        const f32x4 xv = src[i * TPR];
+        S1.put4(lrow, 4 * (i * TPR + lpart), xv + pos[i * TPR]);  // k input: memory + pos
+        if (SPLIT) S2.put4(lrow, 4 * (i * TPR + lpart), xv);      // v input (f32 mode reads S0)
       }
     }
     __syncthreads();
 #pragma unroll
     for (int dl = 0; dl < 2; ++dl) {
-      f32x16 accK[2], accV[2];
+      f32x16 accK[NT], accV[NT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float bk = p.d.bk[dl][64 * wave + 32 * t + col];
-        const float bv = p.d.bv[dl][64 * wave + 32 * t + col];
+      for (int t = 0; t < NT; ++t) {
+        const float bk = p.d.bk[dl][wcol + 32 * t + col];
+        const float bv = p.d.bv[dl][wcol + 32 * t + col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accK[t][r] = bk; accV[t][r] = bv; }
       }
-      S1.template gemm<C, 2>(p.d.wk[dl], p.d.wk_l[dl], 2 * wave, lane, accK, p.dbg);
-      if (SPLIT) S2.template gemm<C, 2>(p.d.wv[dl], p.d.wv_l[dl], 2 * wave, lane, accV, p.dbg);
-      else gemm_rows32<C, 2>(S0, LDA, p.d.wv[dl], 2 * wave, lane, accV, p.dbg);
+      S1.template gemm<C, NT>(p.d.wk[dl], p.d.wk_l[dl], NT * wave, lane, accK, p.dbg);
+      if (SPLIT) S2.template gemm<C, NT>(p.d.wv[dl], p.d.wv_l[dl], NT * wave, lane, accV, p.dbg);
+      else gemm_rows32<C, NT>(S0, LDA, p.d.wv[dl], NT * wave, lane, accV, p.dbg);
       if (dl == 1) {
-        kv_state_store(accK, accV, ABL(p.dbg, ABL_ELU) ? 1.f : 0.f, L, nvalid, lane, wave,
-                       p.dkv1_out, p.dks1_out, slot);
+        kv_state_store<NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.dkv1_out,
+                           p.dks1_out, slot);
       } else {
         // Decoder layer 0's query is a create-time constant q0 (decoder.hip), and
         // its cross-attention is linear in the state, so this tile contributes
         //   att0[h,v] += sum_d q0[h,d] * KV_tile[h][d][v],  z0[h] += q0[h,:].Ksum_tile[h,:]
         // instead of a full 8192-float state.
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int h = 2 * wave + t;
-          float ksum = 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool ok = crow(r, half) < nvalid;
-            accK[t][r] = ok ? elu1(accK[t][r]) : 0.f;
-            accV[t][r] = ok ? accV[t][r] / (float)L : 0.f;
-            ksum += accK[t][r];
-          }
+        for (int t = 0; t < NT; ++t) {
+          const int h = NT * wave + t;
+          float ksum = phi_k_scale_v(accK[t], accV[t], false, L, nvalid, half);
           f32x16 kv = {0};
 #pragma unroll
           for (int r = 0; r < 16; ++r)
@@ -452,12 +493,23 @@ __global__ __launch_bounds__(NTHREADS) void k_encoder(EncLaunch p) {
   }
 }
 
+#ifndef OETR_SPLIT_WAVES
+#define OETR_SPLIT_WAVES 8
+#endif
+#ifndef OETR_F32_WAVES
+#define OETR_F32_WAVES 4
+#endif
+
 hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, bool split, hipStream_t s) {
-  const dim3 grid(p.g.ntiles), block(NTHREADS);
-#define OETR_LAUNCH(B, T)                                                           \
-  do {                                                                              \
-    if (split) hipLaunchKernelGGL((k_encoder<B, T, true>), grid, block, 0, s, p);   \
-    else hipLaunchKernelGGL((k_encoder<B, T, false>), grid, block, 0, s, p);        \
+  const dim3 grid(p.g.ntiles);
+#define OETR_LAUNCH(B, T)                                                                      \
+  do {                                                                                         \
+    if (split)                                                                                 \
+      hipLaunchKernelGGL((k_encoder<B, T, true, OETR_SPLIT_WAVES>), grid,                      \
+                         dim3(64 * OETR_SPLIT_WAVES), 0, s, p);                                \
+    else                                                                                       \
+      hipLaunchKernelGGL((k_encoder<B, T, false, OETR_F32_WAVES>), grid,                       \
+                         dim3(64 * OETR_F32_WAVES), 0, s, p);                                  \
   } while (0)
   if (has_b) {
     if (tail == 0) OETR_LAUNCH(true, 0);

@@ -21,8 +21,12 @@ constexpr int GN_GROUPS = 32;
 constexpr float GN_EPS = 1e-5f;
 
 // ---------------------------------------------------------------------------
-template <bool SPLIT>
-__global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
+// NW waves per workgroup (4 for the exact-f32 mode, 8 for the split mode: see
+// encoder.hip); wave w owns NT = 8/NW 32-column tiles of the 256 outputs.
+template <bool SPLIT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
+  constexpr int NT = 8 / NW, THREADS = 64 * NW, WC = 32 * NT;
+  constexpr int TPR = THREADS / TM, F4 = 64 / TPR;  // threads / float4s per row when staging
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -40,32 +44,33 @@ __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
   const float* mem = p.mem[side] + (size_t)n * L * C;
   // att[l'] = memory[l'] . hs for the halo rows l0-wf-1 .. l0+TM+wf of this tile,
-  // once (not per tap): 8 threads per row, DPP row sums.
+  // once (not per tap): TPR threads per row, DPP row sums.
   __shared__ float att_s[TM + 2 * (100 + 1) + 6];
   const int halo0 = l0 - wf - 1, nhalo = TM + 2 * (wf + 1);
-  const int hrow = tid >> 3, hpart = tid & 7;
+  const int hrow = tid / TPR, hpart = tid % TPR;
   {
     const f32x4* hsp = reinterpret_cast<const f32x4*>(p.hs[side] + (size_t)n * C) + hpart;
-    f32x4 hv[8];
+    f32x4 hv[F4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) hv[i] = hsp[i * 8];
+    for (int i = 0; i < F4; ++i) hv[i] = hsp[i * TPR];
     for (int r0 = 0; r0 < nhalo; r0 += TM) {
       const int hr = r0 + hrow;
       const int l = min(max(halo0 + hr, 0), L - 1);  // clamped: out-of-image rows are masked below
       const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)l * C) + hpart;
       float d = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 v = mp[i * 8];
+      for (int i = 0; i < F4; ++i) {
+        const f32x4 v = mp[i * TPR];
         d += (v[0] * hv[i][0] + v[1] * hv[i][1]) + (v[2] * hv[i][2] + v[3] * hv[i][3]);
       }
       d = sum8(d);
+      if (TPR == 16) d += dpp_mov<0x140>(d);
       if (hpart == 0 && hr < nhalo) att_s[hr] = d;
     }
   }
   __syncthreads();
 
-  // gather + scale one tap tile (8 threads per row, float4 columns i*8 + part)
+  // gather + scale one tap tile (TPR threads per row, float4 columns i*TPR + part)
   auto stage = [&](int tap, const ATile<SPLIT>& S) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     const int l = l0 + hrow;
@@ -78,13 +83,13 @@ __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
     const float att = ok ? att_s[src_row - halo0] : 0.f;
     const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)src_row * C) + hpart;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) S.put4(hrow, 4 * (i * 8 + hpart), mp[i * 8] * att);
+    for (int i = 0; i < F4; ++i) S.put4(hrow, 4 * (i * TPR + hpart), mp[i * TPR] * att);
   };
 
-  f32x16 acc[2];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const float b = p.w.conv_b[64 * wave + 32 * t + col];
+  for (int t = 0; t < NT; ++t) {
+    const float b = p.w.conv_b[WC * wave + 32 * t + col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = b;
   }
@@ -97,15 +102,15 @@ __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
   __syncthreads();
   for (int tap = 0; tap < 9; ++tap) {
     if (tap + 1 < 9) stage(tap + 1, buf[(tap + 1) & 1]);
-    buf[tap & 1].template gemm<C, 2>(p.w.conv_w + tap * TAP_UNITS, p.w.conv_w_l + tap * TAP_UNITS,
-                                     2 * wave, lane, acc, 0);
+    buf[tap & 1].template gemm<C, NT>(p.w.conv_w + tap * TAP_UNITS, p.w.conv_w_l + tap * TAP_UNITS,
+                                      NT * wave, lane, acc, 0);
     __syncthreads();
   }
 
   // conv output + per-(tile, group) moments for GroupNorm
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int c = 64 * wave + 32 * t + col;
+  for (int t = 0; t < NT; ++t) {
+    const int c = WC * wave + 32 * t + col;
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -138,8 +143,8 @@ __global__ __launch_bounds__(NTHREADS) void k_heat_conv(HeatLaunch p) {
 }
 
 hipError_t launch_heat_conv(const HeatLaunch& p, bool split, hipStream_t s) {
-  if (split) hipLaunchKernelGGL(k_heat_conv<true>, dim3(p.g.ntiles), dim3(NTHREADS), 0, s, p);
-  else hipLaunchKernelGGL(k_heat_conv<false>, dim3(p.g.ntiles), dim3(NTHREADS), 0, s, p);
+  if (split) hipLaunchKernelGGL((k_heat_conv<true, 8>), dim3(p.g.ntiles), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((k_heat_conv<false, 4>), dim3(p.g.ntiles), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
