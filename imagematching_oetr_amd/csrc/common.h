@@ -71,11 +71,6 @@ struct Geom {
 // ---------------------------------------------------------------- device
 #if defined(__HIPCC__)
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -119,6 +114,15 @@ __device__ __forceinline__ float sum8(float v) {
   v += dpp_mov<0xB1>(v);
   v += dpp_mov<0x4E>(v);
   v += dpp_mov<0x141>(v);
+  return v;
+}
+// Sum over all 64 lanes (result in every lane): DPP inside rows of 16, then two
+// cross-row exchanges (the only steps that need the LDS permute network).
+__device__ __forceinline__ float wave_sum(float v) {
+  v = sum8(v);
+  v += dpp_mov<0x140>(v);  // row_mirror
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 // Branch-free fp32 erf (coefficients and error analysis: tools/fit_erf.py;

@@ -174,13 +174,18 @@ __global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
   const int slot0 = g.tile0[side] + n * nts;
   const size_t row0 = (size_t)g.row0[side] + (size_t)n * L;
 
+  // Chan et al. combination of (count, mean, M2) over the tiles, per group.  The
+  // partials are fetched first (one thread per (tile, group) pair, all loads in
+  // flight together), then 32 threads fold them in tile order.
+  __shared__ float gnp_s[320 * GN_GROUPS * 2];  // up to 313 tiles (100x100 tokens)
+  for (int i = tid; i < nts * GN_GROUPS * 2; i += FIN_THREADS)
+    gnp_s[i] = p.gn_part[(size_t)slot0 * GN_GROUPS * 2 + i];
+  __syncthreads();
   if (tid < GN_GROUPS) {
-    // Chan et al. parallel combination of (count, mean, M2) over the tiles
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
     for (int ti = 0; ti < nts; ++ti) {
       const float nb = 8.f * (float)min(TM, L - ti * TM);
-      const float* src = p.gn_part + ((size_t)(slot0 + ti) * GN_GROUPS + tid) * 2;
-      const float mb = src[0], m2b = src[1];
+      const float mb = gnp_s[(ti * GN_GROUPS + tid) * 2], m2b = gnp_s[(ti * GN_GROUPS + tid) * 2 + 1];
       const float tot = cnt + nb, delta = mb - mean;
       mean += delta * (nb / tot);
       m2 += m2b + delta * delta * (cnt * nb / tot);
@@ -191,20 +196,33 @@ __global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
   }
   __syncthreads();
 
-  {  // logits: one wave per token row
-    const f32x4 gw = reinterpret_cast<const f32x4*>(p.w.gn_w)[lane];
-    const f32x4 gb = reinterpret_cast<const f32x4*>(p.w.gn_b)[lane];
-    const f32x4 ow = reinterpret_cast<const f32x4*>(p.w.out_w)[lane];
-    const float mu = gmean_s[lane >> 1], rs = grstd_s[lane >> 1];
+  {  // logits: 16 threads per token row (64 rows per pass), DPP row sums
+    const int part = tid & 15, rsub = tid >> 4;
+    f32x4 gw[4], gb[4], ow[4];
+    float mu[4], rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f4 = i * 16 + part;  // float4 index -> channels 4*f4 .. 4*f4+3, group f4 >> 1
+      gw[i] = reinterpret_cast<const f32x4*>(p.w.gn_w)[f4];
+      gb[i] = reinterpret_cast<const f32x4*>(p.w.gn_b)[f4];
+      ow[i] = reinterpret_cast<const f32x4*>(p.w.out_w)[f4];
+      mu[i] = gmean_s[f4 >> 1];
+      rs[i] = grstd_s[f4 >> 1];
+    }
     const float ob = p.w.out_b[0];
-    for (int l = wave; l < L; l += FIN_THREADS / 64) {
-      const f32x4 v = reinterpret_cast<const f32x4*>(p.conv_out + (row0 + l) * C)[lane];
-      f32x4 y = (v - mu) * rs * gw + gb;
+    for (int l0 = 0; l0 < L; l0 += FIN_THREADS / 16) {
+      const int l = l0 + rsub;
+      const f32x4* row = reinterpret_cast<const f32x4*>(p.conv_out + (row0 + min(l, L - 1)) * C) + part;
       float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d += fmaxf(y[j], 0.f) * ow[j];
-      d = wave_sum(d) + ob;
-      if (lane == 0) { logit_s[l] = d; p.logits[row0 + l] = d; }
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 y = (row[i * 16] - mu[i]) * rs[i] * gw[i] + gb[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d += fmaxf(y[j], 0.f) * ow[i][j];
+      }
+      d = sum8(d);
+      d += dpp_mov<0x140>(d);  // row_mirror: the other 8 lanes of the 16
+      if (part == 0 && l < L) { logit_s[l] = d + ob; p.logits[row0 + l] = d + ob; }
     }
   }
   __syncthreads();
@@ -240,8 +258,14 @@ __global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
   {
     const int kc = tid >> 8, o = tid & (C - 1);
     float a = 0.f;
-#pragma unroll 16
-    for (int k = kc * 64; k < kc * 64 + 64; ++k) a += p.w.tlbr0_t[k * C + o] * h_s[k];
+#pragma unroll
+    for (int k0 = 0; k0 < 64; k0 += 32) {
+      float wv[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wv[k] = p.w.tlbr0_t[(kc * 64 + k0 + k) * C + o];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) a += wv[k] * h_s[kc * 64 + k0 + k];
+    }
     hid_part[kc][o] = a;
   }
   __syncthreads();
