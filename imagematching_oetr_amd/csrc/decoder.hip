@@ -150,6 +150,41 @@ hipError_t launch_decoder_consts(const DecConstLaunch& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
+// Software-pipelined GEMV chain: a stage's weights are consumed in batches of 16
+// float4 per thread (64 VGPRs); as soon as a batch has been multiplied in, the
+// NEXT batch (of this or the following stage - weights do not depend on data) is
+// issued into the same registers, so its L2 round trip runs under the current
+// stage's partial-sum exchange, barriers and LayerNorm.
+template <int K, int NOUT>
+struct GemvShape {
+  static constexpr int NO4 = NOUT / 4;
+  static constexpr int KCH = DEC_THREADS / NO4;  // k-chunks (threads per output float4)
+  static constexpr int KPER = K / KCH;           // k rows per thread
+  static constexpr int NB = KPER / 16;           // batches of 16 rows
+  static_assert(KPER % 16 == 0, "batching");
+};
+template <int K, int NOUT, int B>
+__device__ __forceinline__ void gemv_issue(const float* __restrict__ Wt, int tid, f32x4 (&wv)[16]) {
+  using S = GemvShape<K, NOUT>;
+  const int kc = tid / S::NO4, o4 = tid % S::NO4;
+  const f32x4* w = reinterpret_cast<const f32x4*>(Wt) + (size_t)(kc * S::KPER + B * 16) * S::NO4 + o4;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wv[i] = w[(size_t)i * S::NO4];
+  __builtin_amdgcn_sched_barrier(0);  // keep the loads here
+}
+template <int K, int NOUT, int B>
+__device__ __forceinline__ void gemv_fma(const f32x4 (&wv)[16], const float* x_s, int tid, f32x4& acc) {
+  using S = GemvShape<K, NOUT>;
+  const int kc = tid / S::NO4;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += wv[i] * x_s[kc * S::KPER + B * 16 + i];
+}
+template <int K, int NOUT>
+__device__ __forceinline__ void gemv_put(const f32x4& acc, float* part_s, int tid) {
+  using S = GemvShape<K, NOUT>;
+  *reinterpret_cast<f32x4*>(part_s + (tid / S::NO4) * NOUT + 4 * (tid % S::NO4)) = acc;
+}
+
 __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   __shared__ __attribute__((aligned(16))) float kv_s[KV_FLOATS];  // [h][d][v], layer 1
   __shared__ __attribute__((aligned(16))) float part_s[3 * 4096];
@@ -157,7 +192,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   __shared__ __attribute__((aligned(16))) float qkv_s[3 * C];
   __shared__ __attribute__((aligned(16))) float hdn_s[FF];
   float *tgt = vec_s[0], *t2 = vec_s[1], *qk = vec_s[2], *vq = vec_s[3], *att = vec_s[4],
-        *msg = vec_s[5], *qe = vec_s[6], *ksum = vec_s[7];
+        *qe = vec_s[6], *ksum = vec_s[7];
 
   const Geom& g = p.g;
   const int tid = threadIdx.x;
@@ -167,11 +202,16 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   const int slot0 = g.tile0[side] + n * nts;
   const DecLayerDev& w0 = p.layer[0];
   const DecLayerDev& w1 = p.layer[1];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 wv[16];
+  f32x4 acc;
+  gemv_issue<C, C, 0>(w0.cross.wm_t, tid, wv);  // stage 1 weights, under the state reduction
 
   // ---- layer 1 memory state: reduce the tile partials into LDS (4 tiles in flight)
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(p.dkv1) + (size_t)slot0 * (KV_FLOATS / 4) + tid;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    f32x4 s0 = zero4, s1 = zero4;
     float ks = 0.f;
     for (int ti0 = 0; ti0 < nts; ti0 += 4) {
       f32x4 a[4], b[4];
@@ -218,20 +258,51 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
     qe[tid] = p.qe[side][tid];
   }
   __syncthreads();
-  gemv<C, C>(w0.cross.wm_t, att, nullptr, msg, part_s, tid);
-  if (tid < C) tgt[tid] += msg[tid];
+
+  // S1: tgt += Wm_c0 . att0
+  acc = zero4;
+  gemv_fma<C, C, 0>(wv, att, tid, acc);
+  gemv_issue<C, FF, 0>(w0.w1_t, tid, wv);
+  gemv_put<C, C>(acc, part_s, tid);
   __syncthreads();
+  if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
+  __syncthreads();
+  // S2: hdn = relu(W1_0 . LN3(tgt))
   ln_vec(tgt, w0.n3w, w0.n3b, t2, nullptr, nullptr, tid);
-  gemv<C, FF>(w0.w1_t, t2, nullptr, hdn_s, part_s, tid, true);
-  gemv<FF, C>(w0.w2_t, hdn_s, nullptr, msg, part_s, tid);
-  if (tid < C) tgt[tid] += msg[tid];
+  acc = zero4;
+  gemv_fma<C, FF, 0>(wv, t2, tid, acc);
+  gemv_issue<C, FF, 1>(w0.w1_t, tid, wv);
+  gemv_fma<C, FF, 1>(wv, t2, tid, acc);
+  gemv_issue<FF, C, 0>(w0.w2_t, tid, wv);
+  gemv_put<C, FF>(acc, part_s, tid);
+  __syncthreads();
+  if (tid < FF) hdn_s[tid] = fmaxf(gemv_collect<C, FF>(part_s, tid), 0.f);
+  __syncthreads();
+  // S3: tgt += W2_0 . hdn
+  acc = zero4;
+  gemv_fma<FF, C, 0>(wv, hdn_s, tid, acc);
+  gemv_issue<FF, C, 1>(w0.w2_t, tid, wv);
+  gemv_fma<FF, C, 1>(wv, hdn_s, tid, acc);
+  gemv_issue<C, C, 0>(w1.self_attn.wq_t, tid, wv);
+  gemv_put<FF, C>(acc, part_s, tid);
+  __syncthreads();
+  if (tid < C) tgt[tid] += gemv_collect<FF, C>(part_s, tid);
   __syncthreads();
 
-  // ---- layer 1 self-attention: fused q|k|v from LN1(tgt)
+  // S4: layer 1 self-attention: fused q|k|v from LN1(tgt)
   ln_vec(tgt, w1.n1w, w1.n1b, t2, nullptr, nullptr, tid);
-  gemv_partial<C, C>(w1.self_attn.wq_t, t2, part_s, tid);
-  gemv_partial<C, C>(w1.self_attn.wk_t, t2, part_s + 4096, tid);
-  gemv_partial<C, C>(w1.self_attn.wv_t, t2, part_s + 8192, tid);
+  acc = zero4;
+  gemv_fma<C, C, 0>(wv, t2, tid, acc);
+  gemv_issue<C, C, 0>(w1.self_attn.wk_t, tid, wv);
+  gemv_put<C, C>(acc, part_s, tid);
+  acc = zero4;
+  gemv_fma<C, C, 0>(wv, t2, tid, acc);
+  gemv_issue<C, C, 0>(w1.self_attn.wv_t, tid, wv);
+  gemv_put<C, C>(acc, part_s + 4096, tid);
+  acc = zero4;
+  gemv_fma<C, C, 0>(wv, t2, tid, acc);
+  gemv_issue<C, C, 0>(w1.self_attn.wm_t, tid, wv);
+  gemv_put<C, C>(acc, part_s + 8192, tid);
   __syncthreads();
   if (tid < 3 * C) {
     const int m = tid >> 8, o = tid & (C - 1);
@@ -240,13 +311,22 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   __syncthreads();
   if (tid < C) att[tid] = self_attn_1x1(qkv_s, qkv_s + C, qkv_s[2 * C + tid], tid);
   __syncthreads();
-  gemv<C, C>(w1.self_attn.wm_t, att, nullptr, msg, part_s, tid);
-  if (tid < C) tgt[tid] += msg[tid];
+  // S5: tgt += Wm_s1 . att
+  acc = zero4;
+  gemv_fma<C, C, 0>(wv, att, tid, acc);
+  gemv_issue<C, C, 0>(w1.cross.wq_t, tid, wv);
+  gemv_put<C, C>(acc, part_s, tid);
   __syncthreads();
-  // ---- layer 1 cross-attention against the memory state
+  if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
+  __syncthreads();
+  // S6: layer 1 cross-attention query
   ln_vec(tgt, w1.n2w, w1.n2b, t2, qe, qk, tid);
-  gemv<C, C>(w1.cross.wq_t, qk, w1.cross.bq, vq, part_s, tid);
-  if (tid < C) vq[tid] = elu1(vq[tid]);
+  acc = zero4;
+  gemv_fma<C, C, 0>(wv, qk, tid, acc);
+  gemv_issue<C, C, 0>(w1.cross.wm_t, tid, wv);
+  gemv_put<C, C>(acc, part_s, tid);
+  __syncthreads();
+  if (tid < C) vq[tid] = elu1(gemv_collect<C, C>(part_s, tid) + w1.cross.bq[tid]);
   __syncthreads();
   if (tid < C) {
     const int h = tid >> 5, v = tid & 31;
@@ -260,14 +340,32 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
     att[tid] = s * (1.0f / (z + ATTN_EPS)) * (float)L;
   }
   __syncthreads();
-  gemv<C, C>(w1.cross.wm_t, att, nullptr, msg, part_s, tid);
-  if (tid < C) tgt[tid] += msg[tid];
+  // S7: tgt += Wm_c1 . att
+  acc = zero4;
+  gemv_fma<C, C, 0>(wv, att, tid, acc);
+  gemv_issue<C, FF, 0>(w1.w1_t, tid, wv);
+  gemv_put<C, C>(acc, part_s, tid);
   __syncthreads();
-  // ---- ReLU MLP
+  if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
+  __syncthreads();
+  // S8/S9: ReLU MLP
   ln_vec(tgt, w1.n3w, w1.n3b, t2, nullptr, nullptr, tid);
-  gemv<C, FF>(w1.w1_t, t2, nullptr, hdn_s, part_s, tid, true);
-  gemv<FF, C>(w1.w2_t, hdn_s, nullptr, msg, part_s, tid);
-  if (tid < C) p.hs[(size_t)img * C + tid] = tgt[tid] + msg[tid];
+  acc = zero4;
+  gemv_fma<C, FF, 0>(wv, t2, tid, acc);
+  gemv_issue<C, FF, 1>(w1.w1_t, tid, wv);
+  gemv_fma<C, FF, 1>(wv, t2, tid, acc);
+  gemv_issue<FF, C, 0>(w1.w2_t, tid, wv);
+  gemv_put<C, FF>(acc, part_s, tid);
+  __syncthreads();
+  if (tid < FF) hdn_s[tid] = fmaxf(gemv_collect<C, FF>(part_s, tid), 0.f);
+  __syncthreads();
+  acc = zero4;
+  gemv_fma<FF, C, 0>(wv, hdn_s, tid, acc);
+  gemv_issue<FF, C, 1>(w1.w2_t, tid, wv);
+  gemv_fma<FF, C, 1>(wv, hdn_s, tid, acc);
+  gemv_put<FF, C>(acc, part_s, tid);
+  __syncthreads();
+  if (tid < C) p.hs[(size_t)img * C + tid] = tgt[tid] + gemv_collect<FF, C>(part_s, tid);
 }
 
 hipError_t launch_decoder(const DecLaunch& p, hipStream_t s) {
