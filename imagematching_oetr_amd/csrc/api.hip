@@ -280,6 +280,10 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
     d.tgt1 = h->dec_tgt1; d.qkv1 = h->dec_qkv1;
     d.att0_part = w.att0; d.z0_part = w.z0; d.dkv1 = w.dkv1; d.dks1 = w.dks1;
     d.hs = w.hs;
+    d.tbuf = nullptr;
+#ifdef OETR_PHASE_TIMING
+    d.tbuf = g_tbuf ? g_tbuf + 16 * 4096 : nullptr;
+#endif
     TRACED(h, s, K_DECODER, launch_decoder(d, s));
   }
   return OETR_OK;
@@ -679,6 +683,10 @@ oetr_status oetr_trace_summary(oetr_trace_handle t, int* n_kernels,
 int oetr_debug_read_tbuf(long long* host, int n_blocks) {
   if (!g_tbuf) return 1;
   return hipMemcpy(host, g_tbuf, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost) != hipSuccess;
+}
+int oetr_debug_read_tbuf_decoder(long long* host, int n_blocks) {
+  if (!g_tbuf) return 1;
+  return hipMemcpy(host, g_tbuf + 16 * 4096, sizeof(long long) * 16 * n_blocks, hipMemcpyDeviceToHost) != hipSuccess;
 }
 #endif
 

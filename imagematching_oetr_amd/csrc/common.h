@@ -478,6 +478,7 @@ struct DecLaunch {
   const float* dkv1;       // [ntiles][8192]
   const float* dks1;       // [ntiles][256]
   float* hs;               // [2N][256]
+  long long* tbuf;         // OETR_PHASE_TIMING builds only
 };
 struct DecConstLaunch {
   DecLayerDev layer[2];

@@ -207,25 +207,30 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   f32x4 wv[16];
   f32x4 acc;
   gemv_issue<C, C, 0>(w0.cross.wm_t, tid, wv);  // stage 1 weights, under the state reduction
+  PHASE_STAMP(p, 0);
 
-  // ---- layer 1 memory state: reduce the tile partials into LDS (4 tiles in flight)
+  // ---- reduce the tile partials of this image in one pass (4 tiles in flight per
+  // round trip): layer 1 memory state -> LDS, layer 0 partial messages -> att
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(p.dkv1) + (size_t)slot0 * (KV_FLOATS / 4) + tid;
+    const int c = tid & (C - 1), hh = c >> 5;
     f32x4 s0 = zero4, s1 = zero4;
-    float ks = 0.f;
+    float ks = 0.f, a0 = 0.f, z0 = 0.f;
     for (int ti0 = 0; ti0 < nts; ti0 += 4) {
       f32x4 a[4], b[4];
-      float kt[4];
+      float kt[4], av[4], zv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t ti = min(ti0 + u, nts - 1);
         a[u] = src[ti * (KV_FLOATS / 4)];
         b[u] = src[ti * (KV_FLOATS / 4) + DEC_THREADS];
-        kt[u] = p.dks1[(slot0 + ti) * C + (tid & (C - 1))];
+        kt[u] = p.dks1[(slot0 + ti) * C + c];
+        av[u] = p.att0_part[(slot0 + ti) * C + c];
+        zv[u] = p.z0_part[(slot0 + ti) * NH + hh];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (ti0 + u < nts) { s0 += a[u]; s1 += b[u]; ks += kt[u]; }
+        if (ti0 + u < nts) { s0 += a[u]; s1 += b[u]; ks += kt[u]; a0 += av[u]; z0 += zv[u]; }
     }
 #pragma unroll
     for (int e2 = 0; e2 < 2; ++e2) {
@@ -235,30 +240,16 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) kv_s[(h * HD + (j + 8 * q + 4 * (ln >> 5))) * HD + (ln & 31)] = s[j];
     }
-    if (tid < C) ksum[tid] = ks;
-  }
-  // ---- layer 0 cross-attention: partial messages from the encoder tail
-  if (tid < C) {
-    float a = 0.f, z = 0.f;
-    const int h = tid >> 5;
-    for (int ti0 = 0; ti0 < nts; ti0 += 4) {
-      float av[4], zv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const size_t ti = slot0 + min(ti0 + u, nts - 1);
-        av[u] = p.att0_part[ti * C + tid];
-        zv[u] = p.z0_part[ti * NH + h];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ti0 + u < nts) { a += av[u]; z += zv[u]; }
+    if (tid < C) {
+      ksum[tid] = ks;
+      att[tid] = a0 * (1.0f / (z0 + ATTN_EPS)) * (float)L;
+      tgt[tid] = p.tgt1[side * C + tid];
+      qe[tid] = p.qe[side][tid];
     }
-    att[tid] = a * (1.0f / (z + ATTN_EPS)) * (float)L;
-    tgt[tid] = p.tgt1[side * C + tid];
-    qe[tid] = p.qe[side][tid];
   }
   __syncthreads();
 
+  PHASE_STAMP(p, 1);
   // S1: tgt += Wm_c0 . att0
   acc = zero4;
   gemv_fma<C, C, 0>(wv, att, tid, acc);
@@ -267,6 +258,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   __syncthreads();
   if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
   __syncthreads();
+  PHASE_STAMP(p, 2);
   // S2: hdn = relu(W1_0 . LN3(tgt))
   ln_vec(tgt, w0.n3w, w0.n3b, t2, nullptr, nullptr, tid);
   acc = zero4;
@@ -278,6 +270,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   __syncthreads();
   if (tid < FF) hdn_s[tid] = fmaxf(gemv_collect<C, FF>(part_s, tid), 0.f);
   __syncthreads();
+  PHASE_STAMP(p, 3);
   // S3: tgt += W2_0 . hdn
   acc = zero4;
   gemv_fma<FF, C, 0>(wv, hdn_s, tid, acc);
@@ -289,6 +282,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   if (tid < C) tgt[tid] += gemv_collect<FF, C>(part_s, tid);
   __syncthreads();
 
+  PHASE_STAMP(p, 4);
   // S4: layer 1 self-attention: fused q|k|v from LN1(tgt)
   ln_vec(tgt, w1.n1w, w1.n1b, t2, nullptr, nullptr, tid);
   acc = zero4;
@@ -309,8 +303,23 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
     qkv_s[tid] = gemv_collect<C, C>(part_s + 4096 * m, o) + p.qkv1[side * 3 * C + tid];
   }
   __syncthreads();
-  if (tid < C) att[tid] = self_attn_1x1(qkv_s, qkv_s + C, qkv_s[2 * C + tid], tid);
+  if (tid < 2 * C) qkv_s[tid] = elu1(qkv_s[tid]);  // phi(q), phi(k) once per element
   __syncthreads();
+  if (tid < C) {
+    // L = S = 1 linear attention (values / v_length with v_length = 1)
+    const int h = tid >> 5;
+    const float vval = qkv_s[2 * C + tid] / 1.0f;
+    float z = 0.f, sacc = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) {
+      const float fq = qkv_s[h * HD + d], fk = qkv_s[C + h * HD + d];
+      z += fq * fk;
+      sacc += fq * (fk * vval);
+    }
+    att[tid] = sacc * (1.0f / (z + ATTN_EPS)) * 1.0f;
+  }
+  __syncthreads();
+  PHASE_STAMP(p, 5);
   // S5: tgt += Wm_s1 . att
   acc = zero4;
   gemv_fma<C, C, 0>(wv, att, tid, acc);
@@ -319,6 +328,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   __syncthreads();
   if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
   __syncthreads();
+  PHASE_STAMP(p, 6);
   // S6: layer 1 cross-attention query
   ln_vec(tgt, w1.n2w, w1.n2b, t2, qe, qk, tid);
   acc = zero4;
@@ -340,6 +350,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
     att[tid] = s * (1.0f / (z + ATTN_EPS)) * (float)L;
   }
   __syncthreads();
+  PHASE_STAMP(p, 7);
   // S7: tgt += Wm_c1 . att
   acc = zero4;
   gemv_fma<C, C, 0>(wv, att, tid, acc);
@@ -348,6 +359,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   __syncthreads();
   if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
   __syncthreads();
+  PHASE_STAMP(p, 8);
   // S8/S9: ReLU MLP
   ln_vec(tgt, w1.n3w, w1.n3b, t2, nullptr, nullptr, tid);
   acc = zero4;
@@ -366,6 +378,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   gemv_put<FF, C>(acc, part_s, tid);
   __syncthreads();
   if (tid < C) p.hs[(size_t)img * C + tid] = tgt[tid] + gemv_collect<FF, C>(part_s, tid);
+  PHASE_STAMP(p, 9);
 }
 
 hipError_t launch_decoder(const DecLaunch& p, hipStream_t s) {
