@@ -37,22 +37,23 @@ F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 DOMINANT = 'k_encoder<B,A>'
 
 
-def synthetic_inputs(pairs, size, device):
+def synthetic_inputs(pairs, size, size2, device):
     """Random-init weights of the architecture + uniform features with the
     spread of the real extraction path (std ~0.29).  No oracle involved."""
     import imagematching_oetr_amd as pkg
     torch.manual_seed(0)
     model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
     weights = {k: v.detach().clone() for k, v in model.hot_path_state().items()}
-    hf = size // 32
+    hf, hf2 = size // 32, size2 // 32
     g = torch.Generator().manual_seed(1 + int(os.environ.get('RANK', 0)))
     feat1 = (torch.rand(pairs, 256, hf, hf, generator=g) - 0.5).to(device)
-    feat2 = (torch.rand(pairs, 256, hf, hf, generator=g) - 0.5).to(device)
-    pos = model.pos_encoding(feat1.cpu()).contiguous().to(device)
-    return model, weights, feat1, feat2, pos, hf
+    feat2 = (torch.rand(pairs, 256, hf2, hf2, generator=g) - 0.5).to(device)
+    pos1 = model.pos_encoding(feat1.cpu()).contiguous().to(device)
+    pos2 = model.pos_encoding(feat2.cpu()).contiguous().to(device)
+    return model, weights, feat1, feat2, pos1, pos2, hf, hf2
 
 
-def cpu_baseline(weights, feat1, feat2, size, budget_s=12.0):
+def cpu_baseline(weights, feat1, feat2, size, size2, budget_s=12.0):
     """The oracle timed on the host cores (bounded sample, rank 0 only).
     torch's intra-op pool is tried at a few sizes first (small tensors stop
     scaling long before a 100+-core host is full; more threads only add
@@ -61,7 +62,7 @@ def cpu_baseline(weights, feat1, feat2, size, budget_s=12.0):
     f1, f2 = feat1.cpu(), feat2.cpu()
     w = {k: v.cpu() for k, v in weights.items()}
     ncpu = os.cpu_count() or 1
-    run = lambda: orc.hot_path(f1, f2, w, (size, size), (size, size))
+    run = lambda: orc.hot_path(f1, f2, w, (size, size), (size2, size2))
     best_t, best_dt = 1, float('inf')
     for threads in sorted({t for t in (4, 8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)}):
         torch.set_num_threads(threads)
@@ -82,7 +83,9 @@ def cpu_baseline(weights, feat1, feat2, size, budget_s=12.0):
             break
     return dict(value=round(f1.shape[0] * iters / dt, 2), unit='image-pairs/s',
                 cores=best_t, kind='port',
-                sample=f'{iters} batches of {f1.shape[0]} pairs @ {size}x{size} '
+                sample=f'{iters} batches of {f1.shape[0]} pairs @ {size}x{size}'
+                       + (f' vs {size2}x{size2} ' if size2 != size else ' ')
+                       +
                        f'(hot path only, features precomputed) in {dt:.1f} s; '
                        f'oracle/oetr_oracle.py on torch CPU, {best_t} intra-op '
                        f'threads (best of 4..64 on a {ncpu}-CPU host)'), boxes
@@ -118,6 +121,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--pairs-per-gpu', type=int, default=8)
     ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--size2', type=int, default=None,
+                    help='side of image2 (default: same as --size); BASELINE configs[4] = 1280')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true')
     ap.add_argument('--precision', default='f32_split_f16', choices=['f32_split_f16', 'f32'],
@@ -144,13 +149,14 @@ def main():
     from imagematching_oetr_amd.parallel import gather_boxes
     torch.set_grad_enabled(False)
     n = args.pairs_per_gpu
-    model, weights, feat1, feat2, pos, hf = synthetic_inputs(n, args.size, device)
+    size2 = args.size2 or args.size
+    model, weights, feat1, feat2, pos, pos2, hf, hf2 = synthetic_inputs(n, args.size, size2, device)
     eng = pkg.HotPathEngine(weights, device=device, precision=args.precision)
-    hw = (args.size, args.size)
+    hw, hw2 = (args.size, args.size), (size2, size2)
     n_total = n * world
 
     def step():
-        b1, b2 = eng.forward(feat1, feat2, pos, pos, hw, hw)
+        b1, b2 = eng.forward(feat1, feat2, pos, pos2, hw, hw2)
         if world > 1:
             # every rank holds the same number of pairs: plain padded all-gather
             b1, b2 = gather_boxes(b1, b2, n_total)
@@ -203,19 +209,21 @@ def main():
         'gemm_mode': ('fp32-class products from 3 f16 MFMAs (a=ah+al/2^11 split), fp32 accumulate'
                       if args.precision == 'f32_split_f16' else 'exact fp32 MFMA'),
         'data': 'synthetic',
-        'config': {'workload': f'BASELINE configs[1]: batch={n} pairs/GPU, '
-                               f'{args.size}x{args.size} -> {hf}x{hf} tokens/image, '
-                               'C=256, 8 enc + 2 dec layers, fp32',
+        'config': {'workload': (f'BASELINE configs[1]: ' if (n, args.size, size2) == (8, 640, 640) else '')
+                               + f'batch={n} pairs/GPU, {args.size}x{args.size}'
+                               + (f' vs {size2}x{size2}' if size2 != args.size else '')
+                               + f' -> {hf}x{hf}' + (f' / {hf2}x{hf2}' if hf2 != hf else '')
+                               + ' tokens/image, C=256, 8 enc + 2 dec layers, fp32',
                    'pairs_per_gpu': n, 'global_pairs': n_total,
                    'tokens_per_image': hf * hf,
                    'parallelism': f'pairs sharded over {world} rank(s); '
                                   'all-gather of boxes only'},
-        'hot_path_tflops': round(value * PAIR_GFLOP_640 * (args.size / 640) ** 2 / 1e3, 2),
+        'hot_path_tflops': round(value * PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800 / 1e3, 2),
     }
     if kern and DOMINANT in kern:
         launches, total_ms = kern[DOMINANT]
         avg_ms = total_ms / launches
-        flop = ENC_FLOP_PER_TOKEN * 2 * n * hf * hf     # tokens of both sides (algorithmic)
+        flop = ENC_FLOP_PER_TOKEN * n * (hf * hf + hf2 * hf2)   # tokens of both sides (algorithmic)
         split = args.precision == 'f32_split_f16'
         # split mode executes 3 f16 MFMA products per algorithmic product
         executed = flop * (3 if split else 1)
@@ -227,7 +235,7 @@ def main():
             'mfma_dtype': 'f16 (3 products per fp32 product)' if split else 'f32',
             'achieved_algorithmic_tflops': round(flop / (avg_ms * 1e-3) / 1e12, 2),
             'frac_of_f32_mfma_peak': round(flop / (avg_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-            'traffic': pmc_traffic_bytes('k_encoderILb1ELi0E') if (n, args.size) == (8, 640) else None,
+            'traffic': pmc_traffic_bytes('k_encoderILb1ELi0E') if (n, args.size, size2) == (8, 640, 640) else None,
             'avg_launch_us': round(avg_ms * 1e3, 2), 'launches': launches,
             'flop_per_launch': flop,
             'share_of_step': round(total_ms / (elapsed_traced * 1e3), 4),
@@ -235,10 +243,10 @@ def main():
         out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
                              for k, v in kern.items()}
     if not args.no_cpu_baseline:
-        base, ref_boxes = cpu_baseline(weights, feat1, feat2, args.size)
+        base, ref_boxes = cpu_baseline(weights, feat1, feat2, args.size, size2)
         out['cpu_baseline'] = base
         from oracle import oetr_oracle as orc
-        mine = eng.forward(feat1, feat2, pos, pos, hw, hw)
+        mine = eng.forward(feat1, feat2, pos, pos2, hw, hw2)
         iou = torch.cat([orc.bbox_iou_aligned(mine[0].cpu(), ref_boxes[0]),
                          orc.bbox_iou_aligned(mine[1].cpu(), ref_boxes[1])])
         out['iou_vs_cpu_min'] = round(float(iou.min()), 6)
@@ -248,7 +256,7 @@ def main():
             model = model.to(device)
             g = torch.Generator().manual_seed(2)
             im1 = torch.rand(n, args.size, args.size, 3, generator=g).to(device)
-            im2 = torch.rand(n, args.size, args.size, 3, generator=g).to(device)
+            im2 = torch.rand(n, size2, size2, 3, generator=g).to(device)
             for _ in range(3):
                 model.forward_dummy(im1, im2)
             torch.cuda.synchronize()

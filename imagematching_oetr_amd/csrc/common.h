@@ -275,6 +275,9 @@ struct GemmRegsH {
 //            holds, for output column n = 32*ntile + (lane&31), inputs
 //            k = 16*ks + 8*(lane>>5) + {0..7}.
 //   acc = main + cross/2^11 is formed at the end; `acc` enters as the initial main part.
+#ifndef OETR_SPLIT_DEPTH
+#define OETR_SPLIT_DEPTH 3   // register buffers in the weight/activation prefetch ring
+#endif
 #ifndef OETR_SPLIT_U1
 #define OETR_SPLIT_U1 2   // chunk depth (k16 steps) when a wave owns one n-tile (8-wave shape)
 #endif
@@ -332,6 +335,32 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
     }
   };
 
+#if OETR_SPLIT_DEPTH == 3
+  // ring of three register buffers: two chunks of fragments in flight while the
+  // third is consumed (per-CU weight streaming is latency-bound: ~2000 cycles per
+  // L2 round trip under the all-workgroups-read-the-same-lines load)
+  GemmRegsH<NT, U> r0, r1, r2;
+  fetch(r0, 0);
+  fetch(r1, 1);
+  for (int c = 0; c < NCH; c += 3) {
+    if (c + 2 < NCH) fetch(r2, c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(r0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NCH) {
+      if (c + 3 < NCH) fetch(r0, c + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(r1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c + 2 < NCH) {
+      if (c + 4 < NCH) fetch(r1, c + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(r2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#else
   GemmRegsH<NT, U> r0, r1;
   fetch(r0, 0);
   for (int c = 0; c < NCH; c += 2) {
@@ -344,6 +373,7 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
     mma(r1);
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
