@@ -259,6 +259,31 @@ def test_properties_at_bench_size(gpu, engines):
     assert (orc.bbox_iou_aligned(b2.cpu(), r2) >= 1 - 1e-3).all()
 
 
+def test_forward_is_hipgraph_capturable(gpu, engines):
+    """The ABI promises enqueue-only calls (no allocation / sync inside): a
+    forward captured into a HIP graph must replay bit-identically."""
+    eng = engines(1, True)
+    n = 4
+    f1, f2 = orc.make_features(61, n, 20, 20).to(gpu), orc.make_features(62, n, 15, 12).to(gpu)
+    p1, p2 = orc.position_table(20, 20).to(gpu), orc.position_table(15, 12).to(gpu)
+    eager = eng.forward(f1, f2, p1, p2, (640, 640), (480, 384))   # also sizes the workspace
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = eng.forward(f1, f2, p1, p2, (640, 640), (480, 384))
+    for _ in range(3):
+        captured[0].zero_(); captured[1].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(captured[0], eager[0]) and torch.equal(captured[1], eager[1])
+    # new inputs through the same graph (static buffers)
+    f1.copy_(orc.make_features(63, n, 20, 20).to(gpu))
+    graph.replay()
+    torch.cuda.synchronize()
+    fresh = eng.forward(f1, f2, p1, p2, (640, 640), (480, 384))
+    assert torch.equal(captured[0], fresh[0])
+
+
 def test_drop_in_module_forward_dummy(gpu):
     """OETR.forward_dummy on images: host backbone (torch/MIOpen) + HIP hot
     path, vs the same backbone features pushed through the oracle."""
