@@ -139,14 +139,21 @@ def main():
         print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with '
               f'torchrun --nproc-per-node {args.gpus}', file=sys.stderr)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # (dry runs of the N>1 logic on a 1-GPU box: OETR_BENCH_BACKEND=gloo maps every
+    #  rank onto the GPUs that exist; the real launch is one rank per GPU over RCCL)
+    backend = os.environ.get('OETR_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import imagematching_oetr_amd as pkg
-    from imagematching_oetr_amd.parallel import gather_boxes
+    from imagematching_oetr_amd.parallel import BoxGatherer
     torch.set_grad_enabled(False)
     n = args.pairs_per_gpu
     size2 = args.size2 or args.size
@@ -155,11 +162,14 @@ def main():
     hw, hw2 = (args.size, args.size), (size2, size2)
     n_total = n * world
 
+    gatherer = BoxGatherer() if world > 1 else None
+
     def step():
         b1, b2 = eng.forward(feat1, feat2, pos, pos2, hw, hw2)
-        if world > 1:
-            # every rank holds the same number of pairs: plain padded all-gather
-            b1, b2 = gather_boxes(b1, b2, n_total)
+        if gatherer is not None:
+            # the all-gather of this batch's boxes runs on RCCL's stream under the
+            # next batch's kernels; it is completed at the next submit / the flush
+            gatherer.submit(b1, b2)
         return b1, b2
 
     def barrier():
@@ -172,6 +182,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        if gatherer is not None:
+            gatherer.flush()            # last batch's gather is inside the timed region
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:

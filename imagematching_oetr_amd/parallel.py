@@ -47,9 +47,10 @@ def gather_boxes(box1, box2, n_pairs, group=None):
     if n_pairs % world == 0 and dist.get_backend(group) != 'gloo':
         # equal shards (the benchmarked case): one stack, one collective, views
         mine = torch.stack((box1, box2))                         # [2, n_local, 4]
-        everyone = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype,
-                               device=mine.device)
-        dist.all_gather_into_tensor(everyone, mine, group=group)
+        flat = torch.empty((world * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype,
+                           device=mine.device)                   # concatenation along dim 0
+        dist.all_gather_into_tensor(flat, mine, group=group)
+        everyone = flat.view((world, 2) + tuple(mine.shape[1:]))
         return (everyone[:, 0].reshape(n_pairs, 4), everyone[:, 1].reshape(n_pairs, 4))
     cap = -(-n_pairs // world)                       # ceil: padded shard size
     mine = torch.zeros(cap, 2, 4, dtype=box1.dtype, device=box1.device)
@@ -69,6 +70,41 @@ def gather_boxes(box1, box2, n_pairs, group=None):
         for r in range(world)]).to(everyone.device)
     full = everyone.index_select(0, keep)
     return full[:, 0].contiguous(), full[:, 1].contiguous()
+
+
+class BoxGatherer:
+    """Pipelined box all-gather for a stream of batches: the collective of
+    batch k is issued asynchronously (RCCL's own stream) and completed when
+    batch k+1 is submitted, so the latency-bound gather runs under the next
+    batch's compute.  ``submit`` returns the gathered boxes of
+    the PREVIOUS batch (None the first time); ``flush`` returns the last one.
+    Equal shards only (every rank holds ``n_local`` pairs)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._pending = None
+
+    def _finish(self):
+        if self._pending is None:
+            return None
+        work, everyone, n_pairs = self._pending
+        self._pending = None
+        work.wait()
+        return (everyone[:, 0].reshape(n_pairs, 4), everyone[:, 1].reshape(n_pairs, 4))
+
+    def submit(self, box1, box2):
+        done = self._finish()
+        world = dist.get_world_size(self.group)
+        mine = torch.stack((box1, box2))                          # [2, n_local, 4]
+        flat = torch.empty((world * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype,
+                           device=mine.device)             # concatenation along dim 0
+        work = dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)
+        self._pending = (work, flat.view((world, 2) + tuple(mine.shape[1:])),
+                         world * box1.shape[0])
+        return done
+
+    def flush(self):
+        return self._finish()
 
 
 @torch.no_grad()

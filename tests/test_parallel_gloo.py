@@ -75,6 +75,41 @@ def test_gather_boxes_world2_gloo(n_pairs):
         assert torch.equal(torch.tensor(g2), -expect1), rank
 
 
+def _pipe_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from imagematching_oetr_amd.parallel import BoxGatherer
+        g = BoxGatherer()
+        outs = []
+        for k in range(3):                       # three batches of 2 pairs per rank
+            b1 = torch.full((2, 4), float(10 * k + rank))
+            done = g.submit(b1, -b1)
+            assert (done is None) == (k == 0)
+            if done is not None:
+                outs.append(done[0][:, 0].tolist())
+        outs.append(g.flush()[0][:, 0].tolist())
+        assert g.flush() is None
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_box_gatherer_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs in results:
+        assert outs == [[0.0, 0.0, 1.0, 1.0], [10.0, 10.0, 11.0, 11.0], [20.0, 20.0, 21.0, 21.0]]
+
+
 def test_gather_is_identity_without_process_group():
     b1, b2 = torch.rand(3, 4), torch.rand(3, 4)
     g1, g2 = gather_boxes(b1, b2, 3)
