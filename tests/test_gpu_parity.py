@@ -195,6 +195,26 @@ def test_edge_shapes(n, g1, g2, precision, gpu, engines):
     check_stages(out, ref, f'{n} {g1} {g2}')
 
 
+def test_random_shapes_fuzz(gpu, engines):
+    """A fixed sample of the random-shape fuzz (tools/fuzz_gpu.py runs more)."""
+    import random
+    rng = random.Random(7)
+    for case in range(10):
+        wseed, sharp = rng.randrange(4), rng.random() < 0.5
+        prec = rng.choice(PRECISIONS)
+        n = rng.randrange(1, 5)
+        g1 = (rng.randrange(1, 41), rng.randrange(1, 41))
+        g2 = (rng.randrange(1, 41), rng.randrange(1, 41))
+        w = orc.make_hot_weights(wseed, sharpen=sharp)
+        f1, f2 = orc.make_features(3000 + case, n, *g1), orc.make_features(4000 + case, n, *g2)
+        p1, p2 = orc.position_table(*g1), orc.position_table(*g2)
+        im1, im2 = (g1[0] * 32, g1[1] * 32), (g2[0] * 32, g2[1] * 32)
+        out = engines(wseed, sharp, prec).forward(f1.to(gpu), f2.to(gpu), p1.to(gpu),
+                                                  p2.to(gpu), im1, im2, stages=True)
+        ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
+        check_stages(out, ref, f'fuzz {case} n={n} {g1} {g2} {prec}')
+
+
 def test_error_paths(gpu, engines):
     from imagematching_oetr_amd import OetrError
     eng = engines(0, False)
