@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) kvB[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      constexpr int KVR = 4;  // tiles per round trip (16*NT float4 loads per lane in flight)
+      constexpr int KVR = NT == 1 ? 7 : 4;  // tiles per round trip (28 / 32 float4 per lane in flight)
       const f32x4* kvp = reinterpret_cast<const f32x4*>(p.kv_in) +
                          ((size_t)src_slot0 * NH + NT * wave) * 256 + lane;
       const float* ksp = p.ks_in + (size_t)src_slot0 * C + (tid & (C - 1));
