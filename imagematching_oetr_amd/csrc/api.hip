@@ -102,10 +102,11 @@ struct Packer {
 }  // namespace
 
 enum KernelId { K_PREP, K_ENC_A, K_ENC_BA, K_ENC_BDEC, K_ENC_B, K_DECODER, K_HEAT_CONV,
-                K_HEAT_FINAL, K_SIZE_REG, K_BOXES, K_COUNT };
+                K_HEAT_FINAL, K_SIZE_REG, K_BOXES, K_DEC_CONVP, K_HEAT_COMBINE, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {
     "k_prep_tokens", "k_encoder<A>", "k_encoder<B,A>", "k_encoder<B,dec>", "k_encoder<B>",
-    "k_decoder", "k_heat_conv", "k_heat_final", "k_size_reg", "k_boxes"};
+    "k_decoder", "k_heat_conv", "k_heat_final", "k_size_reg", "k_boxes", "k_decoder_convp",
+    "k_heat_combine"};
 
 struct oetr_trace {
   std::vector<hipEvent_t> ev;  // 2 per launch
@@ -136,7 +137,7 @@ long long* g_tbuf = nullptr;
 
 struct Workspace {
   float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
-      *logits, *cxy, *tlbr;
+      *logits, *cxy, *tlbr, *convp;
   size_t bytes;
 };
 
@@ -178,6 +179,7 @@ Workspace carve(const Geom& g, void* base) {
   w.logits = take(rows);
   w.cxy = take((size_t)2 * g.N * 2);
   w.tlbr = take((size_t)2 * g.N * 4);
+  w.convp = take((size_t)9 * rows * C);  // P_tap = W_tap . memory (forward path)
   w.bytes = off;
   return w;
 }
@@ -231,9 +233,23 @@ struct Scoped {
   } while (0)
 
 // Encoder (+ decoder) shared by forward and feature_correlation.
+DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w) {
+  DecLaunch d;
+  d.g = g;
+  for (int i = 0; i < 2; ++i) { d.layer[i] = h->dec[i]; d.qe[i] = h->qe[i]; }
+  d.tgt1 = h->dec_tgt1; d.qkv1 = h->dec_qkv1;
+  d.att0_part = w.att0; d.z0_part = w.z0; d.dkv1 = w.dkv1; d.dks1 = w.dks1;
+  d.hs = w.hs;
+  d.tbuf = nullptr;
+#ifdef OETR_PHASE_TIMING
+  d.tbuf = g_tbuf ? g_tbuf + 16 * 4096 : nullptr;
+#endif
+  return d;
+}
+
 oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, const float* feat1,
                             const float* feat2, const float* pos1, const float* pos2,
-                            int enc_layers, hipStream_t s) {
+                            int enc_layers, hipStream_t s, bool with_decoder = true) {
   TRACED(h, s, K_PREP, launch_prep_tokens(g, feat1, feat2, pos1, pos2, w.x, w.pos, s));
   EncLaunch p;
   memset(&p, 0, sizeof(p));
@@ -273,17 +289,8 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
     TRACED(h, s, tail == 0 ? K_ENC_BA : tail == 1 ? K_ENC_BDEC : K_ENC_B,
            launch_encoder(p, true, tail, h->split, s));
   }
-  if (enc_layers == OETR_N_ENC) {
-    DecLaunch d;
-    d.g = g;
-    for (int i = 0; i < 2; ++i) { d.layer[i] = h->dec[i]; d.qe[i] = h->qe[i]; }
-    d.tgt1 = h->dec_tgt1; d.qkv1 = h->dec_qkv1;
-    d.att0_part = w.att0; d.z0_part = w.z0; d.dkv1 = w.dkv1; d.dks1 = w.dks1;
-    d.hs = w.hs;
-    d.tbuf = nullptr;
-#ifdef OETR_PHASE_TIMING
-    d.tbuf = g_tbuf ? g_tbuf + 16 * 4096 : nullptr;
-#endif
+  if (enc_layers == OETR_N_ENC && with_decoder) {
+    DecLaunch d = dec_launch(h, g, w);
     TRACED(h, s, K_DECODER, launch_decoder(d, s));
   }
   return OETR_OK;
@@ -510,7 +517,7 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
   oetr_status rc = check_ws(g, workspace, workspace_bytes, &w);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, enc_layers, s);
+  rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, enc_layers, s, /*with_decoder=*/false);
   if (rc) return rc;
   const size_t r1 = (size_t)g.N * g.L[0], r2 = (size_t)g.N * g.L[1];
   if (st) {
@@ -528,7 +535,9 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
   hp.tlbr[0] = tl1; hp.tlbr[1] = tl2;
   hp.box[0] = box1; hp.box[1] = box2;
   hp.img_w[0] = img_w1; hp.img_w[1] = img_w2;
-  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, h->split, s));
+  // decoder || P_tap = W_tap.memory in one launch, then the att-weighted combine
+  TRACED(h, s, K_DEC_CONVP, launch_decoder_convp(dec_launch(h, g, w), hp, w.convp, h->split, s));
+  TRACED(h, s, K_HEAT_COMBINE, launch_heat_combine(hp, w.convp, s));
   TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));  // + size regression + boxes
   if (st) {
     if ((rc = copy_out(st->hs1, hs1, (size_t)g.N * C, s))) return rc;

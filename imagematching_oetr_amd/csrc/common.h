@@ -541,6 +541,13 @@ struct HeatLaunch {
   int img_w[2];
 };
 hipError_t launch_heat_conv(const HeatLaunch& p, bool split, hipStream_t s);
+// Forward path: decoder (2N workgroups) and the hs-independent part of the heat-map
+// conv, P_tap = W_tap . memory (one workgroup per token tile), in ONE launch so that
+// the 16-CU decoder runs beside the conv GEMMs; then the cheap combine
+// conv_out[l] = b + sum_tap att[l+tap] * P_tap[l+tap].
+hipError_t launch_decoder_convp(const DecLaunch& d, const HeatLaunch& h, float* P, bool split,
+                                hipStream_t s);
+hipError_t launch_heat_combine(const HeatLaunch& h, const float* P, hipStream_t s);
 hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s);
 hipError_t launch_size_regression(const HeadsDev& w, const float* hs1, const float* hs2,
                                   int n, float* tlbr1, float* tlbr2, hipStream_t s);

@@ -1,0 +1,57 @@
+// P_tap = W_tap . memory for one 32-token tile (device body, 512 threads): the
+// hs-independent part of the heat-map 3x3 conv (reference src/model.py:65-77,
+// :152-164).  conv(memory * att)[l] = b + sum_tap att[l+tap] * P_tap[l+tap]
+// because att is a per-token scalar; the combine is k_heat_combine (heads.hip).
+#pragma once
+#include "common.h"
+
+namespace oetr {
+
+template <bool SPLIT>
+__device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restrict__ P, int tile,
+                                            float* smem) {
+  constexpr int NW = 8, NT = 1, THREADS = 64 * NW, WC = 32 * NT;
+  constexpr int TPR = THREADS / TM, F4 = 64 / TPR;
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int col = lane & 31;
+  const int logical = xcd_remap(tile, g.ntiles);
+  const int per = g.nt[0] + g.nt[1];
+  const int n = logical / per;
+  const int rem = logical - n * per;
+  const int side = rem >= g.nt[0];
+  const int t_idx = side ? rem - g.nt[0] : rem;
+  const int L = g.L[side];
+  const int l0 = t_idx * TM;
+  const int nvalid = min(TM, L - l0);
+  const float* mem = p.mem[side] + ((size_t)n * L + l0) * C;
+  const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
+
+  // the tile's own rows, once (rows past the image end re-read the last valid row)
+  const ATile<SPLIT> A(smem, LDA, LDAH);
+  {
+    const int r = tid / TPR, part = tid % TPR;
+    const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)min(r, nvalid - 1) * C) + part;
+#pragma unroll
+    for (int i = 0; i < F4; ++i) A.put4(r, 4 * (i * TPR + part), mp[i * TPR]);
+  }
+  __syncthreads();
+  constexpr size_t TAP_UNITS = SPLIT ? (size_t)C * C / 8 : (size_t)C * C / 4;
+  for (int tap = 0; tap < 9; ++tap) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+    A.template gemm<C, NT>(p.w.conv_w + tap * TAP_UNITS, p.w.conv_w_l + tap * TAP_UNITS, NT * wave,
+                           lane, acc, 0);
+    float* dst = P + ((size_t)tap * g.rows + row_base) * C + WC * wave + col;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        if (row < nvalid) dst[(size_t)row * C + 32 * t] = acc[t][r];
+      }
+  }
+}
+
+}  // namespace oetr

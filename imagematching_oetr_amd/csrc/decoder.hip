@@ -21,10 +21,11 @@
 //    flight (weights stored transposed [in][out]: every wave-load is 1 KiB
 //    contiguous, 16 independent float4 loads per thread).
 #include "common.h"
+#include "conv_p.h"
 
 namespace oetr {
 
-constexpr int DEC_THREADS = 1024;
+constexpr int DEC_THREADS = 1024;  // create-time constants kernel
 
 // part[kc][NOUT] = sum over this thread's k-chunk of x[k] * Wt[k][NOUT]; the
 // caller syncs and then sums the KCH partials.
@@ -150,53 +151,82 @@ hipError_t launch_decoder_consts(const DecConstLaunch& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// Software-pipelined GEMV chain: a stage's weights are consumed in batches of 16
-// float4 per thread (64 VGPRs); as soon as a batch has been multiplied in, the
-// NEXT batch (of this or the following stage - weights do not depend on data) is
-// issued into the same registers, so its L2 round trip runs under the current
-// stage's partial-sum exchange, barriers and LayerNorm.
-template <int K, int NOUT>
+// Software-pipelined GEMV chain, T threads per image.  A stage's weights are
+// consumed in batches of 16 float4 per thread (64 VGPRs); as soon as a batch has
+// been multiplied in, the NEXT batch (of this or the following stage - weights
+// do not depend on data) is issued into the same registers, so its L2 round trip
+// runs under the current stage's partial-sum exchange, barriers and LayerNorm.
+template <int T, int K, int NOUT>
 struct GemvShape {
   static constexpr int NO4 = NOUT / 4;
-  static constexpr int KCH = DEC_THREADS / NO4;  // k-chunks (threads per output float4)
-  static constexpr int KPER = K / KCH;           // k rows per thread
-  static constexpr int NB = KPER / 16;           // batches of 16 rows
-  static_assert(KPER % 16 == 0, "batching");
+  static constexpr int KCH = T / NO4;   // k-chunks (threads per output float4)
+  static constexpr int KPER = K / KCH;  // k rows per thread
+  static constexpr int NB = KPER / 16;  // batches of 16 rows
+  static_assert(KPER % 16 == 0 && KCH * NOUT == 4 * T, "batching");
 };
-template <int K, int NOUT, int B>
+template <int T, int K, int NOUT, int B>
 __device__ __forceinline__ void gemv_issue(const float* __restrict__ Wt, int tid, f32x4 (&wv)[16]) {
-  using S = GemvShape<K, NOUT>;
+  using S = GemvShape<T, K, NOUT>;
   const int kc = tid / S::NO4, o4 = tid % S::NO4;
   const f32x4* w = reinterpret_cast<const f32x4*>(Wt) + (size_t)(kc * S::KPER + B * 16) * S::NO4 + o4;
 #pragma unroll
   for (int i = 0; i < 16; ++i) wv[i] = w[(size_t)i * S::NO4];
   __builtin_amdgcn_sched_barrier(0);  // keep the loads here
 }
-template <int K, int NOUT, int B>
-__device__ __forceinline__ void gemv_fma(const f32x4 (&wv)[16], const float* x_s, int tid, f32x4& acc) {
-  using S = GemvShape<K, NOUT>;
+// All batches of one stage: FMA batch B, then issue batch B+1 - or, after the last
+// one, whatever `next` issues (the first batch of the following stage).
+template <int T, int K, int NOUT, int B = 0, class Next>
+__device__ __forceinline__ void gemv_stage(const float* __restrict__ Wt, const float* x_s, int tid,
+                                           f32x4 (&wv)[16], f32x4& acc, Next next) {
+  using S = GemvShape<T, K, NOUT>;
   const int kc = tid / S::NO4;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc += wv[i] * x_s[kc * S::KPER + B * 16 + i];
+  if constexpr (B + 1 < S::NB) {
+    gemv_issue<T, K, NOUT, B + 1>(Wt, tid, wv);
+    gemv_stage<T, K, NOUT, B + 1>(Wt, x_s, tid, wv, acc, next);
+  } else {
+    next();
+  }
 }
-template <int K, int NOUT>
+// partial sums -> LDS [KCH][NOUT]; collect = sum over the KCH chunks
+template <int T, int K, int NOUT>
 __device__ __forceinline__ void gemv_put(const f32x4& acc, float* part_s, int tid) {
-  using S = GemvShape<K, NOUT>;
+  using S = GemvShape<T, K, NOUT>;
   *reinterpret_cast<f32x4*>(part_s + (tid / S::NO4) * NOUT + 4 * (tid % S::NO4)) = acc;
 }
+template <int T, int K, int NOUT>
+__device__ __forceinline__ float gemv_get(const float* part_s, int o) {
+  using S = GemvShape<T, K, NOUT>;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < S::KCH; ++c) s += part_s[c * NOUT + o];
+  return s;
+}
 
-__global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
-  __shared__ __attribute__((aligned(16))) float kv_s[KV_FLOATS];  // [h][d][v], layer 1
-  __shared__ __attribute__((aligned(16))) float part_s[3 * 4096];
-  __shared__ __attribute__((aligned(16))) float vec_s[8][C];
-  __shared__ __attribute__((aligned(16))) float qkv_s[3 * C];
-  __shared__ __attribute__((aligned(16))) float hdn_s[FF];
-  float *tgt = vec_s[0], *t2 = vec_s[1], *qk = vec_s[2], *vq = vec_s[3], *att = vec_s[4],
-        *qe = vec_s[6], *ksum = vec_s[7];
+// LDS of one decoder workgroup (floats)
+template <int T>
+struct DecSmem {
+  static constexpr int PART = 4 * T;  // one partial-sum buffer
+  static constexpr int KV = 0, PARTS = KV + KV_FLOATS, VEC = PARTS + 3 * PART,
+                       QKV = VEC + 8 * C, HDN = QKV + 3 * C, TOTAL = HDN + FF;
+};
+
+// The whole decoder for image `img` (both layers); see the file header.
+template <int T>
+__device__ __forceinline__ void decoder_body(const DecLaunch& p, int img, float* smem) {
+  using M = DecSmem<T>;
+  float* kv_s = smem + M::KV;  // [h][d][v], layer 1
+  float* part_s = smem + M::PARTS;
+  float* vec = smem + M::VEC;
+  float* qkv_s = smem + M::QKV;
+  float* hdn_s = smem + M::HDN;
+  float *tgt = vec, *t2 = vec + C, *qk = vec + 2 * C, *vq = vec + 3 * C, *att = vec + 4 * C,
+        *qe = vec + 6 * C, *ksum = vec + 7 * C;
+  constexpr int PART = M::PART;
 
   const Geom& g = p.g;
   const int tid = threadIdx.x;
-  const int img = blockIdx.x;
   const int side = img >= g.N, n = side ? img - g.N : img;
   const int L = g.L[side], nts = g.nt[side];
   const int slot0 = g.tile0[side] + n * nts;
@@ -206,39 +236,46 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
 
   f32x4 wv[16];
   f32x4 acc;
-  gemv_issue<C, C, 0>(w0.cross.wm_t, tid, wv);  // stage 1 weights, under the state reduction
+  gemv_issue<T, C, C, 0>(w0.cross.wm_t, tid, wv);  // stage 1 weights, under the state reduction
   PHASE_STAMP(p, 0);
 
   // ---- reduce the tile partials of this image in one pass (4 tiles in flight per
   // round trip): layer 1 memory state -> LDS, layer 0 partial messages -> att
   {
+    constexpr int NE = (KV_FLOATS / 4) / T;  // float4 of the state per thread
     const f32x4* src = reinterpret_cast<const f32x4*>(p.dkv1) + (size_t)slot0 * (KV_FLOATS / 4) + tid;
     const int c = tid & (C - 1), hh = c >> 5;
-    f32x4 s0 = zero4, s1 = zero4;
+    f32x4 sacc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) sacc[e] = zero4;
     float ks = 0.f, a0 = 0.f, z0 = 0.f;
     for (int ti0 = 0; ti0 < nts; ti0 += 4) {
-      f32x4 a[4], b[4];
+      f32x4 a[4][NE];
       float kt[4], av[4], zv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t ti = min(ti0 + u, nts - 1);
-        a[u] = src[ti * (KV_FLOATS / 4)];
-        b[u] = src[ti * (KV_FLOATS / 4) + DEC_THREADS];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) a[u][e] = src[ti * (KV_FLOATS / 4) + e * T];
         kt[u] = p.dks1[(slot0 + ti) * C + c];
         av[u] = p.att0_part[(slot0 + ti) * C + c];
         zv[u] = p.z0_part[(slot0 + ti) * NH + hh];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (ti0 + u < nts) { s0 += a[u]; s1 += b[u]; ks += kt[u]; a0 += av[u]; z0 += zv[u]; }
+        if (ti0 + u < nts) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) sacc[e] += a[u][e];
+          ks += kt[u]; a0 += av[u]; z0 += zv[u];
+        }
     }
 #pragma unroll
-    for (int e2 = 0; e2 < 2; ++e2) {
-      const int e = tid + DEC_THREADS * e2;  // ((h*4+q)*64 + lane)
-      const f32x4 s = e2 ? s1 : s0;
+    for (int e2 = 0; e2 < NE; ++e2) {
+      const int e = tid + T * e2;  // ((h*4+q)*64 + lane)
       const int ln = e & 63, q = (e >> 6) & 3, h = e >> 8;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) kv_s[(h * HD + (j + 8 * q + 4 * (ln >> 5))) * HD + (ln & 31)] = s[j];
+      for (int j = 0; j < 4; ++j)
+        kv_s[(h * HD + (j + 8 * q + 4 * (ln >> 5))) * HD + (ln & 31)] = sacc[e2][j];
     }
     if (tid < C) {
       ksum[tid] = ks;
@@ -252,91 +289,84 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   PHASE_STAMP(p, 1);
   // S1: tgt += Wm_c0 . att0
   acc = zero4;
-  gemv_fma<C, C, 0>(wv, att, tid, acc);
-  gemv_issue<C, FF, 0>(w0.w1_t, tid, wv);
-  gemv_put<C, C>(acc, part_s, tid);
+  gemv_stage<T, C, C>(w0.cross.wm_t, att, tid, wv, acc, [&] { gemv_issue<T, C, FF, 0>(w0.w1_t, tid, wv); });
+  gemv_put<T, C, C>(acc, part_s, tid);
   __syncthreads();
-  if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
+  if (tid < C) tgt[tid] += gemv_get<T, C, C>(part_s, tid);
   __syncthreads();
   PHASE_STAMP(p, 2);
   // S2: hdn = relu(W1_0 . LN3(tgt))
   ln_vec(tgt, w0.n3w, w0.n3b, t2, nullptr, nullptr, tid);
   acc = zero4;
-  gemv_fma<C, FF, 0>(wv, t2, tid, acc);
-  gemv_issue<C, FF, 1>(w0.w1_t, tid, wv);
-  gemv_fma<C, FF, 1>(wv, t2, tid, acc);
-  gemv_issue<FF, C, 0>(w0.w2_t, tid, wv);
-  gemv_put<C, FF>(acc, part_s, tid);
+  gemv_stage<T, C, FF>(w0.w1_t, t2, tid, wv, acc, [&] { gemv_issue<T, FF, C, 0>(w0.w2_t, tid, wv); });
+  gemv_put<T, C, FF>(acc, part_s, tid);
   __syncthreads();
-  if (tid < FF) hdn_s[tid] = fmaxf(gemv_collect<C, FF>(part_s, tid), 0.f);
+  for (int o = tid; o < FF; o += T) hdn_s[o] = fmaxf(gemv_get<T, C, FF>(part_s, o), 0.f);
   __syncthreads();
   PHASE_STAMP(p, 3);
   // S3: tgt += W2_0 . hdn
   acc = zero4;
-  gemv_fma<FF, C, 0>(wv, hdn_s, tid, acc);
-  gemv_issue<FF, C, 1>(w0.w2_t, tid, wv);
-  gemv_fma<FF, C, 1>(wv, hdn_s, tid, acc);
-  gemv_issue<C, C, 0>(w1.self_attn.wq_t, tid, wv);
-  gemv_put<FF, C>(acc, part_s, tid);
+  gemv_stage<T, FF, C>(w0.w2_t, hdn_s, tid, wv, acc,
+                       [&] { gemv_issue<T, C, C, 0>(w1.self_attn.wq_t, tid, wv); });
+  gemv_put<T, FF, C>(acc, part_s, tid);
   __syncthreads();
-  if (tid < C) tgt[tid] += gemv_collect<FF, C>(part_s, tid);
+  if (tid < C) tgt[tid] += gemv_get<T, FF, C>(part_s, tid);
   __syncthreads();
 
   PHASE_STAMP(p, 4);
   // S4: layer 1 self-attention: fused q|k|v from LN1(tgt)
   ln_vec(tgt, w1.n1w, w1.n1b, t2, nullptr, nullptr, tid);
   acc = zero4;
-  gemv_fma<C, C, 0>(wv, t2, tid, acc);
-  gemv_issue<C, C, 0>(w1.self_attn.wk_t, tid, wv);
-  gemv_put<C, C>(acc, part_s, tid);
+  gemv_stage<T, C, C>(w1.self_attn.wq_t, t2, tid, wv, acc,
+                      [&] { gemv_issue<T, C, C, 0>(w1.self_attn.wk_t, tid, wv); });
+  gemv_put<T, C, C>(acc, part_s, tid);
   acc = zero4;
-  gemv_fma<C, C, 0>(wv, t2, tid, acc);
-  gemv_issue<C, C, 0>(w1.self_attn.wv_t, tid, wv);
-  gemv_put<C, C>(acc, part_s + 4096, tid);
+  gemv_stage<T, C, C>(w1.self_attn.wk_t, t2, tid, wv, acc,
+                      [&] { gemv_issue<T, C, C, 0>(w1.self_attn.wv_t, tid, wv); });
+  gemv_put<T, C, C>(acc, part_s + PART, tid);
   acc = zero4;
-  gemv_fma<C, C, 0>(wv, t2, tid, acc);
-  gemv_issue<C, C, 0>(w1.self_attn.wm_t, tid, wv);
-  gemv_put<C, C>(acc, part_s + 8192, tid);
+  gemv_stage<T, C, C>(w1.self_attn.wv_t, t2, tid, wv, acc,
+                      [&] { gemv_issue<T, C, C, 0>(w1.self_attn.wm_t, tid, wv); });
+  gemv_put<T, C, C>(acc, part_s + 2 * PART, tid);
   __syncthreads();
-  if (tid < 3 * C) {
-    const int m = tid >> 8, o = tid & (C - 1);
-    qkv_s[tid] = gemv_collect<C, C>(part_s + 4096 * m, o) + p.qkv1[side * 3 * C + tid];
+  for (int i = tid; i < 3 * C; i += T) {
+    const int m = i >> 8, o = i & (C - 1);
+    const float v = gemv_get<T, C, C>(part_s + PART * m, o) + p.qkv1[side * 3 * C + i];
+    qkv_s[i] = m < 2 ? elu1(v) : v;  // phi(q), phi(k) once per element; v as is
   }
-  __syncthreads();
-  if (tid < 2 * C) qkv_s[tid] = elu1(qkv_s[tid]);  // phi(q), phi(k) once per element
   __syncthreads();
   if (tid < C) {
     // L = S = 1 linear attention (values / v_length with v_length = 1)
     const int h = tid >> 5;
     const float vval = qkv_s[2 * C + tid] / 1.0f;
-    float z = 0.f, sacc = 0.f;
+    float z = 0.f, sa = 0.f;
 #pragma unroll 8
     for (int d = 0; d < HD; ++d) {
       const float fq = qkv_s[h * HD + d], fk = qkv_s[C + h * HD + d];
       z += fq * fk;
-      sacc += fq * (fk * vval);
+      sa += fq * (fk * vval);
     }
-    att[tid] = sacc * (1.0f / (z + ATTN_EPS)) * 1.0f;
+    att[tid] = sa * (1.0f / (z + ATTN_EPS)) * 1.0f;
   }
   __syncthreads();
   PHASE_STAMP(p, 5);
   // S5: tgt += Wm_s1 . att
   acc = zero4;
-  gemv_fma<C, C, 0>(wv, att, tid, acc);
-  gemv_issue<C, C, 0>(w1.cross.wq_t, tid, wv);
-  gemv_put<C, C>(acc, part_s, tid);
+  gemv_stage<T, C, C>(w1.self_attn.wm_t, att, tid, wv, acc,
+                      [&] { gemv_issue<T, C, C, 0>(w1.cross.wq_t, tid, wv); });
+  gemv_put<T, C, C>(acc, part_s, tid);
   __syncthreads();
-  if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
+  if (tid < C) tgt[tid] += gemv_get<T, C, C>(part_s, tid);
   __syncthreads();
   PHASE_STAMP(p, 6);
   // S6: layer 1 cross-attention query
   ln_vec(tgt, w1.n2w, w1.n2b, t2, qe, qk, tid);
   acc = zero4;
-  gemv_fma<C, C, 0>(wv, qk, tid, acc);
-  gemv_issue<C, C, 0>(w1.cross.wm_t, tid, wv);
-  gemv_put<C, C>(acc, part_s, tid);
+  gemv_stage<T, C, C>(w1.cross.wq_t, qk, tid, wv, acc,
+                      [&] { gemv_issue<T, C, C, 0>(w1.cross.wm_t, tid, wv); });
+  gemv_put<T, C, C>(acc, part_s, tid);
   __syncthreads();
-  if (tid < C) vq[tid] = elu1(gemv_collect<C, C>(part_s, tid) + w1.cross.bq[tid]);
+  if (tid < C) vq[tid] = elu1(gemv_get<T, C, C>(part_s, tid) + w1.cross.bq[tid]);
   __syncthreads();
   if (tid < C) {
     const int h = tid >> 5, v = tid & 31;
@@ -353,36 +383,59 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decoder(DecLaunch p) {
   PHASE_STAMP(p, 7);
   // S7: tgt += Wm_c1 . att
   acc = zero4;
-  gemv_fma<C, C, 0>(wv, att, tid, acc);
-  gemv_issue<C, FF, 0>(w1.w1_t, tid, wv);
-  gemv_put<C, C>(acc, part_s, tid);
+  gemv_stage<T, C, C>(w1.cross.wm_t, att, tid, wv, acc, [&] { gemv_issue<T, C, FF, 0>(w1.w1_t, tid, wv); });
+  gemv_put<T, C, C>(acc, part_s, tid);
   __syncthreads();
-  if (tid < C) tgt[tid] += gemv_collect<C, C>(part_s, tid);
+  if (tid < C) tgt[tid] += gemv_get<T, C, C>(part_s, tid);
   __syncthreads();
   PHASE_STAMP(p, 8);
   // S8/S9: ReLU MLP
   ln_vec(tgt, w1.n3w, w1.n3b, t2, nullptr, nullptr, tid);
   acc = zero4;
-  gemv_fma<C, FF, 0>(wv, t2, tid, acc);
-  gemv_issue<C, FF, 1>(w1.w1_t, tid, wv);
-  gemv_fma<C, FF, 1>(wv, t2, tid, acc);
-  gemv_issue<FF, C, 0>(w1.w2_t, tid, wv);
-  gemv_put<C, FF>(acc, part_s, tid);
+  gemv_stage<T, C, FF>(w1.w1_t, t2, tid, wv, acc, [&] { gemv_issue<T, FF, C, 0>(w1.w2_t, tid, wv); });
+  gemv_put<T, C, FF>(acc, part_s, tid);
   __syncthreads();
-  if (tid < FF) hdn_s[tid] = fmaxf(gemv_collect<C, FF>(part_s, tid), 0.f);
+  for (int o = tid; o < FF; o += T) hdn_s[o] = fmaxf(gemv_get<T, C, FF>(part_s, o), 0.f);
   __syncthreads();
   acc = zero4;
-  gemv_fma<FF, C, 0>(wv, hdn_s, tid, acc);
-  gemv_issue<FF, C, 1>(w1.w2_t, tid, wv);
-  gemv_fma<FF, C, 1>(wv, hdn_s, tid, acc);
-  gemv_put<FF, C>(acc, part_s, tid);
+  gemv_stage<T, FF, C>(w1.w2_t, hdn_s, tid, wv, acc, [] {});
+  gemv_put<T, FF, C>(acc, part_s, tid);
   __syncthreads();
-  if (tid < C) p.hs[(size_t)img * C + tid] = tgt[tid] + gemv_collect<FF, C>(part_s, tid);
+  if (tid < C) p.hs[(size_t)img * C + tid] = tgt[tid] + gemv_get<T, FF, C>(part_s, tid);
   PHASE_STAMP(p, 9);
 }
 
+#ifndef OETR_DEC_THREADS
+#define OETR_DEC_THREADS 512   // measured equal to 1024 (the chain is L1-rate bound)
+#endif
+template <int T>
+__global__ __launch_bounds__(T) void k_decoder(DecLaunch p) {
+  __shared__ __attribute__((aligned(16))) float smem[DecSmem<T>::TOTAL];
+  decoder_body<T>(p, blockIdx.x, smem);
+}
+
 hipError_t launch_decoder(const DecLaunch& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_decoder, dim3(2 * p.g.N), dim3(DEC_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_decoder<OETR_DEC_THREADS>, dim3(2 * p.g.N), dim3(OETR_DEC_THREADS), 0, s, p);
+  return hipGetLastError();
+}
+
+// Decoder (blocks [0, 2N)) and conv P tiles (blocks [2N, 2N + ntiles)) in one
+// launch: the decoder occupies 2N CUs for ~50 us while the P GEMMs fill the rest
+// of the chip; decoder blocks come first in the grid so they are dispatched first.
+template <bool SPLIT>
+__global__ __launch_bounds__(512) void k_decoder_convp(DecLaunch d, HeatLaunch h, float* P) {
+  constexpr int LDS_FLOATS = DecSmem<512>::TOTAL > TILE_FLOATS ? DecSmem<512>::TOTAL : TILE_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  const int nd = 2 * d.g.N;
+  if ((int)blockIdx.x < nd) decoder_body<512>(d, blockIdx.x, smem);
+  else conv_p_body<SPLIT>(h, P, blockIdx.x - nd, smem);
+}
+
+hipError_t launch_decoder_convp(const DecLaunch& d, const HeatLaunch& h, float* P, bool split,
+                                hipStream_t s) {
+  const dim3 grid(2 * d.g.N + d.g.ntiles);
+  if (split) hipLaunchKernelGGL(k_decoder_convp<true>, grid, dim3(512), 0, s, d, h, P);
+  else hipLaunchKernelGGL(k_decoder_convp<false>, grid, dim3(512), 0, s, d, h, P);
   return hipGetLastError();
 }
 

@@ -149,6 +149,112 @@ hipError_t launch_heat_conv(const HeatLaunch& p, bool split, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
+// conv_out[l] = b + sum_tap att[l+tap] * P_tap[l+tap]  (P from k_decoder_convp),
+// plus the per-tile GroupNorm moments.  512 threads, 16 per token row.
+__global__ __launch_bounds__(512) void k_heat_combine(HeatLaunch p, const float* __restrict__ P) {
+  constexpr int TPR = 16, F4 = 4;
+  __shared__ __attribute__((aligned(16))) float out_s[TM * LDA];
+  __shared__ float att_s[TM + 2 * (100 + 1) + 6];
+  const Geom& g = p.g;
+  const int tid = threadIdx.x;
+  const int logical = xcd_remap(blockIdx.x, g.ntiles);
+  const int per = g.nt[0] + g.nt[1];
+  const int n = logical / per;
+  const int rem = logical - n * per;
+  const int side = rem >= g.nt[0];
+  const int t_idx = side ? rem - g.nt[0] : rem;
+  const int L = g.L[side], hf = g.hf[side], wf = g.wf[side];
+  const int l0 = t_idx * TM;
+  const int nvalid = min(TM, L - l0);
+  const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
+  const float* mem = p.mem[side] + (size_t)n * L * C;
+  const size_t img_row0 = (size_t)g.row0[side] + (size_t)n * L;
+  const int halo0 = l0 - wf - 1, nhalo = TM + 2 * (wf + 1);
+  const int hrow = tid / TPR, hpart = tid % TPR;
+  {  // att for the halo rows
+    const f32x4* hsp = reinterpret_cast<const f32x4*>(p.hs[side] + (size_t)n * C) + hpart;
+    f32x4 hv[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) hv[i] = hsp[i * TPR];
+    for (int r0 = 0; r0 < nhalo; r0 += TM) {
+      const int hr = r0 + hrow;
+      const int l = min(max(halo0 + hr, 0), L - 1);
+      const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)l * C) + hpart;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < F4; ++i) {
+        const f32x4 v = mp[i * TPR];
+        d += (v[0] * hv[i][0] + v[1] * hv[i][1]) + (v[2] * hv[i][2] + v[3] * hv[i][3]);
+      }
+      d = sum8(d);
+      d += dpp_mov<0x140>(d);
+      if (hpart == 0 && hr < nhalo) att_s[hr] = d;
+    }
+  }
+  __syncthreads();
+  {
+    const int l = l0 + hrow;
+    const int y = l / wf, x = l - y * wf;
+    f32x4 acc[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) acc[i] = reinterpret_cast<const f32x4*>(p.w.conv_b)[i * TPR + hpart];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int yy = y + dy, xx = x + dx;
+      const bool ok = (l < L) && (yy >= 0) && (yy < hf) && (xx >= 0) && (xx < wf);
+      const int src_row = ok ? yy * wf + xx : 0;
+      const float att = ok ? att_s[src_row - halo0] : 0.f;
+      const f32x4* pp = reinterpret_cast<const f32x4*>(
+                            P + ((size_t)tap * g.rows + img_row0 + src_row) * C) + hpart;
+#pragma unroll
+      for (int i = 0; i < F4; ++i) acc[i] += pp[i * TPR] * att;
+    }
+    f32x4* go = reinterpret_cast<f32x4*>(p.conv_out + (img_row0 + min(l, L - 1)) * C) + hpart;
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+      if (l < L) go[i * TPR] = acc[i];
+      *reinterpret_cast<f32x4*>(out_s + hrow * LDA + 4 * (i * TPR + hpart)) = acc[i];
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {  // GroupNorm moments: group = tid >> 3, 8 threads x 4 rows each
+    const int grp = tid >> 3, rs = tid & 7;
+    float s = 0.f;
+    f32x4 v[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rs * 4 + r;
+      v[r][0] = *reinterpret_cast<const f32x4*>(out_s + row * LDA + 8 * grp);
+      v[r][1] = *reinterpret_cast<const f32x4*>(out_s + row * LDA + 8 * grp + 4);
+      if (row < nvalid)
+        s += ((v[r][0][0] + v[r][0][1]) + (v[r][0][2] + v[r][0][3])) +
+             ((v[r][1][0] + v[r][1][1]) + (v[r][1][2] + v[r][1][3]));
+    }
+    const float mean = sum8(s) / (float)(nvalid * 8);
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (rs * 4 + r < nvalid)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float d = v[r][k][j] - mean; m2 += d * d; }
+    m2 = sum8(m2);
+    if (rs == 0) {
+      float* dst = p.gn_part + ((size_t)slot * GN_GROUPS + grp) * 2;
+      dst[0] = mean;
+      dst[1] = m2;
+    }
+  }
+}
+
+hipError_t launch_heat_combine(const HeatLaunch& h, const float* P, hipStream_t s) {
+  hipLaunchKernelGGL(k_heat_combine, dim3(h.g.ntiles), dim3(512), 0, s, h, P);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 constexpr int FIN_THREADS = 1024;
 
 __device__ __forceinline__ float block_reduce(float v, float* red_s, int tid, bool is_max) {
