@@ -239,8 +239,8 @@ __device__ __forceinline__ void decoder_body(const DecLaunch& p, int img, float*
   gemv_issue<T, C, C, 0>(w0.cross.wm_t, tid, wv);  // stage 1 weights, under the state reduction
   PHASE_STAMP(p, 0);
 
-  // ---- reduce the tile partials of this image in one pass (4 tiles in flight per
-  // round trip): layer 1 memory state -> LDS, layer 0 partial messages -> att
+  // ---- reduce the tile partials of this image in one pass (several tiles in flight
+  // per round trip): layer 1 memory state -> LDS, layer 0 partial messages -> att
   {
     constexpr int NE = (KV_FLOATS / 4) / T;  // float4 of the state per thread
     const f32x4* src = reinterpret_cast<const f32x4*>(p.dkv1) + (size_t)slot0 * (KV_FLOATS / 4) + tid;
@@ -249,11 +249,12 @@ __device__ __forceinline__ void decoder_body(const DecLaunch& p, int img, float*
 #pragma unroll
     for (int e = 0; e < NE; ++e) sacc[e] = zero4;
     float ks = 0.f, a0 = 0.f, z0 = 0.f;
-    for (int ti0 = 0; ti0 < nts; ti0 += 4) {
-      f32x4 a[4][NE];
-      float kt[4], av[4], zv[4];
+    constexpr int R = T == 512 ? 7 : 4;  // tiles per round trip (R*NE float4 in flight per thread)
+    for (int ti0 = 0; ti0 < nts; ti0 += R) {
+      f32x4 a[R][NE];
+      float kt[R], av[R], zv[R];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < R; ++u) {
         const size_t ti = min(ti0 + u, nts - 1);
 #pragma unroll
         for (int e = 0; e < NE; ++e) a[u][e] = src[ti * (KV_FLOATS / 4) + e * T];
@@ -262,7 +263,7 @@ __device__ __forceinline__ void decoder_body(const DecLaunch& p, int img, float*
         zv[u] = p.z0_part[(slot0 + ti) * NH + hh];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < R; ++u)
         if (ti0 + u < nts) {
 #pragma unroll
           for (int e = 0; e < NE; ++e) sacc[e] += a[u][e];
