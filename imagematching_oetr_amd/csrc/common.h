@@ -441,6 +441,137 @@ struct ATile {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Weight stream of one wave across the GEMMs of a kernel.
+//
+// A GEMM that fetches its first B fragments when it is called starts with an
+// exposed L2 round trip (~2000 cycles under the all-workgroups-read-the-same-
+// lines load) and every isolated call pays it: 7 calls per B;A launch.  The
+// stream keeps a ring of D B-fragment chunks in registers that runs ACROSS
+// calls: while a GEMM consumes its last chunks it already fetches the first
+// PRE = D-1 chunks of the next GEMM's weights, so those are in flight during
+// the epilogue / LayerNorm / barrier between the two.  A fragments come from
+// LDS one chunk ahead.  P is the ring slot of a GEMM's chunk 0 (compile time);
+// adv(P, K) is the slot the following GEMM starts at.
+//
+// Generic form (exact-f32 mode, or a wave owning several n-tiles): no run-
+// ahead, plain calls.
+// ---------------------------------------------------------------------------
+#ifndef OETR_WSTREAM
+#define OETR_WSTREAM 1
+#endif
+#ifndef OETR_RING
+#define OETR_RING 3
+#endif
+template <bool SPLIT, int NT>
+struct WStream {
+  static constexpr int adv(int, int) { return 0; }
+  template <int K, int P>
+  __device__ __forceinline__ void prime(const f32x4*, const f32x4*, int, int) {}
+  template <int K, int P, int NK, class AT>
+  __device__ __forceinline__ void gemm(const AT& A, const f32x4* W, const f32x4* Wl, int nt0,
+                                       int lane, f32x16 (&acc)[NT], const f32x4*, const f32x4*,
+                                       int, int dbg) {
+    A.template gemm<K, NT>(W, Wl, nt0, lane, acc, dbg);
+  }
+};
+
+#if OETR_WSTREAM
+template <>
+struct WStream<true, 1> {
+  static constexpr int U = 2, D = OETR_RING, PRE = D - 1;
+  struct BChunk { f32x4 bh[U], bl[U]; };
+  struct AChunk { f32x4 ah[U], al[U]; };
+  BChunk ring[D];
+
+  static constexpr int adv(int P, int K) { return (P + K / 16 / U) % D; }
+
+  template <int SLOT>
+  __device__ __forceinline__ void fetch(const f32x4* wh, const f32x4* wl, int chunk) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ring[SLOT].bh[u] = wh[(chunk * U + u) * 64];
+      ring[SLOT].bl[u] = wl[(chunk * U + u) * 64];
+    }
+  }
+  template <int P, int J>
+  __device__ __forceinline__ void fetch_first(const f32x4* wh, const f32x4* wl) {
+    if constexpr (J < PRE) {
+      fetch<(P + J) % D>(wh, wl, J);
+      fetch_first<P, J + 1>(wh, wl);
+    }
+  }
+  // Issue the first PRE chunks of a GEMM's weights (K = its reduction length).
+  template <int K, int P>
+  __device__ __forceinline__ void prime(const f32x4* W, const f32x4* Wl, int nt0, int lane) {
+    const size_t off = (size_t)nt0 * (K / 16) * 64 + lane;
+    fetch_first<P, 0>(W + off, Wl + off);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  template <int K, int P, int NK, int CI>
+  __device__ __forceinline__ void step(const _Float16* ah_ptr, const _Float16* al_ptr,
+                                       const f32x4* wh, const f32x4* wl, const f32x4* nwh,
+                                       const f32x4* nwl, AChunk (&a)[2], f32x16& acc,
+                                       f32x16& cross, f32x16& cross2) {
+    constexpr int NCH = K / 16 / U;
+    if constexpr (CI < NCH) {
+      constexpr int PF = CI + PRE;
+      if constexpr (PF < NCH) fetch<(P + PF) % D>(wh, wl, PF);
+      else if constexpr (NK != 0) fetch<(P + PF) % D>(nwh, nwl, PF - NCH);
+      if constexpr (CI + 1 < NCH) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          a[(CI + 1) & 1].ah[u] = *reinterpret_cast<const f32x4*>(ah_ptr + ((CI + 1) * U + u) * 16);
+          a[(CI + 1) & 1].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + ((CI + 1) * U + u) * 16);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const BChunk& b = ring[(P + CI) % D];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, a[CI & 1].ah[u]);
+        const f16x8 al = __builtin_bit_cast(f16x8, a[CI & 1].al[u]);
+        const f16x8 bh = __builtin_bit_cast(f16x8, b.bh[u]);
+        const f16x8 bl = __builtin_bit_cast(f16x8, b.bl[u]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cross, 0, 0, 0);
+        cross2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cross2, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      step<K, P, NK, CI + 1>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross, cross2);
+    }
+  }
+
+  // acc += A . W^T for this wave's n-tile nt0; chunks 0..PRE-1 of W are already in
+  // the ring (prime<K,P> or the previous gemm's NK).  NK != 0: the next GEMM has
+  // reduction length NK and weights (nW, nWl, nnt0); its first chunks are fetched
+  // while this one finishes.
+  template <int K, int P, int NK, class AT>
+  __device__ __forceinline__ void gemm(const AT& A, const f32x4* W, const f32x4* Wl, int nt0,
+                                       int lane, f32x16 (&acc)[1], const f32x4* nW,
+                                       const f32x4* nWl, int nnt0, int) {
+    static_assert(PRE * U * 16 <= K && (NK == 0 || PRE * U * 16 <= NK), "ring deeper than a GEMM");
+    const size_t off = (size_t)nt0 * (K / 16) * 64 + lane;
+    const size_t noff = (size_t)nnt0 * ((NK ? NK : 16) / 16) * 64 + lane;
+    const int a_off = (lane & 31) * A.ldh + 8 * (lane >> 5);
+    const _Float16* ah_ptr = A.h + a_off;
+    const _Float16* al_ptr = A.l + a_off;
+    AChunk a[2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[0].ah[u] = *reinterpret_cast<const f32x4*>(ah_ptr + u * 16);
+      a[0].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + u * 16);
+    }
+    f32x16 cross = {0}, cross2 = {0};
+    step<K, P, NK, 0>(ah_ptr, al_ptr, W + off, Wl + off, NK ? nW + noff : nullptr,
+                      NK ? nWl + noff : nullptr, a, acc[0], cross, cross2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = fmaf(cross[r] + cross2[r], SPLIT_INV, acc[0][r]);
+  }
+};
+#endif  // OETR_WSTREAM
+
 #endif  // __HIPCC__
 
 // ------------------------------------------------------------------ host

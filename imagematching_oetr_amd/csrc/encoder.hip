@@ -24,6 +24,8 @@
 // 2w, 2w+1, so a head's 32x32 MFMA tile never leaves its wave: phi(K)^T V is
 // computed straight from the K and V accumulators, and the reduced KV state
 // is consumed as an MFMA B operand in the register layout it was produced in.
+#include <type_traits>
+
 #include "common.h"
 
 namespace oetr {
@@ -94,7 +96,8 @@ constexpr int S1_OFF = S0_OFF + TM * LDA;
 constexpr int H_OFF = S1_OFF + TILE_FLOATS;  // hidden tile; S2 aliases its start
 constexpr int KSUM_OFF = H_OFF + HID_FLOATS;
 constexpr int Z_OFF = KSUM_OFF + C;
-constexpr int SMEM_FLOATS = Z_OFF + TM * NH;
+constexpr int LNP_OFF = Z_OFF + TM * NH;  // LayerNorm affines: ln2 w,b | lnq w,b | lnkv w,b
+constexpr int SMEM_FLOATS = LNP_OFF + 6 * C;
 
 // Workgroup shape: NW waves.  NW = 4 (one wave per SIMD) for the exact-f32
 // mode, where the MFMA pipe is the bound; NW = 8 (two per SIMD) for the split
@@ -214,6 +217,18 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   const ATile<SPLIT> Hh(smem + H_OFF, LDH, LDHH);
   float* ksum_s = smem + KSUM_OFF;
   float* z_s = smem + Z_OFF;
+  float* lnp_s = smem + LNP_OFF;
+  using WS = WStream<SPLIT, NT>;
+  WS ws;  // this wave's weight stream (runs ahead across the GEMMs below)
+  // ring slot of each GEMM's first chunk
+  constexpr int P_MERGE = 0;
+  constexpr int P_W1A = WS::adv(P_MERGE, C);
+  constexpr int P_W1B = WS::adv(P_W1A, C);
+  constexpr int P_W2 = WS::adv(P_W1B, C);
+  constexpr int P_T0 = HAS_B ? WS::adv(P_W2, FF) : 0;  // first GEMM of the tail
+  constexpr int P_T1 = WS::adv(P_T0, C);
+  constexpr int P_T2 = WS::adv(P_T1, C);
+  constexpr int P_T3 = WS::adv(P_T2, C);
 
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -233,6 +248,16 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   const int nvalid = min(TM, L - l0);
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
+
+  // LayerNorm affines -> LDS once (the row-wise phases then issue no global loads
+  // that would queue behind the weight stream's run-ahead fetches)
+  for (int i = tid; i < 6 * C; i += THREADS) {
+    const int which = i >> 8, c = i & (C - 1);
+    const float* src = which == 0 ? p.b.ln2_w : which == 1 ? p.b.ln2_b : which == 2 ? p.a.lnq_w
+                     : which == 3 ? p.a.lnq_b : which == 4 ? p.a.lnkv_w : p.a.lnkv_b;
+    const bool used = which < 2 ? HAS_B : TAIL == 0;
+    if (used) lnp_s[i] = src[c];
+  }
 
   f32x16 xacc[NT];  // residual stream of this wave's columns (C layout)
   PHASE_STAMP(p, 0);
@@ -287,6 +312,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       }
       if (THREADS == C || tid < C) ksum_s[tid] = ks;
     }
+    ws.template prime<C, P_MERGE>(p.b.wmerge, p.b.wmerge_l, NT * wave, lane);
     __syncthreads();
     PHASE_STAMP(p, 1);
 
@@ -335,7 +361,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     PHASE_STAMP(p, 2);
 
     // x1 = x + message . Wmerge^T
-    S1.template gemm<C, NT>(p.b.wmerge, p.b.wmerge_l, NT * wave, lane, xacc, p.dbg);
+    ws.template gemm<C, P_MERGE, C>(S1, p.b.wmerge, p.b.wmerge_l, NT * wave, lane, xacc, p.b.w1,
+                                    p.b.w1_l, 2 * NT * wave, p.dbg);
     acc_to_lds<NT>(S0, LDA, wcol, lane, xacc);
     __syncthreads();
     PHASE_STAMP(p, 3);
@@ -344,8 +371,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     {
       f32x4 xn[F4];
       ln_rows<TPR, F4>(S0, tid, xn, p.dbg);
-      const f32x4* gw = reinterpret_cast<const f32x4*>(p.b.ln2_w) + lpart;
-      const f32x4* gb = reinterpret_cast<const f32x4*>(p.b.ln2_b) + lpart;
+      const f32x4* gw = reinterpret_cast<const f32x4*>(lnp_s) + lpart;
+      const f32x4* gb = reinterpret_cast<const f32x4*>(lnp_s + C) + lpart;
 #pragma unroll
       for (int i = 0; i < F4; ++i)
         S1.put4(lrow, 4 * (i * TPR + lpart), xn[i] * gw[i * TPR] + gb[i * TPR]);
@@ -354,23 +381,34 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     PHASE_STAMP(p, 4);
 
     // hidden = gelu(LN2(x1) . W1^T) -> Hh   (wave w: hidden columns [2*WC*w, 2*WC*(w+1)))
-#pragma unroll
-    for (int cpart = 0; cpart < 2; ++cpart) {
+    {
       f32x16 hacc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) hacc[t] = f32x16{0};
-      S1.template gemm<C, NT>(p.b.w1, p.b.w1_l, 2 * NT * wave + NT * cpart, lane, hacc, p.dbg);
+      ws.template gemm<C, P_W1A, C>(S1, p.b.w1, p.b.w1_l, 2 * NT * wave, lane, hacc, p.b.w1,
+                                    p.b.w1_l, 2 * NT * wave + NT, p.dbg);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[t][r] = ABL(p.dbg, ABL_GELU) ? hacc[t][r] : gelu_erf(hacc[t][r]);
-      Hh.template put_acc<NT>(2 * wcol + WC * cpart, lane, hacc);
+      Hh.template put_acc<NT>(2 * wcol, lane, hacc);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) hacc[t] = f32x16{0};
+      ws.template gemm<C, P_W1B, FF>(S1, p.b.w1, p.b.w1_l, 2 * NT * wave + NT, lane, hacc, p.b.w2,
+                                     p.b.w2_l, NT * wave, p.dbg);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[t][r] = ABL(p.dbg, ABL_GELU) ? hacc[t][r] : gelu_erf(hacc[t][r]);
+      Hh.template put_acc<NT>(2 * wcol + WC, lane, hacc);
     }
     __syncthreads();
     PHASE_STAMP(p, 5);
 
     // x2 = x1 + hidden . W2^T ; write back
-    Hh.template gemm<FF, NT>(p.b.w2, p.b.w2_l, NT * wave, lane, xacc, p.dbg);
+    ws.template gemm<FF, P_W2, (TAIL == 2 ? 0 : C)>(
+        Hh, p.b.w2, p.b.w2_l, NT * wave, lane, xacc, TAIL == 0 ? p.a.wq : p.d.wk[0],
+        TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], NT * wave, p.dbg);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -383,6 +421,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     PHASE_STAMP(p, 6);
   } else {
     load_tile<THREADS>(S0, p.x + row_base * C, nvalid, tid);  // first launch: x from HBM
+    if (TAIL == 0) ws.template prime<C, P_T0>(p.a.wq, p.a.wq_l, NT * wave, lane);
+    if (TAIL == 1) ws.template prime<C, P_T0>(p.d.wk[0], p.d.wk_l[0], NT * wave, lane);
     __syncthreads();
   }
 
@@ -394,10 +434,10 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     {
       f32x4 xn[F4];
       ln_rows<TPR, F4>(S0, tid, xn, p.dbg);
-      const f32x4* qw = reinterpret_cast<const f32x4*>(p.a.lnq_w) + lpart;
-      const f32x4* qb = reinterpret_cast<const f32x4*>(p.a.lnq_b) + lpart;
-      const f32x4* kw = reinterpret_cast<const f32x4*>(p.a.lnkv_w) + lpart;
-      const f32x4* kb = reinterpret_cast<const f32x4*>(p.a.lnkv_b) + lpart;
+      const f32x4* qw = reinterpret_cast<const f32x4*>(lnp_s + 2 * C) + lpart;
+      const f32x4* qb = reinterpret_cast<const f32x4*>(lnp_s + 3 * C) + lpart;
+      const f32x4* kw = reinterpret_cast<const f32x4*>(lnp_s + 4 * C) + lpart;
+      const f32x4* kb = reinterpret_cast<const f32x4*>(lnp_s + 5 * C) + lpart;
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
         const f32x4 ps = pos[i * TPR];
@@ -412,7 +452,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       f32x16 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
-      S1.template gemm<C, NT>(p.a.wq, p.a.wq_l, NT * wave, lane, acc, p.dbg);
+      ws.template gemm<C, P_T0, C>(S1, p.a.wq, p.a.wq_l, NT * wave, lane, acc, p.a.wk, p.a.wk_l,
+                                   NT * wave, p.dbg);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -426,8 +467,10 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     f32x16 accK[NT], accV[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { accK[t] = f32x16{0}; accV[t] = f32x16{0}; }
-    S2.template gemm<C, NT>(p.a.wk, p.a.wk_l, NT * wave, lane, accK, p.dbg);
-    S2.template gemm<C, NT>(p.a.wv, p.a.wv_l, NT * wave, lane, accV, p.dbg);
+    ws.template gemm<C, P_T1, C>(S2, p.a.wk, p.a.wk_l, NT * wave, lane, accK, p.a.wv, p.a.wv_l,
+                                 NT * wave, p.dbg);
+    ws.template gemm<C, P_T2, 0>(S2, p.a.wv, p.a.wv_l, NT * wave, lane, accV, nullptr, nullptr, 0,
+                                 p.dbg);
     PHASE_STAMP(p, 9);
     kv_state_store<NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 10);
@@ -444,20 +487,30 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       }
     }
     __syncthreads();
+    // biases first: a load issued after the stream's run-ahead fetches would wait for them
+    float bias_k[2][NT], bias_v[2][NT];
 #pragma unroll
-    for (int dl = 0; dl < 2; ++dl) {
-      f32x16 accK[NT], accV[NT];
+    for (int dl = 0; dl < 2; ++dl)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float bk = p.d.bk[dl][wcol + 32 * t + col];
-        const float bv = p.d.bv[dl][wcol + 32 * t + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accK[t][r] = bk; accV[t][r] = bv; }
+        bias_k[dl][t] = p.d.bk[dl][wcol + 32 * t + col];
+        bias_v[dl][t] = p.d.bv[dl][wcol + 32 * t + col];
       }
-      S1.template gemm<C, NT>(p.d.wk[dl], p.d.wk_l[dl], NT * wave, lane, accK, p.dbg);
-      if (SPLIT) S2.template gemm<C, NT>(p.d.wv[dl], p.d.wv_l[dl], NT * wave, lane, accV, p.dbg);
-      else gemm_rows32<C, NT>(S0, LDA, p.d.wv[dl], NT * wave, lane, accV, p.dbg);
-      if (dl == 1) {
+    const ATile<SPLIT> S0t(S0, LDA, LDAH);
+    const ATile<SPLIT>& Vin = SPLIT ? S2 : S0t;  // f32 mode reads the memory tile itself
+    auto dec_layer = [&](auto DL) {
+      constexpr int dl = decltype(DL)::value;
+      constexpr int PK = dl == 0 ? P_T0 : P_T2, PV = dl == 0 ? P_T1 : P_T3;
+      f32x16 accK[NT], accV[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accK[t][r] = bias_k[dl][t]; accV[t][r] = bias_v[dl][t]; }
+      ws.template gemm<C, PK, C>(S1, p.d.wk[dl], p.d.wk_l[dl], NT * wave, lane, accK, p.d.wv[dl],
+                                 p.d.wv_l[dl], NT * wave, p.dbg);
+      ws.template gemm<C, PV, (dl == 0 ? C : 0)>(Vin, p.d.wv[dl], p.d.wv_l[dl], NT * wave, lane,
+                                                 accV, p.d.wk[1], p.d.wk_l[1], NT * wave, p.dbg);
+      if constexpr (dl == 1) {
         kv_state_store<NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.dkv1_out,
                            p.dks1_out, slot);
       } else {
@@ -489,7 +542,9 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
           if (lane == 0) p.z0_out[(size_t)slot * NH + h] = z;
         }
       }
-    }
+    };
+    dec_layer(std::integral_constant<int, 0>{});
+    dec_layer(std::integral_constant<int, 1>{});
   }
 }
 
