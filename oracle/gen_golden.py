@@ -218,6 +218,37 @@ def gen_full(out_dir, model):
           float(f1.abs().max()))
 
 
+NECK_CASES = [
+    # tag, weight seed, feature seed, n images, (hb, wb) of the backbone output
+    ('s20_40x40', 20, 30, 2, (40, 40)),     # 640x640 image
+    ('s21_30x40', 21, 31, 1, (30, 40)),     # 480x640
+    ('s22_25x33', 22, 32, 3, (25, 33)),     # odd sizes: floor(h/2) outputs
+    ('s23_64x64', 23, 33, 1, (64, 64)),     # 1024x1024
+]
+
+
+@torch.no_grad()
+def gen_neck(out_dir, model):
+    """input_proj -> PatchMerging -> input_proj2 of the reference model
+    (src/model.py:113-118, backbone.py:53-67) on seeded backbone features."""
+    for (tag, wseed, fseed, n, (hb, wb)) in NECK_CASES:
+        w = orc.make_neck_weights(wseed)
+        missing, unexpected = model.load_state_dict(w, strict=False)
+        assert not unexpected, unexpected
+        bb = orc.make_backbone_features(fseed, n, hb, wb)
+        proj = model.input_proj(bb)
+        merged = model.patchmerging(proj)
+        feat = model.input_proj2(merged)
+        np.savez_compressed(
+            out_dir / f'neck_{tag}.npz', weight_seed=np.int64(wseed),
+            feat_seed=np.int64(fseed), n=np.int64(n), grid=np.asarray((hb, wb)),
+            bb_fp=fp(bb), weights_fp=fp(torch.cat([w[k].flatten() for k in sorted(w)])),
+            proj_sample=proj[:, :, ::5, ::7].contiguous().numpy(),
+            merged_sample=merged[:, :, ::3, ::4].contiguous().numpy(),
+            feat=feat.numpy())
+        print(f'neck_{tag}.npz feat {tuple(feat.shape)} absmax {float(feat.abs().max()):.3f}')
+
+
 def gen_misc(out_dir):
     """Position table window, box conversion and the reference's only
     known-answer vectors (bbox_overlaps docstring, src/losses/utils.py:31-53)."""
@@ -258,6 +289,7 @@ def main():
     model = build_reference_model()
     gen_hot(out_dir, model)
     gen_full(out_dir, model)
+    gen_neck(out_dir, model)
 
 
 if __name__ == '__main__':

@@ -132,6 +132,80 @@ def checksum(t):
 
 
 # --------------------------------------------------------------------------
+# neck: input_proj -> PatchMerging -> input_proj2   
+# --------------------------------------------------------------------------
+BACKBONE_C = 1024            # ResNet-50 layer3 channels (reference default.py LAST_LAYER)
+PATCH_SIZES = (4, 8, 16)     # reference model.py:51-55
+
+
+def neck_param_shapes():
+    """name -> shape of the neck tensors, reference state-dict key names
+    (src/model.py:44-56, src/models/backbone.py:27-51)."""
+    C = D_MODEL
+    s = {'input_proj.weight': (C, BACKBONE_C, 1, 1), 'input_proj.bias': (C,),
+         'patchmerging.norm.weight': (C,), 'patchmerging.norm.bias': (C,)}
+    for i, ps in enumerate(PATCH_SIZES):
+        # backbone.py:38-42: 2C/2^(i+1) channels, the last one 2C/2^i
+        out = 2 * C // 2 ** i if i == len(PATCH_SIZES) - 1 else 2 * C // 2 ** (i + 1)
+        s[f'patchmerging.reductions.{i}.weight'] = (out, C, ps, ps)
+        s[f'patchmerging.reductions.{i}.bias'] = (out,)
+    s['input_proj2.weight'] = (C, 2 * C, 1, 1)
+    s['input_proj2.bias'] = (C,)
+    return s
+
+
+def make_neck_weights(seed):
+    """Seeded synthetic neck weights (same recipe as ``make_hot_weights``:
+    ``torch.rand`` only; conv matrices Xavier-uniform, norm scale 1 +- 0.2,
+    biases +-0.1)."""
+    g = torch.Generator().manual_seed(int(seed))
+    w = {}
+    for name, shape in neck_param_shapes().items():
+        u = torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1
+        if len(shape) == 4:
+            rf = shape[2] * shape[3]
+            w[name] = u * math.sqrt(6.0 / ((shape[0] + shape[1]) * rf))
+        elif name.endswith('norm.weight'):
+            w[name] = 1.0 + 0.2 * u
+        else:
+            w[name] = 0.1 * u
+    return w
+
+
+def make_backbone_features(seed, n, hb, wb):
+    """Synthetic ResNet layer3 output [n,1024,hb,wb]: non-negative (post-ReLU),
+    about half the entries zero."""
+    g = torch.Generator().manual_seed(int(seed))
+    u = torch.rand(n, BACKBONE_C, hb, wb, generator=g)
+    return torch.clamp(u * 2 - 1, min=0)
+
+
+def neck(bb, w, return_stages=False):
+    """Backbone features [n,1024,hb,wb] -> feat [n,256,hb//2,wb//2].
+
+    reference src/model.py:113-118 (``input_proj2(patchmerging(input_proj(.)))``)
+    with PatchMerging.forward, backbone.py:53-67: LayerNorm over channels at
+    every position, three stride-2 convs (kernel 4/8/16, padding (k-2)/2) whose
+    outputs are concatenated along channels (256+128+128)."""
+    x = F.conv2d(bb, w['input_proj.weight'], w['input_proj.bias'])
+    n, c, h, ww = x.shape
+    t = x.flatten(2).transpose(1, 2)                       # n (h w) c
+    t = F.layer_norm(t, (c,), w['patchmerging.norm.weight'],
+                     w['patchmerging.norm.bias'], 1e-5)
+    xn = t.transpose(1, 2).reshape(n, c, h, ww).contiguous()
+    ys = []
+    for i, ps in enumerate(PATCH_SIZES):
+        ys.append(F.conv2d(xn, w[f'patchmerging.reductions.{i}.weight'],
+                           w[f'patchmerging.reductions.{i}.bias'], stride=2,
+                           padding=(ps - 2) // 2))
+    y = torch.cat(ys, dim=1)
+    feat = F.conv2d(y, w['input_proj2.weight'], w['input_proj2.bias'])
+    if return_stages:
+        return dict(proj=x, xn=xn, merged=y, feat=feat)
+    return feat
+
+
+# --------------------------------------------------------------------------
 # position table (reference src/models/utils.py:174-205)
 # --------------------------------------------------------------------------
 def position_table(hf, wf, d_model=D_MODEL, dtype=torch.float32):

@@ -156,3 +156,30 @@ def test_state_dict_contract(golden_dir):
     assert all(list(own[k].shape) == keys[k] for k in keys)
     assert set(hot_path_keys()) == set(orc.hot_path_param_shapes())
     assert len(keys) == 749
+
+
+# --------------------------------------------------------------------------
+# neck: input_proj -> PatchMerging -> input_proj2
+# --------------------------------------------------------------------------
+NECK = sorted(glob.glob(str(__import__('pathlib').Path(__file__).parent / 'golden' / 'neck_*.npz')))
+
+
+def load_neck_case(path):
+    g = np.load(path)
+    w = orc.make_neck_weights(int(g['weight_seed']))
+    hb, wb = (int(v) for v in g['grid'])
+    bb = orc.make_backbone_features(int(g['feat_seed']), int(g['n']), hb, wb)
+    assert np.array_equal(orc.checksum(bb), g['bb_fp']), 'seeded backbone features differ'
+    assert np.array_equal(
+        orc.checksum(torch.cat([w[k].flatten() for k in sorted(w)])), g['weights_fp'])
+    return g, w, bb
+
+
+@pytest.mark.parametrize('path', NECK, ids=lambda p: p.split('neck_')[-1][:-4])
+def test_neck_matches_reference(path):
+    g, w, bb = load_neck_case(path)
+    st = orc.neck(bb, w, return_stages=True)
+    _close(st['proj'][:, :, ::5, ::7].numpy(), g['proj_sample'], 2e-5, what='input_proj')
+    _close(st['merged'][:, :, ::3, ::4].numpy(), g['merged_sample'], 5e-5, what='patchmerging')
+    _close(st['feat'].numpy(), g['feat'], 5e-5, what='feat')
+    assert st['feat'].shape[2:] == (bb.shape[2] // 2, bb.shape[3] // 2)
