@@ -102,11 +102,12 @@ struct Packer {
 }  // namespace
 
 enum KernelId { K_PREP, K_ENC_A, K_ENC_BA, K_ENC_BDEC, K_ENC_B, K_DECODER, K_HEAT_CONV,
-                K_HEAT_FINAL, K_SIZE_REG, K_BOXES, K_DEC_CONVP, K_HEAT_COMBINE, K_COUNT };
+                K_HEAT_FINAL, K_SIZE_REG, K_BOXES, K_DEC_CONVP, K_HEAT_COMBINE, K_NECK_PROJ,
+                K_NECK_CONV, K_NECK_OUT, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {
     "k_prep_tokens", "k_encoder<A>", "k_encoder<B,A>", "k_encoder<B,dec>", "k_encoder<B>",
     "k_decoder", "k_heat_conv", "k_heat_final", "k_size_reg", "k_boxes", "k_decoder_convp",
-    "k_heat_combine"};
+    "k_heat_combine", "k_neck_proj", "k_neck_conv", "k_neck_out"};
 
 struct oetr_trace {
   std::vector<hipEvent_t> ev;  // 2 per launch
@@ -127,6 +128,18 @@ struct oetr_ctx {
   const float* qe[2];
   const float *dec_tgt1, *dec_q0, *dec_qkv1;  // create-time decoder constants
   HeadsDev heads;
+};
+
+struct oetr_neck_ctx {
+  oetr_trace* trace = nullptr;
+  int device = 0;
+  float* dev = nullptr;  // all repacked weights
+  const f32x4 *proj_wh[2], *proj_wl[2];
+  const float *proj_b, *ln_w, *ln_b;
+  const f32x4 *conv_wh[3], *conv_wl[3];
+  const float* conv_b[3];
+  const f32x4 *out_wh, *out_wl;
+  const float* out_b;
 };
 
 namespace {
@@ -217,7 +230,7 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
 // Brackets one kernel launch with two events when a trace is attached.
 struct Scoped {
   oetr_trace* t; hipStream_t s; int slot;
-  Scoped(oetr_ctx* h, hipStream_t s_, int kid) : t(h ? h->trace : nullptr), s(s_), slot(-1) {
+  Scoped(oetr_trace* tr, hipStream_t s_, int kid) : t(tr), s(s_), slot(-1) {
     if (!t) return;
     if (2 * (t->used + 1) > (int)t->ev.size()) { t->dropped++; t = nullptr; return; }
     slot = t->used++;
@@ -228,7 +241,7 @@ struct Scoped {
 };
 #define TRACED(h, s, kid, expr)            \
   do {                                     \
-    Scoped sc__(h, s, kid);                \
+    Scoped sc__((h)->trace, s, kid);       \
     HIP_TRY(expr);                         \
   } while (0)
 
@@ -636,6 +649,212 @@ oetr_status oetr_full_attention(const float* q, const float* k, const float* v, 
   if (!q || !k || !v || !out || n <= 0 || L <= 0 || S <= 0)
     return fail(OETR_ERR_BAD_ARG, "oetr_full_attention: bad argument");
   HIP_TRY(launch_full_attention(q, k, v, n, L, S, out, static_cast<hipStream_t>(stream)));
+  return OETR_OK;
+}
+
+// ---------------------------------------------------------------- neck ----
+namespace {
+
+// PatchMerging reductions (reference backbone.py:39-51): kernel, out channels,
+// K slices of 16 kernel pixels, 128-column halves.
+struct NeckConvShape { int ks, log2ks, cout, nsplit, nhalf; };
+constexpr NeckConvShape kNeckConv[3] = {{4, 2, 256, 1, 2}, {8, 3, 128, 4, 1}, {16, 4, 128, 16, 1}};
+
+// W [cout][256][ks][ks] -> per (K slice, column half, n-tile): f16 B fragments of
+// the [16 pixels * 256 channels][32] slab, hi and lo*2^11 planes (k_neck_conv).
+void pack_conv(Packer& pk, const float* W, const NeckConvShape& cs, size_t* hi_off, size_t* lo_off) {
+  const int ks2 = cs.ks * cs.ks, steps = NECK_PIX * C / 16;
+  const size_t plane_floats = (size_t)cs.cout * C * ks2 / 2;
+  *hi_off = pk.reserve_aligned(plane_floats);
+  *lo_off = pk.reserve_aligned(plane_floats);
+  _Float16* hi = reinterpret_cast<_Float16*>(pk.buf.data() + *hi_off);
+  _Float16* lo = reinterpret_cast<_Float16*>(pk.buf.data() + *lo_off);
+  for (int sp = 0; sp < cs.nsplit; ++sp)
+    for (int nh = 0; nh < cs.nhalf; ++nh)
+      for (int nt = 0; nt < 4; ++nt)
+        for (int st = 0; st < steps; ++st)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int n = nh * 128 + nt * 32 + (lane & 31);
+              const int k = st * 16 + 8 * (lane >> 5) + j;      // within the slab
+              const int pix = NECK_PIX * sp + k / C, c = k % C;  // kernel pixel ky*ks+kx
+              const float w = W[((size_t)n * C + c) * ks2 + pix];
+              const _Float16 h = (_Float16)w;
+              const size_t idx = (((((size_t)sp * cs.nhalf + nh) * 4 + nt) * steps + st) * 64 + lane) * 8 + j;
+              hi[idx] = h;
+              lo[idx] = (_Float16)((w - (float)h) * SPLIT_SCALE);
+            }
+}
+
+bool make_neck_geom(int n_img, int hb, int wb, NeckGeom* g) {
+  if (n_img <= 0 || hb < 2 || wb < 2 || hb > 400 || wb > 400) return false;
+  const long lo = (long)(hb / 2) * (wb / 2);
+  if (lo > OETR_MAX_TOKENS) return false;
+  if ((long)n_img * hb * wb > (1L << 30) / C || n_img >= (1 << 13)) return false;
+  g->n_img = n_img; g->hb = hb; g->wb = wb; g->ho = hb / 2; g->wo = wb / 2;
+  g->HW = hb * wb;
+  g->rows_in = n_img * g->HW;
+  g->M = n_img * g->ho * g->wo;
+  return true;
+}
+
+struct NeckWorkspace {
+  _Float16 *xh, *xl;
+  float* part[3];
+  size_t bytes;
+};
+NeckWorkspace neck_carve(const NeckGeom& g, void* base) {
+  NeckWorkspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? static_cast<char*>(base) + off : nullptr;
+    off += (bytes + 255) & ~size_t(255);
+    return p;
+  };
+  const size_t plane = ((size_t)g.rows_in + 1) * C * sizeof(_Float16);
+  w.xh = reinterpret_cast<_Float16*>(take(plane));
+  w.xl = reinterpret_cast<_Float16*>(take(plane));
+  for (int i = 0; i < 3; ++i)
+    w.part[i] = reinterpret_cast<float*>(
+        take((size_t)kNeckConv[i].nsplit * g.M * kNeckConv[i].cout * sizeof(float)));
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace
+
+oetr_status oetr_neck_create(const oetr_neck_weights* w, int device, oetr_neck_handle* out) {
+  if (!w || !out) return fail(OETR_ERR_BAD_ARG, "oetr_neck_create: NULL argument");
+  *out = nullptr;
+  if (w->struct_size != sizeof(oetr_neck_weights) || w->abi_version != OETR_ABI_VERSION)
+    return fail(OETR_ERR_BAD_ARG, "oetr_neck_create: oetr_neck_weights size/ABI mismatch");
+  {
+    const float* const* p = reinterpret_cast<const float* const*>(&w->input_proj_w);
+    const size_t n = (sizeof(oetr_neck_weights) - offsetof(oetr_neck_weights, input_proj_w)) / sizeof(float*);
+    for (size_t i = 0; i < n; ++i)
+      if (!p[i]) return fail(OETR_ERR_BAD_ARG, "oetr_neck_create: weight pointer #" +
+                                                   std::to_string(i) + " is NULL");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+    return fail(OETR_ERR_NO_DEVICE, "no HIP device " + std::to_string(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (!strstr(prop.gcnArchName, "gfx950"))
+    return fail(OETR_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName +
+                                        ", this library is built for gfx950 only");
+  Packer pk;
+  size_t pwh[2], pwl[2], cwh[3], cwl[3], cb[3], owh, owl;
+  for (int kh = 0; kh < 2; ++kh)  // input_proj, K halves [256][512] of the [256][1024] matrix
+    pk.frag_h(w->input_proj_w + kh * 512, C, 512, &pwh[kh], &pwl[kh], BBC);
+  const size_t pb = pk.copy(w->input_proj_b, C), lw = pk.copy(w->norm_w, C), lb = pk.copy(w->norm_b, C);
+  for (int i = 0; i < 3; ++i) {
+    pack_conv(pk, w->reduction_w[i], kNeckConv[i], &cwh[i], &cwl[i]);
+    cb[i] = pk.copy(w->reduction_b[i], kNeckConv[i].cout);
+  }
+  pk.frag_h(w->input_proj2_w, C, 2 * C, &owh, &owl);
+  const size_t ob = pk.copy(w->input_proj2_b, C);
+
+  oetr_neck_ctx* h = new oetr_neck_ctx();
+  h->device = device;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(&h->dev, pk.buf.size() * sizeof(float));
+  if (e == hipSuccess)
+    e = hipMemcpy(h->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    if (h->dev) (void)hipFree(h->dev);
+    delete h;
+    return hip_fail(e, "oetr_neck_create: uploading weights");
+  }
+  const float* B = h->dev;
+  auto F4 = [&](size_t off) { return reinterpret_cast<const f32x4*>(B + off); };
+  for (int kh = 0; kh < 2; ++kh) { h->proj_wh[kh] = F4(pwh[kh]); h->proj_wl[kh] = F4(pwl[kh]); }
+  h->proj_b = B + pb; h->ln_w = B + lw; h->ln_b = B + lb;
+  for (int i = 0; i < 3; ++i) { h->conv_wh[i] = F4(cwh[i]); h->conv_wl[i] = F4(cwl[i]); h->conv_b[i] = B + cb[i]; }
+  h->out_wh = F4(owh); h->out_wl = F4(owl); h->out_b = B + ob;
+  *out = h;
+  return OETR_OK;
+}
+
+void oetr_neck_destroy(oetr_neck_handle h) {
+  if (!h) return;
+  if (h->dev) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->dev);
+    (void)hipSetDevice(prev);
+  }
+  delete h;
+}
+
+size_t oetr_neck_workspace_bytes(oetr_neck_handle h, int n_images, int hb, int wb) {
+  NeckGeom g;
+  (void)h;  // shape-only: usable before a handle exists
+  if (!make_neck_geom(n_images, hb, wb, &g)) return 0;
+  return neck_carve(g, nullptr).bytes;
+}
+
+oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, int n_images,
+                              int hb, int wb, void* workspace, size_t workspace_bytes,
+                              float* feat_out, void* stream) {
+  if (!h || !backbone_feat || !feat_out)
+    return fail(OETR_ERR_BAD_ARG, "oetr_neck_forward: NULL argument");
+  NeckGeom g;
+  if (!make_neck_geom(n_images, hb, wb, &g))
+    return fail(OETR_ERR_BAD_SHAPE, "oetr_neck_forward: need n_images > 0, 2 <= hb,wb <= 400 and "
+                                    "(hb/2)*(wb/2) <= " + std::to_string(OETR_MAX_TOKENS));
+  if (!workspace) return fail(OETR_ERR_WORKSPACE, "workspace is NULL");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255)
+    return fail(OETR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  const NeckWorkspace w = neck_carve(g, workspace);
+  if (w.bytes > workspace_bytes)
+    return fail(OETR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(w.bytes) +
+                                        " bytes, got " + std::to_string(workspace_bytes));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  NeckProjLaunch pp;
+  pp.g = g; pp.bb = backbone_feat;
+  for (int kh = 0; kh < 2; ++kh) { pp.wh[kh] = h->proj_wh[kh]; pp.wl[kh] = h->proj_wl[kh]; }
+  pp.bias = h->proj_b; pp.ln_w = h->ln_w; pp.ln_b = h->ln_b;
+  pp.xh = w.xh; pp.xl = w.xl;
+  TRACED(h, s, K_NECK_PROJ, launch_neck_proj(pp, s));
+
+  NeckConvLaunch cp;
+  cp.g = g; cp.xh = w.xh; cp.xl = w.xl;
+  const int mtiles = (g.M + NECK_MT - 1) / NECK_MT;
+  int blocks = 0;
+  // the 16-slice conv first: its partials are the last thing k_neck_out needs
+  const int order[3] = {2, 1, 0};
+  for (int oi = 0; oi < 3; ++oi) {
+    const int i = order[oi];
+    NeckConvDesc& d = cp.conv[oi];
+    const NeckConvShape& cs = kNeckConv[i];
+    d.wh = h->conv_wh[i]; d.wl = h->conv_wl[i];
+    d.part = w.part[i];
+    d.log2ks = cs.log2ks; d.pad = (cs.ks - 2) / 2;
+    d.nsplit = cs.nsplit; d.nhalf = cs.nhalf; d.ncols = cs.cout;
+    d.block0 = blocks;
+    blocks += mtiles * cs.nsplit * cs.nhalf;
+  }
+  cp.nblocks = blocks;
+  TRACED(h, s, K_NECK_CONV, launch_neck_conv(cp, s));
+
+  NeckOutLaunch op;
+  op.g = g;
+  for (int i = 0; i < 3; ++i) { op.part[i] = w.part[i]; op.nsplit[i] = kNeckConv[i].nsplit; op.bias[i] = h->conv_b[i]; }
+  op.wh = h->out_wh; op.wl = h->out_wl; op.bias2 = h->out_b;
+  op.feat = feat_out;
+  TRACED(h, s, K_NECK_OUT, launch_neck_out(op, s));
+  return OETR_OK;
+}
+
+oetr_status oetr_neck_set_trace(oetr_neck_handle h, oetr_trace_handle t) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_set_trace: NULL handle");
+  h->trace = t;
   return OETR_OK;
 }
 

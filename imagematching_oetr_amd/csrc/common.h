@@ -441,6 +441,40 @@ struct ATile {
   }
 };
 
+// Sum over the TPR (8 or 16) consecutive lanes that share a row.
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v) {
+  v = sum8(v);
+  if (TPR == 16) v += dpp_mov<0x140>(v);  // row_mirror: lane i <-> 15 - i
+  return v;
+}
+
+// LayerNorm over a [TM][256] LDS tile with TPR threads per row: thread tid owns
+// row tid/TPR and the float4 columns i*TPR + tid%TPR (the threads of a row read
+// contiguous 16-byte pieces per step).  Row sums need only 3-4 DPP exchanges.
+// Returns (x - mean) * rstd in registers; the caller applies its affine(s).
+template <int TPR, int F4>
+__device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4], int dbg) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(S + (tid / TPR) * LDA) + (tid % TPR);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < F4; ++i) {
+    xn[i] = src[i * TPR];
+    s += (xn[i][0] + xn[i][1]) + (xn[i][2] + xn[i][3]);
+  }
+  if (ABL(dbg, ABL_LN)) return;
+  const float mean = row_sum<TPR>(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < F4; ++i) {
+    xn[i] -= mean;
+    q += (xn[i][0] * xn[i][0] + xn[i][1] * xn[i][1]) + (xn[i][2] * xn[i][2] + xn[i][3] * xn[i][3]);
+  }
+  const float rstd = 1.0f / sqrtf(row_sum<TPR>(q) * (1.0f / C) + LN_EPS);
+#pragma unroll
+  for (int i = 0; i < F4; ++i) xn[i] *= rstd;
+}
+
 // ---------------------------------------------------------------------------
 // Weight stream of one wave across the GEMMs of a kernel.
 //
@@ -684,6 +718,48 @@ hipError_t launch_size_regression(const HeadsDev& w, const float* hs1, const flo
                                   int n, float* tlbr1, float* tlbr2, hipStream_t s);
 hipError_t launch_boxes(const float* cxy, const float* tlbr, int n, int max_h, int max_w,
                         float* box, hipStream_t s);
+// ---- neck (input_proj -> PatchMerging -> input_proj2), neck.hip ----
+constexpr int BBC = 1024;        // backbone (ResNet layer3) channels
+constexpr int NECK_MT = 256;     // output positions per conv workgroup
+constexpr int NECK_PIX = 16;     // kernel pixels per conv workgroup (its K slice = 16 * 256)
+struct NeckGeom {
+  int n_img, hb, wb, ho, wo;
+  int HW;        // hb * wb
+  int rows_in;   // n_img * HW  (row rows_in of the X planes is all zero: padding source)
+  int M;         // n_img * ho * wo output positions
+};
+struct NeckProjLaunch {
+  NeckGeom g;
+  const float* bb;              // [n_img][1024][HW]
+  const f32x4 *wh[2], *wl[2];   // input_proj weight, K halves, f16 fragment planes
+  const float *bias, *ln_w, *ln_b;
+  _Float16 *xh, *xl;            // [rows_in + 1][256] LayerNorm'ed projection, split planes
+};
+struct NeckConvDesc {
+  const f32x4 *wh, *wl;   // [split][nhalf][4 n-tiles][256 k16-steps][64 lanes] 16-byte units
+  float* part;            // [nsplit][M][ncols] partial sums
+  int log2ks, pad, nsplit, nhalf, ncols;
+  int block0;             // first block of this conv in the merged grid
+};
+struct NeckConvLaunch {
+  NeckGeom g;
+  const _Float16 *xh, *xl;
+  NeckConvDesc conv[3];
+  int nblocks;
+};
+struct NeckOutLaunch {
+  NeckGeom g;
+  const float* part[3];
+  int nsplit[3];
+  const float* bias[3];
+  const f32x4 *wh, *wl;   // input_proj2 weight [256][512]
+  const float* bias2;
+  float* feat;            // [n_img][256][ho*wo]
+};
+hipError_t launch_neck_proj(const NeckProjLaunch& p, hipStream_t s);
+hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s);
+hipError_t launch_neck_out(const NeckOutLaunch& p, hipStream_t s);
+
 hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n,
                                    int L, int S, float* out, hipStream_t s);
 hipError_t launch_full_attention(const float* q, const float* k, const float* v, int n,

@@ -113,40 +113,6 @@ struct EncCfg {
   static constexpr int F4 = 64 / TPR;       // float4 per thread per row
 };
 
-// Sum over the TPR (8 or 16) consecutive lanes that share a row.
-template <int TPR>
-__device__ __forceinline__ float row_sum(float v) {
-  v = sum8(v);
-  if (TPR == 16) v += dpp_mov<0x140>(v);  // row_mirror: lane i <-> 15 - i
-  return v;
-}
-
-// LayerNorm over a [TM][256] LDS tile with TPR threads per row: thread tid owns
-// row tid/TPR and the float4 columns i*TPR + tid%TPR (the threads of a row read
-// contiguous 16-byte pieces per step).  Row sums need only 3-4 DPP exchanges.
-// Returns (x - mean) * rstd in registers; the caller applies its affine(s).
-template <int TPR, int F4>
-__device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4], int dbg) {
-  const f32x4* src = reinterpret_cast<const f32x4*>(S + (tid / TPR) * LDA) + (tid % TPR);
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < F4; ++i) {
-    xn[i] = src[i * TPR];
-    s += (xn[i][0] + xn[i][1]) + (xn[i][2] + xn[i][3]);
-  }
-  if (ABL(dbg, ABL_LN)) return;
-  const float mean = row_sum<TPR>(s) * (1.0f / C);
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < F4; ++i) {
-    xn[i] -= mean;
-    q += (xn[i][0] * xn[i][0] + xn[i][1] * xn[i][1]) + (xn[i][2] * xn[i][2] + xn[i][3] * xn[i][3]);
-  }
-  const float rstd = 1.0f / sqrtf(row_sum<TPR>(q) * (1.0f / C) + LN_EPS);
-#pragma unroll
-  for (int i = 0; i < F4; ++i) xn[i] *= rstd;
-}
-
 // phi(K) and V/S in place (rows past the image end zeroed); returns sum_rows phi(K).
 // values / v_length (linear_attention.py:44) is a multiply by the reciprocal:
 // <= 1 ulp from the division, 1 instruction instead of ~10.

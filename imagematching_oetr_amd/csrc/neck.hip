@@ -1,0 +1,319 @@
+// Neck of the OETR feature extractor on gfx950:
+//
+//   feat = input_proj2( PatchMerging( input_proj( backbone_out ) ) )
+//
+// reference src/model.py:113-118 and src/models/backbone.py:53-67: a 1x1 conv
+// 1024 -> 256, LayerNorm over channels at every position, three stride-2 convs
+// (kernel 4 / 8 / 16, padding (k-2)/2, 256 -> 256 / 128 / 128 channels)
+// concatenated, and a 1x1 conv 512 -> 256.  9.2 of its 10.2 GFLOP per image are
+// the three convs: implicit GEMMs with K = k*k*256 up to 65536.
+//
+// All products use the split-f16 arithmetic of common.h (a = ah + al*2^-11,
+// three f16 MFMAs, fp32 accumulation): fp32-class results at f16 MFMA rate.
+//
+//   k_neck_proj  32 positions per workgroup: NCHW gather -> LDS split planes,
+//                1x1 conv (K = 1024 in two halves, weights streamed as B
+//                fragments), LayerNorm, result stored token-major as two f16
+//                planes X_hi / X_lo (+ one all-zero row used as padding source).
+//   k_neck_conv  the three convs in ONE grid.  A workgroup owns 256 output
+//                positions x 128 output channels x 16 kernel pixels (K = 4096,
+//                split-K over the kernel window: 16 / 4 / 1 slices for k = 16 /
+//                8 / 4): per 64-channel stage the gathered input rows go
+//                through a double-buffered LDS tile, the weights straight from
+//                L2 into B-fragment registers one stage ahead; every weight
+//                fragment feeds four 32-row MFMA tiles.  Partials -> HBM.
+//   k_neck_out   32 positions per workgroup: fixed-order sum of the partials +
+//                biases -> the 512-channel concat as split planes in LDS, 1x1
+//                conv 512 -> 256, transposed store to NCHW.
+#include "common.h"
+
+namespace oetr {
+
+// ---------------------------------------------------------------------------
+// k_neck_proj
+// ---------------------------------------------------------------------------
+constexpr int NP_S0_OFF = HID_FLOATS;            // A planes [32][520] x2 first
+constexpr int NP_PAR_OFF = NP_S0_OFF + TM * LDA; // f32 tile [32][260]
+constexpr int NP_SMEM = NP_PAR_OFF + 2 * C;      // LayerNorm affine
+
+// Stage channels [kh*512, kh*512+512) of 32 positions: NCHW rows (one channel,
+// 32 consecutive positions = 128 B per half-wave) -> LDS [pos][channel] planes.
+__device__ __forceinline__ void proj_stage(const ATile<true>& A, const float* src, int HW,
+                                           int tid) {
+  const int pos = tid & 31, cg = tid >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cb = cg + 16 * i;  // block of 8 channels
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(cb * 8 + j) * HW];
+    f16x2 h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    const f16x8 hv = {h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+    const f16x8 lv = {l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+    *reinterpret_cast<f16x8*>(A.h + pos * A.ldh + cb * 8) = hv;
+    *reinterpret_cast<f16x8*>(A.l + pos * A.ldh + cb * 8) = lv;
+  }
+}
+
+__global__ __launch_bounds__(512) void k_neck_proj(NeckProjLaunch p) {
+  __shared__ __attribute__((aligned(16))) float smem[NP_SMEM];
+  const ATile<true> A(smem, LDH, LDHH);
+  float* S0 = smem + NP_S0_OFF;
+  float* par = smem + NP_PAR_OFF;
+  const NeckGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31;
+  const int tpi = (g.HW + TM - 1) / TM;
+  const int img = blockIdx.x / tpi, p0 = (blockIdx.x - img * tpi) * TM;
+  const int nvalid = min(TM, g.HW - p0);
+
+  if (tid < 2 * C) par[tid] = tid < C ? p.ln_w[tid] : p.ln_b[tid - C];
+  if (blockIdx.x == 0 && tid < 64) {  // the padding row of both planes
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4* zr = reinterpret_cast<f32x4*>((tid < 32 ? p.xh : p.xl) + (size_t)g.rows_in * C);
+    zr[tid & 31] = z;
+  }
+  f32x16 acc[1];
+  {
+    const float b = p.bias[32 * wave + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = b;
+  }
+  using WS = WStream<true, 1>;
+  WS ws;
+  constexpr int P0 = 0, P1 = WS::adv(P0, 512);
+  const float* src = p.bb + (size_t)img * BBC * g.HW + p0 + min(tid & 31, nvalid - 1);
+  proj_stage(A, src, g.HW, tid);
+  ws.template prime<512, P0>(p.wh[0], p.wl[0], wave, lane);
+  __syncthreads();
+  ws.template gemm<512, P0, 512>(A, p.wh[0], p.wl[0], wave, lane, acc, p.wh[1], p.wl[1], wave, 0);
+  __syncthreads();
+  proj_stage(A, src + (size_t)512 * g.HW, g.HW, tid);
+  __syncthreads();
+  ws.template gemm<512, P1, 0>(A, p.wh[1], p.wl[1], wave, lane, acc, nullptr, nullptr, 0, 0);
+  acc_to_lds<1>(S0, LDA, 32 * wave, lane, acc);
+  __syncthreads();
+
+  // LayerNorm over the 256 channels of each position (backbone.py:59), split, store
+  f32x4 xn[4];
+  ln_rows<16, 4>(S0, tid, xn, 0);
+  const int lrow = tid >> 4, lpart = tid & 15;
+  if (lrow < nvalid) {
+    const size_t row = (size_t)img * g.HW + p0 + lrow;
+    const f32x4* gw = reinterpret_cast<const f32x4*>(par) + lpart;
+    const f32x4* gb = reinterpret_cast<const f32x4*>(par + C) + lpart;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      store_split4(p.xh + row * C, p.xl + row * C, 4 * (i * 16 + lpart), xn[i] * gw[i * 16] + gb[i * 16]);
+  }
+}
+
+hipError_t launch_neck_proj(const NeckProjLaunch& p, hipStream_t s) {
+  const int tpi = (p.g.HW + TM - 1) / TM;
+  hipLaunchKernelGGL(k_neck_proj, dim3(p.g.n_img * tpi), dim3(512), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k_neck_conv
+// ---------------------------------------------------------------------------
+constexpr int NC_ROWB = 272;                   // staged row: hi 128 B | lo 128 B | pad 16 B
+constexpr int NC_BUF = NECK_MT * NC_ROWB;      // 69632 B per stage buffer
+constexpr int NC_STAGES = NECK_PIX * 4;        // 16 pixels x 4 channel quarters
+static_assert(NC_ROWB % 16 == 0 && (NC_ROWB / 4) % 64 == 4, "conflict-free b128 row stride");
+
+struct ConvB { f32x4 h, l; };                  // one k16-step of B fragments (hi, lo)
+
+__global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * NC_BUF];
+  const NeckGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int nt = wave & 3, rh = wave >> 2;  // this wave: n-tile nt, rows [128*rh, 128*rh+128)
+
+  // ---- which conv / output tile / K slice ----
+  const int b = blockIdx.x;
+  const int ci = b >= p.conv[2].block0 ? 2 : (b >= p.conv[1].block0 ? 1 : 0);
+  const NeckConvDesc& cd = p.conv[ci];
+  const int lb = b - cd.block0;
+  const int per_mt = cd.nsplit * cd.nhalf;
+  const int mt = lb / per_mt, rem = lb - mt * per_mt;
+  const int split = rem / cd.nhalf, nh = rem - split * cd.nhalf;
+  const int ksmask = (1 << cd.log2ks) - 1;
+  const size_t wbase = ((size_t)(split * cd.nhalf + nh) * 4 + nt) * (NC_STAGES * 4) * 64 + lane;
+  const f32x4* wh = cd.wh + wbase;
+  const f32x4* wl = cd.wl + wbase;
+
+  // ---- staging role: 16 lanes per input row (8 x 16 B of X_hi, 8 of X_lo) ----
+  const int slot = tid & 15;
+  const f32x4* xplane = reinterpret_cast<const f32x4*>(slot < 8 ? p.xh : p.xl) + (slot & 7);
+  int rinfo[8];  // per staged row: img << 18 | (iy0 + 64) << 9 | (ix0 + 64); -1 = no such row
+  {
+    const int hw_o = g.ho * g.wo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = mt * NECK_MT + (tid >> 4) + 32 * j;
+      if (r < g.M) {
+        const int img = r / hw_o, q = r - img * hw_o;
+        const int oy = q / g.wo, ox = q - oy * g.wo;
+        rinfo[j] = (img << 18) | ((2 * oy - cd.pad + 64) << 9) | (2 * ox - cd.pad + 64);
+      } else {
+        rinfo[j] = -1;
+      }
+    }
+  }
+  auto src_unit = [&](int info, int ky, int kx, int cq) -> size_t {
+    const int iy = ((info >> 9) & 511) - 64 + ky, ix = (info & 511) - 64 + kx;
+    const bool ok = info >= 0 && (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
+    const int row = ok ? (info >> 18) * g.HW + iy * g.wb + ix : g.rows_in;
+    return (size_t)row * 32 + cq * 8;  // 16-byte units: 256 halves per row, 64 per quarter
+  };
+  f32x4 sreg[4];
+  auto stage_load = [&](int s, int jh) {  // rows j = 4*jh .. 4*jh+3 of stage s -> registers
+    const int pix = NECK_PIX * split + (s >> 2), cq = s & 3;
+    const int ky = pix >> cd.log2ks, kx = pix & ksmask;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sreg[j] = xplane[src_unit(rinfo[4 * jh + j], ky, kx, cq)];
+  };
+  auto stage_write = [&](int buf, int jh) {
+    char* dst = smem + buf * NC_BUF + ((tid >> 4) + 128 * jh) * NC_ROWB + slot * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + 32 * j * NC_ROWB) = sreg[j];
+  };
+
+  f32x16 acc[4], cross[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { acc[t] = f32x16{0}; cross[t] = f32x16{0}; }
+  ConvB bf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { bf[kk].h = wh[kk * 64]; bf[kk].l = wl[kk * 64]; }
+
+  stage_load(0, 0); stage_write(0, 0);
+  stage_load(0, 1); stage_write(0, 1);
+  __syncthreads();
+
+  const int a_lane_off = (128 * rh + col) * NC_ROWB + 16 * half;
+  for (int s = 0; s < NC_STAGES; ++s) {
+    const int cur = s & 1;
+    const bool more = s + 1 < NC_STAGES;
+    const char* abase = smem + cur * NC_BUF + a_lane_off;
+    if (more) stage_load(s + 1, 0);
+    f32x4 ah[4], al[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB);
+      al[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB + 128);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const f16x8 bh = __builtin_bit_cast(f16x8, bf[kk].h), bl = __builtin_bit_cast(f16x8, bf[kk].l);
+#pragma unroll
+      for (int tp = 0; tp < 4; tp += 2) {
+        const f16x8 a0h = __builtin_bit_cast(f16x8, ah[tp]), a0l = __builtin_bit_cast(f16x8, al[tp]);
+        const f16x8 a1h = __builtin_bit_cast(f16x8, ah[tp + 1]), a1l = __builtin_bit_cast(f16x8, al[tp + 1]);
+        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[tp], 0, 0, 0);
+        acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[tp + 1], 0, 0, 0);
+        cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[tp], 0, 0, 0);
+        cross[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[tp + 1], 0, 0, 0);
+        cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[tp], 0, 0, 0);
+        cross[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[tp + 1], 0, 0, 0);
+        if (kk < 3) {  // this pair's fragments for the next k16 step
+#pragma unroll
+          for (int t = tp; t < tp + 2; ++t) {
+            ah[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB + (kk + 1) * 32);
+            al[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB + (kk + 1) * 32 + 128);
+          }
+        }
+      }
+      if (more) {  // the same k16 step of the next stage into the slot just consumed
+        bf[kk].h = wh[((s + 1) * 4 + kk) * 64];
+        bf[kk].l = wl[((s + 1) * 4 + kk) * 64];
+      }
+      if (kk == 1 && more) { stage_write(cur ^ 1, 0); stage_load(s + 1, 1); }
+    }
+    if (more) stage_write(cur ^ 1, 1);
+    __syncthreads();
+  }
+
+  // ---- partial sums -> HBM ----
+  float* out = cd.part + ((size_t)split * g.M) * cd.ncols + nh * 128 + nt * 32 + col;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * NECK_MT + 128 * rh + 32 * t + crow(r, half);
+      if (row < g.M) out[(size_t)row * cd.ncols] = fmaf(cross[t][r], SPLIT_INV, acc[t][r]);
+    }
+}
+
+hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_neck_conv, dim3(p.nblocks), dim3(512), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k_neck_out
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_neck_out(NeckOutLaunch p) {
+  __shared__ __attribute__((aligned(16))) float smem[NP_PAR_OFF];
+  const ATile<true> A(smem, LDH, LDHH);
+  float* S0 = smem + NP_S0_OFF;
+  const NeckGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31;
+  const int r0 = blockIdx.x * TM;
+
+  using WS = WStream<true, 1>;
+  WS ws;
+  f32x16 acc[1];
+  {
+    const float b = p.bias2[32 * wave + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = b;
+  }
+  // the 512-channel concat of this tile: bias + partial sums in slice order
+  {
+    const int lrow = tid >> 4, lpart = tid & 15;
+    const int r = r0 + lrow;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = 4 * (i * 16 + lpart);
+      const int ci = c4 < 256 ? 0 : (c4 < 384 ? 1 : 2);
+      const int cc = c4 - (ci == 0 ? 0 : (ci == 1 ? 256 : 384));
+      const int ncols = ci == 0 ? 256 : 128;
+      f32x4 v = *reinterpret_cast<const f32x4*>(p.bias[ci] + cc);
+      if (r < g.M) {
+        const float* src = p.part[ci] + (size_t)r * ncols + cc;
+        for (int sidx = 0; sidx < p.nsplit[ci]; ++sidx)
+          v += *reinterpret_cast<const f32x4*>(src + (size_t)sidx * g.M * ncols);
+      }
+      A.put4(lrow, c4, v);
+    }
+  }
+  ws.template prime<512, 0>(p.wh, p.wl, wave, lane);
+  __syncthreads();
+  ws.template gemm<512, 0, 0>(A, p.wh, p.wl, wave, lane, acc, nullptr, nullptr, 0, 0);
+  acc_to_lds<1>(S0, LDA, 32 * wave, lane, acc);
+  __syncthreads();
+  // transposed store: one channel, 32 consecutive positions per half-wave
+  {
+    const int pos = tid & 31, cg = tid >> 5;
+    const int r = r0 + pos;
+    if (r < g.M) {
+      const int hw_o = g.ho * g.wo;
+      const int img = r / hw_o, q = r - img * hw_o;
+      float* dst = p.feat + (size_t)img * C * hw_o + q;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = cg * 16 + i;
+        dst[(size_t)c * hw_o] = S0[pos * LDA + c];
+      }
+    }
+  }
+}
+
+hipError_t launch_neck_out(const NeckOutLaunch& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_neck_out, dim3((p.g.M + TM - 1) / TM), dim3(512), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace oetr

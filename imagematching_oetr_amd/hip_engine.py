@@ -52,6 +52,13 @@ class _Stages(C.Structure):
                                   'tlbr1', 'tlbr2')]
 
 
+class _NeckWeights(C.Structure):
+    _fields_ = [('struct_size', C.c_uint32), ('abi_version', C.c_uint32)] + [
+        (n, _f32p) for n in ('input_proj_w', 'input_proj_b', 'norm_w', 'norm_b')] + [
+        ('reduction_w', _f32p * 3), ('reduction_b', _f32p * 3),
+        ('input_proj2_w', _f32p), ('input_proj2_b', _f32p)]
+
+
 ABI_VERSION = 1
 EXPORTS = (
     'oetr_last_error', 'oetr_abi_version', 'oetr_create', 'oetr_destroy',
@@ -59,7 +66,9 @@ EXPORTS = (
     'oetr_feature_correlation', 'oetr_center_estimation',
     'oetr_size_regression', 'oetr_box_tlbr_to_xyxy', 'oetr_linear_attention',
     'oetr_full_attention', 'oetr_trace_create', 'oetr_trace_destroy',
-    'oetr_set_trace', 'oetr_trace_summary')
+    'oetr_set_trace', 'oetr_trace_summary', 'oetr_neck_create',
+    'oetr_neck_destroy', 'oetr_neck_workspace_bytes', 'oetr_neck_forward',
+    'oetr_neck_set_trace')
 
 
 def hot_path_keys():
@@ -87,6 +96,16 @@ def hot_path_keys():
              'heatmap_conv.1.bias', 'heatmap_conv.3.weight',
              'heatmap_conv.3.bias']
     return keys
+
+
+def neck_keys():
+    """State-dict keys of the neck (input_proj, PatchMerging, input_proj2)."""
+    keys = ['input_proj.weight', 'input_proj.bias', 'patchmerging.norm.weight',
+            'patchmerging.norm.bias']
+    for i in range(3):
+        keys += [f'patchmerging.reductions.{i}.weight',
+                 f'patchmerging.reductions.{i}.bias']
+    return keys + ['input_proj2.weight', 'input_proj2.bias']
 
 
 _lib = None
@@ -147,6 +166,16 @@ def load_library(path=None):
     lib.oetr_trace_summary.restype = i
     lib.oetr_trace_summary.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_char_p),
                                        C.POINTER(i), C.POINTER(C.c_float)]
+    lib.oetr_neck_create.restype = i
+    lib.oetr_neck_create.argtypes = [C.POINTER(_NeckWeights), i, C.POINTER(vp)]
+    lib.oetr_neck_destroy.restype = None
+    lib.oetr_neck_destroy.argtypes = [vp]
+    lib.oetr_neck_workspace_bytes.restype = sz
+    lib.oetr_neck_workspace_bytes.argtypes = [vp, i, i, i]
+    lib.oetr_neck_forward.restype = i
+    lib.oetr_neck_forward.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp]
+    lib.oetr_neck_set_trace.restype = i
+    lib.oetr_neck_set_trace.argtypes = [vp, vp]
     if lib.oetr_abi_version() != ABI_VERSION:
         raise RuntimeError(f'{p}: ABI version {lib.oetr_abi_version()} != '
                            f'{ABI_VERSION}')
@@ -382,6 +411,82 @@ class HotPathEngine:
         return t1, t2
 
 
+class NeckEngine:
+    """Owns one ``oetr_neck_handle``: input_proj -> PatchMerging -> input_proj2
+    (reference ``src/model.py:113-118``, ``backbone.py:53-67``) as HIP kernels."""
+
+    PATCH_SIZES = (4, 8, 16)
+    BACKBONE_C = 1024
+
+    def __init__(self, weights, device=None):
+        self.lib = load_library()
+        device = torch.device('cuda', torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        if device.type != 'cuda':
+            raise OetrError('NeckEngine needs a GPU device')
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = device
+        missing = [k for k in neck_keys() if k not in weights]
+        if missing:
+            raise KeyError(f'missing neck weights: {missing}')
+        host = {k: weights[k].detach().to('cpu', torch.float32).contiguous()
+                for k in neck_keys()}
+        shapes = {'input_proj.weight': (D_MODEL, self.BACKBONE_C, 1, 1),
+                  'input_proj2.weight': (D_MODEL, 2 * D_MODEL, 1, 1)}
+        for i, ps in enumerate(self.PATCH_SIZES):
+            shapes[f'patchmerging.reductions.{i}.weight'] = (
+                D_MODEL if i == 0 else D_MODEL // 2, D_MODEL, ps, ps)
+        for k, shp in shapes.items():
+            if tuple(host[k].shape) != shp:
+                raise ValueError(f'{k}: expected {shp}, got {tuple(host[k].shape)} '
+                                 '(the HIP neck is built for the default config)')
+        w = _NeckWeights()
+        w.struct_size = C.sizeof(_NeckWeights)
+        w.abi_version = ABI_VERSION
+
+        def ptr(key):
+            return C.cast(host[key].data_ptr(), _f32p)
+
+        w.input_proj_w, w.input_proj_b = ptr('input_proj.weight'), ptr('input_proj.bias')
+        w.norm_w, w.norm_b = ptr('patchmerging.norm.weight'), ptr('patchmerging.norm.bias')
+        for i in range(3):
+            w.reduction_w[i] = ptr(f'patchmerging.reductions.{i}.weight')
+            w.reduction_b[i] = ptr(f'patchmerging.reductions.{i}.bias')
+        w.input_proj2_w, w.input_proj2_b = ptr('input_proj2.weight'), ptr('input_proj2.bias')
+        handle = C.c_void_p()
+        _check(self.lib, self.lib.oetr_neck_create(C.byref(w), device.index, C.byref(handle)),
+               'oetr_neck_create')
+        self._h = handle
+        self._ws = None
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                self.lib.oetr_neck_destroy(h)
+            except Exception:
+                pass
+
+    def forward(self, backbone_feat):
+        """[n,1024,hb,wb] (ResNet layer3 output) -> feat [n,256,hb//2,wb//2]."""
+        x = _dev(backbone_feat, 'backbone_feat')
+        if x.dim() != 4 or x.shape[1] != self.BACKBONE_C:
+            raise ValueError(f'backbone_feat must be [n,{self.BACKBONE_C},hb,wb], '
+                             f'got {tuple(x.shape)}')
+        n, hb, wb = int(x.shape[0]), int(x.shape[2]), int(x.shape[3])
+        need = self.lib.oetr_neck_workspace_bytes(self._h, n, hb, wb)
+        if need == 0:
+            raise ValueError(f'invalid neck shape n={n} grid {hb}x{wb}')
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        feat = torch.empty(n, D_MODEL, hb // 2, wb // 2, device=self.device)
+        _check(self.lib, self.lib.oetr_neck_forward(
+            self._h, x.data_ptr(), n, hb, wb, self._ws.data_ptr(), self._ws.numel(),
+            feat.data_ptr(), _stream()), 'oetr_neck_forward')
+        return feat
+
+
 class KernelTrace:
     """Measurement hook (bench/profiling): per-kernel GPU durations from HIP
     events recorded on the launch stream (``oetr_trace_*`` in the header)."""
@@ -395,13 +500,17 @@ class KernelTrace:
                                                     C.byref(self._t)),
                'oetr_trace_create')
 
+    def _attach(self, t):
+        fn = self.lib.oetr_neck_set_trace if isinstance(self.engine, NeckEngine) \
+            else self.lib.oetr_set_trace
+        return fn(self.engine._h, t)
+
     def __enter__(self):
-        _check(self.lib, self.lib.oetr_set_trace(self.engine._h, self._t),
-               'oetr_set_trace')
+        _check(self.lib, self._attach(self._t), 'oetr_set_trace')
         return self
 
     def __exit__(self, *exc):
-        self.lib.oetr_set_trace(self.engine._h, None)
+        self._attach(None)
 
     def summary(self):
         """{kernel name: (launches, total_ms)} since the last call."""

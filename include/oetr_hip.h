@@ -203,6 +203,39 @@ oetr_status oetr_linear_attention(const float *q, const float *k,
 oetr_status oetr_full_attention(const float *q, const float *k, const float *v,
                                 int n, int L, int S, float *out, void *stream);
 
+/* ---- neck: input_proj -> PatchMerging -> input_proj2 ------
+ * The part of OETR.feature_extraction between the ResNet trunk and the hot
+ * path (reference src/model.py:113-118; PatchMerging.forward,
+ * src/models/backbone.py:53-67).  Separate handle: its 47.7 MB of weights are
+ * independent of the hot-path handle.  GEMMs use the split-f16 arithmetic
+ * (fp32-class) whatever dtype the hot-path handle was created with. */
+typedef struct {
+  uint32_t struct_size; /* = sizeof(oetr_neck_weights) */
+  uint32_t abi_version; /* = OETR_ABI_VERSION */
+  const float *input_proj_w, *input_proj_b;     /* [256][1024][1][1],[256] model.py:45-47 */
+  const float *norm_w, *norm_b;                 /* [256] LayerNorm     backbone.py:37 */
+  const float *reduction_w[3], *reduction_b[3]; /* [256|128|128][256][k][k], k = 4,8,16;
+                                                   stride 2, pad (k-2)/2  backbone.py:39-51 */
+  const float *input_proj2_w, *input_proj2_b;   /* [256][512][1][1],[256] model.py:48-50 */
+} oetr_neck_weights;
+typedef struct oetr_neck_ctx *oetr_neck_handle;
+
+oetr_status oetr_neck_create(const oetr_neck_weights *w, int device,
+                             oetr_neck_handle *out);
+void oetr_neck_destroy(oetr_neck_handle h);
+/* Workspace bytes for n_images backbone maps of hb x wb (0 on invalid shape:
+ * hb, wb in [2, 400], (hb/2)*(wb/2) <= OETR_MAX_TOKENS). */
+size_t oetr_neck_workspace_bytes(oetr_neck_handle h, int n_images, int hb,
+                                 int wb);
+/* Replaces: input_proj2(patchmerging(input_proj(x))) of
+ * OETR.feature_extraction (reference src/model.py:113-118).
+ *   backbone_feat [n_images][1024][hb][wb]   (NCHW, what ResnetEncoder emits)
+ *   feat_out      [n_images][256][hb/2][wb/2] (NCHW, what oetr_forward takes) */
+oetr_status oetr_neck_forward(oetr_neck_handle h, const float *backbone_feat,
+                              int n_images, int hb, int wb, void *workspace,
+                              size_t workspace_bytes, float *feat_out,
+                              void *stream);
+
 /* ---- measurement hook (bench.py / profiling only) -------------------------
  * A trace owns a pool of HIP events.  While attached to a handle, every
  * kernel launched by the forward entry points is bracketed by two events
@@ -217,6 +250,7 @@ typedef struct oetr_trace *oetr_trace_handle;
 oetr_status oetr_trace_create(int max_launches, oetr_trace_handle *out);
 void oetr_trace_destroy(oetr_trace_handle t);
 oetr_status oetr_set_trace(oetr_handle h, oetr_trace_handle t /* NULL detaches */);
+oetr_status oetr_neck_set_trace(oetr_neck_handle h, oetr_trace_handle t);
 oetr_status oetr_trace_summary(oetr_trace_handle t, int *n_kernels,
                                const char *names[OETR_TRACE_MAX_KERNELS],
                                int launches[OETR_TRACE_MAX_KERNELS],

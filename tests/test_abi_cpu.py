@@ -23,7 +23,7 @@ def header_functions():
 def test_library_exports_every_declared_symbol():
     lib = pkg.load_library()
     names = header_functions()
-    assert len(names) == 17, names
+    assert len(names) == 22, names
     assert set(names) == set(hip_engine.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/oetr_hip.h but not exported'
@@ -35,6 +35,8 @@ def test_struct_layout_matches_header_sizes():
     n_ptr = 8 * 12 + 2 * 22 + 11
     assert ctypes.sizeof(hip_engine._Weights) == 8 + 8 * n_ptr
     assert ctypes.sizeof(hip_engine._Stages) == 8 + 8 * 10
+    # neck: 4 + 3 + 3 + 2 pointers
+    assert ctypes.sizeof(hip_engine._NeckWeights) == 8 + 8 * 12
 
 
 def test_workspace_query_and_shape_errors_need_no_gpu():
@@ -47,6 +49,28 @@ def test_workspace_query_and_shape_errors_need_no_gpu():
     assert lib.oetr_workspace_bytes(None, 0, 20, 20, 20, 20) == 0
     # ragged grids grow monotonically
     assert lib.oetr_workspace_bytes(None, 8, 20, 20, 40, 40) > b
+
+
+def test_neck_workspace_query_and_errors_need_no_gpu():
+    lib = pkg.load_library()
+    b = lib.oetr_neck_workspace_bytes(None, 16, 40, 40)
+    # X planes (2 x f16) + 21 partial slabs
+    assert b >= 2 * (16 * 1600 + 1) * 256 * 2 + 16 * 400 * (256 + 4 * 128 + 16 * 128) * 4
+    assert b % 256 == 0
+    assert lib.oetr_neck_workspace_bytes(None, 1, 1, 40) == 0      # no output row
+    assert lib.oetr_neck_workspace_bytes(None, 1, 201, 202) == 0   # > 100x100 tokens out
+    assert lib.oetr_neck_workspace_bytes(None, 0, 40, 40) == 0
+    st = lib.oetr_neck_forward(None, None, 1, 40, 40, None, 0, None, None)
+    assert st == 1 and b'NULL' in lib.oetr_last_error()
+    h = ctypes.c_void_p()
+    w = hip_engine._NeckWeights()
+    w.struct_size = 4
+    assert lib.oetr_neck_create(ctypes.byref(w), 0, ctypes.byref(h)) == 1
+    assert b'size/ABI' in lib.oetr_last_error()
+    w.struct_size = ctypes.sizeof(hip_engine._NeckWeights)
+    w.abi_version = hip_engine.ABI_VERSION
+    assert lib.oetr_neck_create(ctypes.byref(w), 0, ctypes.byref(h)) == 1
+    assert b'is NULL' in lib.oetr_last_error()
 
 
 def test_null_arguments_are_rejected_not_crashed():

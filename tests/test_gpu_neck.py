@@ -1,0 +1,73 @@
+"""GPU parity of the HIP neck (input_proj -> PatchMerging -> input_proj2,
+SURVEY.md §8f.1) through the C ABI, against the reference goldens and the
+oracle.  Tolerance: the reference's own fp32-vs-fp64 drift on ``feat`` is
+~5e-6 (abs-max 5.7); the bound below is 10x that."""
+import glob
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import imagematching_oetr_amd as pkg
+from oracle import oetr_oracle as orc
+from tests.test_oracle_golden import load_neck_case
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+NECK = sorted(glob.glob(str(Path(__file__).parent / 'golden' / 'neck_*.npz')))
+FEAT_TOL = 5e-5
+
+
+@pytest.mark.parametrize('path', NECK, ids=lambda p: p.split('neck_')[-1][:-4])
+def test_neck_matches_reference_golden(gpu, path):
+    g, w, bb = load_neck_case(path)
+    eng = pkg.NeckEngine(w, device=gpu)
+    feat = eng.forward(bb.to(gpu))
+    ref = torch.from_numpy(g['feat'])
+    assert feat.shape == ref.shape
+    err = (feat.cpu() - ref).abs().max().item()
+    assert err <= FEAT_TOL, f'feat max err {err:.3e}'
+    # second call on the same workspace: bit-identical (fixed summation order)
+    assert torch.equal(eng.forward(bb.to(gpu)), feat)
+
+
+@pytest.mark.parametrize('n,hb,wb', [(1, 2, 2), (1, 3, 5), (2, 7, 40), (5, 16, 18), (1, 40, 99)])
+def test_neck_edge_shapes_vs_oracle(gpu, n, hb, wb):
+    """Tiny, odd and ragged grids (floor(h/2) outputs; kernel 16 wider than the map)."""
+    w = orc.make_neck_weights(40)
+    bb = orc.make_backbone_features(41 + hb, n, hb, wb)
+    ref = orc.neck(bb.double(), {k: v.double() for k, v in w.items()})
+    feat = pkg.NeckEngine(w, device=gpu).forward(bb.to(gpu))
+    assert feat.shape == (n, 256, hb // 2, wb // 2)
+    err = (feat.cpu().double() - ref).abs().max().item()
+    assert err <= FEAT_TOL, f'feat max err {err:.3e}'
+
+
+def test_neck_bench_size_properties(gpu):
+    """16 images of 40x40 (both sides of 8 pairs at 640x640): per-image independence
+    (a batch equals its images run one by one) and shift of the padding row."""
+    w = orc.make_neck_weights(42)
+    eng = pkg.NeckEngine(w, device=gpu)
+    bb = orc.make_backbone_features(43, 16, 40, 40).to(gpu)
+    feat = eng.forward(bb)
+    assert torch.isfinite(feat).all()
+    for i in (0, 7, 15):
+        assert torch.equal(eng.forward(bb[i:i + 1].contiguous())[0], feat[i])
+    ref = orc.neck(bb[3:4].cpu(), w)
+    assert (feat[3:4].cpu() - ref).abs().max().item() <= FEAT_TOL
+
+
+def test_neck_errors(gpu):
+    w = orc.make_neck_weights(44)
+    eng = pkg.NeckEngine(w, device=gpu)
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(1, 1024, 1, 8, device=gpu))
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(1, 512, 8, 8, device=gpu))
+    with pytest.raises(pkg.OetrError):
+        eng.forward(torch.zeros(1, 1024, 8, 8))
+    bad = dict(w)
+    bad['patchmerging.reductions.2.weight'] = torch.zeros(128, 256, 8, 8)
+    with pytest.raises(ValueError):
+        pkg.NeckEngine(bad, device=gpu)
