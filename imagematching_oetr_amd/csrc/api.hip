@@ -826,9 +826,8 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
   NeckConvLaunch cp;
   cp.g = g; cp.xh = w.xh; cp.xl = w.xl;
   const int mtiles = (g.M + NECK_MT - 1) / NECK_MT;
-  int blocks = 0;
-  // the 16-slice conv first: its partials are the last thing k_neck_out needs
-  const int order[3] = {2, 1, 0};
+  int items = 0;
+  const int order[3] = {2, 1, 0};  // k = 16 (16 slices), k = 8 (4), k = 4 (2 column halves)
   for (int oi = 0; oi < 3; ++oi) {
     const int i = order[oi];
     NeckConvDesc& d = cp.conv[oi];
@@ -837,10 +836,11 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
     d.part = w.part[i];
     d.log2ks = cs.log2ks; d.pad = (cs.ks - 2) / 2;
     d.nsplit = cs.nsplit; d.nhalf = cs.nhalf; d.ncols = cs.cout;
-    d.block0 = blocks;
-    blocks += mtiles * cs.nsplit * cs.nhalf;
+    d.item0 = items;
+    items += cs.nsplit * cs.nhalf;
   }
-  cp.nblocks = blocks;
+  cp.items_per_mt = items;
+  cp.nblocks = items * mtiles;
   TRACED(h, s, K_NECK_CONV, launch_neck_conv(cp, s));
 
   NeckOutLaunch op;

@@ -739,13 +739,14 @@ struct NeckConvDesc {
   const f32x4 *wh, *wl;   // [split][nhalf][4 n-tiles][256 k16-steps][64 lanes] 16-byte units
   float* part;            // [nsplit][M][ncols] partial sums
   int log2ks, pad, nsplit, nhalf, ncols;
-  int block0;             // first block of this conv in the merged grid
+  int item0;              // first work item of this conv within a tile's items
 };
 struct NeckConvLaunch {
   NeckGeom g;
   const _Float16 *xh, *xl;
   NeckConvDesc conv[3];
-  int nblocks;
+  int items_per_mt;       // K slices x column halves of all three convs (22)
+  int nblocks;            // items_per_mt * number of 256-position tiles
 };
 struct NeckOutLaunch {
   NeckGeom g;

@@ -124,20 +124,26 @@ constexpr int NC_STAGES = NECK_PIX * 4;        // 16 pixels x 4 channel quarters
 static_assert(NC_ROWB % 16 == 0 && (NC_ROWB / 4) % 64 == 4, "conflict-free b128 row stride");
 
 struct ConvB { f32x4 h, l; };                  // one k16-step of B fragments (hi, lo)
+#ifndef NECK_ABL
+#define NECK_ABL 0   // timing experiments only: 1 no A gathers, 2 no B loads, 4 no MFMA, 8 no LDS writes
+#endif
 
 __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * NC_BUF];
+  __shared__ int2 rowinfo[NECK_MT];
   const NeckGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
   const int nt = wave & 3, rh = wave >> 2;  // this wave: n-tile nt, rows [128*rh, 128*rh+128)
 
-  // ---- which conv / output tile / K slice ----
-  const int b = blockIdx.x;
-  const int ci = b >= p.conv[2].block0 ? 2 : (b >= p.conv[1].block0 ? 1 : 0);
+  // ---- which output tile / conv / K slice ----
+  // Work items are ordered tile-major (all 22 slices of the three convs of one
+  // 256-position tile are adjacent) and each XCD takes a contiguous run of them:
+  // the gathered X rows of a tile (~1.6 MB) are then shared through ONE L2.
+  const int logical = xcd_remap(blockIdx.x, p.nblocks);
+  const int mt = logical / p.items_per_mt, it = logical - mt * p.items_per_mt;
+  const int ci = it >= p.conv[2].item0 ? 2 : (it >= p.conv[1].item0 ? 1 : 0);
   const NeckConvDesc& cd = p.conv[ci];
-  const int lb = b - cd.block0;
-  const int per_mt = cd.nsplit * cd.nhalf;
-  const int mt = lb / per_mt, rem = lb - mt * per_mt;
+  const int rem = it - cd.item0;
   const int split = rem / cd.nhalf, nh = rem - split * cd.nhalf;
   const int ksmask = (1 << cd.log2ks) - 1;
   const size_t wbase = ((size_t)(split * cd.nhalf + nh) * 4 + nt) * (NC_STAGES * 4) * 64 + lane;
@@ -147,36 +153,39 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   // ---- staging role: 16 lanes per input row (8 x 16 B of X_hi, 8 of X_lo) ----
   const int slot = tid & 15;
   const f32x4* xplane = reinterpret_cast<const f32x4*>(slot < 8 ? p.xh : p.xl) + (slot & 7);
-  int rinfo[8];  // per staged row: img << 18 | (iy0 + 64) << 9 | (ix0 + 64); -1 = no such row
-  {
+  // per output row: {index of its window origin in X (may be negative), (iy0+64)<<16 | ix0+64}
+  // kept in LDS - eight rows' worth of loop-invariant registers would not fit
+  if (tid < NECK_MT) {
     const int hw_o = g.ho * g.wo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = mt * NECK_MT + (tid >> 4) + 32 * j;
-      if (r < g.M) {
-        const int img = r / hw_o, q = r - img * hw_o;
-        const int oy = q / g.wo, ox = q - oy * g.wo;
-        rinfo[j] = (img << 18) | ((2 * oy - cd.pad + 64) << 9) | (2 * ox - cd.pad + 64);
-      } else {
-        rinfo[j] = -1;
-      }
-    }
+    const int r = mt * NECK_MT + tid;
+    const int rc = min(r, g.M - 1);
+    const int img = rc / hw_o, q = rc - img * hw_o;
+    const int oy = q / g.wo, ox = q - oy * g.wo;
+    const int iy0 = r < g.M ? 2 * oy - cd.pad : -64, ix0 = 2 * ox - cd.pad;  // iy0 = -64: never valid
+    rowinfo[tid] = make_int2(img * g.HW + iy0 * g.wb + ix0, ((iy0 + 64) << 16) | (ix0 + 64));
   }
-  auto src_unit = [&](int info, int ky, int kx, int cq) -> size_t {
-    const int iy = ((info >> 9) & 511) - 64 + ky, ix = (info & 511) - 64 + kx;
-    const bool ok = info >= 0 && (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
-    const int row = ok ? (info >> 18) * g.HW + iy * g.wb + ix : g.rows_in;
+  __syncthreads();
+  auto src_unit = [&](int2 info, int ky, int kx, int cq) -> size_t {
+    const int iy = (info.y >> 16) - 64 + ky, ix = (info.y & 0xffff) - 64 + kx;
+    const bool ok = (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
+    const int m = -(int)ok;  // branch-free select (a branch here serialises the row-info reads)
+    const int row = ((info.x + ky * g.wb + kx) & m) | (g.rows_in & ~m);
     return (size_t)row * 32 + cq * 8;  // 16-byte units: 256 halves per row, 64 per quarter
   };
-  f32x4 sreg[4];
+  f32x4 sreg[4] = {};
   auto stage_load = [&](int s, int jh) {  // rows j = 4*jh .. 4*jh+3 of stage s -> registers
     const int pix = NECK_PIX * split + (s >> 2), cq = s & 3;
     const int ky = pix >> cd.log2ks, kx = pix & ksmask;
+    int2 info[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sreg[j] = xplane[src_unit(rinfo[4 * jh + j], ky, kx, cq)];
+    for (int j = 0; j < 4; ++j) info[j] = rowinfo[(tid >> 4) + 128 * jh + 32 * j];
+    if (NECK_ABL & 1) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sreg[j] = xplane[src_unit(info[j], ky, kx, cq)];
   };
   auto stage_write = [&](int buf, int jh) {
     char* dst = smem + buf * NC_BUF + ((tid >> 4) + 128 * jh) * NC_ROWB + slot * 16;
+    if (NECK_ABL & 8) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + 32 * j * NC_ROWB) = sreg[j];
   };
@@ -192,6 +201,10 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   stage_load(0, 1); stage_write(0, 1);
   __syncthreads();
 
+  // Issue order inside a stage is pinned (sched_barrier): the compiler otherwise sinks
+  // the run-ahead loads to their first use and the MFMAs wait a full L2 round trip.
+  //   G0 (rows 0-127 of stage s+1) | k16 step 0, B(s+1, 0) | step 1, B(s+1, 1) |
+  //   W0, G1 (rows 128-255) | step 2, B(s+1, 2) | step 3, B(s+1, 3) | W1 | barrier
   const int a_lane_off = (128 * rh + col) * NC_ROWB + 16 * half;
   for (int s = 0; s < NC_STAGES; ++s) {
     const int cur = s & 1;
@@ -204,6 +217,7 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
       ah[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB);
       al[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB + 128);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const f16x8 bh = __builtin_bit_cast(f16x8, bf[kk].h), bl = __builtin_bit_cast(f16x8, bf[kk].l);
@@ -211,12 +225,17 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
       for (int tp = 0; tp < 4; tp += 2) {
         const f16x8 a0h = __builtin_bit_cast(f16x8, ah[tp]), a0l = __builtin_bit_cast(f16x8, al[tp]);
         const f16x8 a1h = __builtin_bit_cast(f16x8, ah[tp + 1]), a1l = __builtin_bit_cast(f16x8, al[tp + 1]);
+        if (NECK_ABL & 4) {
+          acc[tp][0] += (float)a0h[0] + (float)a0l[0] + (float)bh[0] + (float)bl[0];
+          acc[tp + 1][0] += (float)a1h[0] + (float)a1l[0];
+        } else {
         acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[tp], 0, 0, 0);
         acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[tp + 1], 0, 0, 0);
         cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[tp], 0, 0, 0);
         cross[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[tp + 1], 0, 0, 0);
         cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[tp], 0, 0, 0);
         cross[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[tp + 1], 0, 0, 0);
+        }
         if (kk < 3) {  // this pair's fragments for the next k16 step
 #pragma unroll
           for (int t = tp; t < tp + 2; ++t) {
@@ -224,12 +243,18 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
             al[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB + (kk + 1) * 32 + 128);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) {  // the same k16 step of the next stage into the slot just consumed
+      if (more && !(NECK_ABL & 2)) {  // the same k16 step of the next stage into the slot just consumed
         bf[kk].h = wh[((s + 1) * 4 + kk) * 64];
         bf[kk].l = wl[((s + 1) * 4 + kk) * 64];
       }
-      if (kk == 1 && more) { stage_write(cur ^ 1, 0); stage_load(s + 1, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 1 && more) {
+        stage_write(cur ^ 1, 0);
+        stage_load(s + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (more) stage_write(cur ^ 1, 1);
     __syncthreads();

@@ -4,9 +4,10 @@ feature-correlation transformer and the regression heads executed by the
 hand-written HIP library (``csrc/`` -> ``liboetr_hip.so``).
 
 Mirrors reference ``src/model.py:38-252`` (inference half) and
-``build_detectors`` (:380-384).  Only ``feature_extraction`` runs as torch ops
-(host code, MIOpen); everything from ``feature_correlation`` to the final
-boxes goes through the C ABI declared in ``include/oetr_hip.h``.  There is no
+``build_detectors`` (:380-384).  The ResNet trunk runs as torch ops (host code,
+MIOpen); the neck (input_proj, PatchMerging, input_proj2) and everything from
+``feature_correlation`` to the final boxes go through the C ABI declared in
+``include/oetr_hip.h``.  There is no
 CPU or eager fallback for that part: if the extension is missing or the
 tensors are not on a GPU the call raises.
 
@@ -20,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .backbone import PatchMerging, PositionEncodingSine, ResnetEncoder
-from .hip_engine import HotPathEngine, hot_path_keys
+from .hip_engine import HotPathEngine, NeckEngine, hot_path_keys, neck_keys
 
 
 class _EncoderLayerParams(nn.Module):
@@ -114,17 +115,34 @@ class OETR(nn.Module):
         self.softmax_temperature = 1
         #: GEMM arithmetic of the HIP hot path: 'f32_split_f16' (default) or 'f32'
         self.hip_precision = 'f32_split_f16'
+        #: run input_proj -> PatchMerging -> input_proj2 as HIP kernels when the
+        #: features are on a GPU (False: the torch modules, as on CPU)
+        self.hip_neck = True
         self._engine = None
         self._engine_key = None
+        self._neck_engine = None
+        self._neck_key = None
 
     # ---------------------------------------------------------------- host
+    def neck(self, x):
+        """Backbone output [n,1024,hb,wb] -> feat [n,256,hb//2,wb//2]
+        (reference ``src/model.py:113-118``): the HIP neck on a GPU, the torch
+        modules otherwise (host code either way)."""
+        if self.hip_neck and x.is_cuda:
+            return self.neck_engine().forward(x)
+        return self.input_proj2(self.patchmerging(self.input_proj(x)))
+
     def feature_extraction(self, image1, image2, mask1=None, mask2=None):
-        """Reference ``src/model.py:109-130`` (torch ops, any device)."""
-        feats = []
-        for img in (image1, image2):
-            f = self.input_proj(self.backbone(img))
-            feats.append(self.input_proj2(self.patchmerging(f)))
-        feat1, feat2 = feats
+        """Reference ``src/model.py:109-130``.  Same-sized image batches go through
+        the trunk and the neck as ONE batch of 2N images (per-sample ops: same
+        results, half the launches)."""
+        if image1.shape == image2.shape:
+            n = image1.shape[0]
+            f = self.neck(self.backbone(torch.cat([image1, image2], dim=0)))
+            feat1, feat2 = f[:n], f[n:]
+        else:
+            feat1 = self.neck(self.backbone(image1))
+            feat2 = self.neck(self.backbone(image2))
         hf1, wf1 = feat1.shape[2:]
         hf2, wf2 = feat2.shape[2:]
         return (feat1, feat2, self.pos_encoding(feat1), self.pos_encoding(feat2),
@@ -150,6 +168,17 @@ class OETR(nn.Module):
                                          precision=self.hip_precision)
             self._engine_key = key
         return self._engine
+
+    def neck_engine(self):
+        """HIP neck bound to the current neck weights (rebuilt when they change)."""
+        params = [self.get_parameter(k) for k in neck_keys()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._neck_engine is None or key != self._neck_key:
+            sd = self.state_dict()
+            self._neck_engine = NeckEngine({k: sd[k] for k in neck_keys()},
+                                           device=params[0].device)
+            self._neck_key = key
+        return self._neck_engine
 
     @staticmethod
     def _no_masks(mask1, mask2):

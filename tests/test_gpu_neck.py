@@ -71,3 +71,28 @@ def test_neck_errors(gpu):
     bad['patchmerging.reductions.2.weight'] = torch.zeros(128, 256, 8, 8)
     with pytest.raises(ValueError):
         pkg.NeckEngine(bad, device=gpu)
+
+
+def test_module_neck_hip_vs_torch_modules(gpu):
+    """OETR.neck: HIP kernels vs the torch modules holding the same weights, and
+    feature_extraction's batched (same-size) vs per-image paths."""
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval().to(gpu)
+    g = torch.Generator().manual_seed(8)
+    im1 = torch.rand(2, 256, 320, 3, generator=g).to(gpu)
+    im2 = torch.rand(2, 256, 320, 3, generator=g).to(gpu)
+    bb = model.backbone(im1)
+    hip = model.neck(bb)
+    model.hip_neck = False
+    ref = model.neck(bb)
+    model.hip_neck = True
+    assert hip.shape == ref.shape == (2, 256, 8, 10)
+    scale = ref.abs().max().item()
+    assert (hip - ref).abs().max().item() <= 2e-5 * max(1.0, scale)
+    f1, f2, *_ = model.feature_extraction(im1, im2)          # one batch of 4
+    f1s = model.neck(model.backbone(im1))
+    assert (f1 - f1s).abs().max().item() <= 2e-5 * max(1.0, scale)
+    # in-place edit of a neck weight rebuilds the engine
+    with torch.no_grad():
+        model.input_proj2.bias.add_(0.5)
+    assert (model.neck(bb) - hip - 0.5).abs().max().item() <= 1e-5
