@@ -280,6 +280,14 @@ def main():
                 model.forward_dummy(im1, im2)
             torch.cuda.synchronize()
             out['end_to_end_pairs_per_s'] = round(n * reps / (time.perf_counter() - t1), 1)
+            # front end of that forward: neck (HIP) per batch of 2N backbone maps
+            bbf = model.backbone(torch.cat([im1, im2])) if args.size == size2 else model.backbone(im1)
+            with pkg.KernelTrace(model.neck_engine()) as ntr:
+                for _ in range(reps):
+                    model.neck(bbf)
+                torch.cuda.synchronize()
+            out['neck_kernels_us'] = {k: round(v[1] / v[0] * 1e3, 1) for k, v in ntr.summary().items()}
+            out['neck_images'] = int(bbf.shape[0])
         except Exception as e:  # host-side extras must never break the bench line
             out['end_to_end_error'] = repr(e)[:200]
     print(json.dumps(out))
