@@ -129,6 +129,10 @@ def main():
                     help='GEMM arithmetic: 3 f16 MFMAs per fp32 product (default) or exact f32 MFMA')
     ap.add_argument('--no-trace', action='store_true',
                     help='do not record per-kernel events in the timed region')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='HIP streams the consecutive steps (batches) alternate over: a step of 8 '
+                         'pairs fills 208 of 256 CUs, the next batch on a second stream fills the '
+                         'rest.  1 = strictly serial steps (also always reported)')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -163,13 +167,18 @@ def main():
     n_total = n * world
 
     gatherer = BoxGatherer() if world > 1 else None
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
 
-    def step():
-        b1, b2 = eng.forward(feat1, feat2, pos, pos2, hw, hw2)
-        if gatherer is not None:
-            # the all-gather of this batch's boxes runs on RCCL's stream under the
-            # next batch's kernels; it is completed at the next submit / the flush
-            gatherer.submit(b1, b2)
+    def step(i=0, ns=1):
+        # consecutive steps alternate over the streams (one workspace per stream in
+        # the engine); every step is a full batch of n pairs through the whole path
+        with torch.cuda.stream(streams[i % ns]):
+            b1, b2 = eng.forward(feat1, feat2, pos, pos2, hw, hw2)
+            if gatherer is not None:
+                # the all-gather of this batch's boxes runs on RCCL's stream under the
+                # next batch's kernels; it is completed at the next submit / the flush
+                gatherer.submit(b1, b2)
         return b1, b2
 
     def barrier():
@@ -177,11 +186,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region():
+    def timed_region(ns):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(args.steps):
+            step(i, ns)
         if gatherer is not None:
             gatherer.flush()            # last batch's gather is inside the timed region
         barrier()
@@ -192,16 +201,18 @@ def main():
             dt = float(t.item())
         return dt
 
-    for _ in range(args.warmup):
-        step()
-    elapsed = timed_region()              # -> value (no instrumentation)
+    for i in range(args.warmup):
+        step(i, n_streams)
+    elapsed = timed_region(n_streams)     # -> value (no instrumentation)
+    elapsed_serial = timed_region(1) if n_streams > 1 else elapsed
     kern, elapsed_traced = {}, None
     if not args.no_trace:
-        # Same K steps again with the library's per-kernel HIP events recorded
-        # on its launch stream.  The events themselves cost ~9% of a step, so
-        # this pass feeds `roofline` only; its own wall time is reported too.
+        # Same K steps again, on ONE stream (kernel durations are only meaningful
+        # when launches do not share the chip), with the library's per-kernel HIP
+        # events recorded on its launch stream.  The events themselves cost ~9% of
+        # a step, so this pass feeds `roofline` only; its wall time is reported too.
         with pkg.KernelTrace(eng, max_launches=16 * args.steps + 64) as trace:
-            elapsed_traced = timed_region()
+            elapsed_traced = timed_region(1)
         kern = trace.summary()
 
     if rank != 0:
@@ -227,10 +238,14 @@ def main():
                                + f' -> {hf}x{hf}' + (f' / {hf2}x{hf2}' if hf2 != hf else '')
                                + ' tokens/image, C=256, 8 enc + 2 dec layers, fp32',
                    'pairs_per_gpu': n, 'global_pairs': n_total,
+                   'streams': n_streams,
                    'tokens_per_image': hf * hf,
                    'parallelism': f'pairs sharded over {world} rank(s); '
                                   'all-gather of boxes only'},
         'hot_path_tflops': round(value * PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800 / 1e3, 2),
+        # the same K steps strictly one after the other on one stream (batch latency)
+        'serial': {'ms_per_step': round(elapsed_serial / args.steps * 1e3, 4),
+                   'pairs_per_s': round(n_total * args.steps / elapsed_serial, 1)},
     }
     if kern and DOMINANT in kern:
         launches, total_ms = kern[DOMINANT]

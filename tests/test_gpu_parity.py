@@ -304,6 +304,29 @@ def test_forward_is_hipgraph_capturable(gpu, engines):
     assert torch.equal(captured[0], fresh[0])
 
 
+def test_batches_on_two_streams_overlap_safely(gpu, engines):
+    """One engine, consecutive batches alternating over two HIP streams (one
+    workspace per stream): every batch must equal its single-stream result bit
+    for bit, however the launches interleave on the chip."""
+    eng = engines(1, True)
+    n = 8
+    feats = [(orc.make_features(70 + i, n, 20, 20).to(gpu), orc.make_features(80 + i, n, 20, 20).to(gpu))
+             for i in range(4)]
+    p = orc.position_table(20, 20).to(gpu)
+    want = [eng.forward(a, b, p, p, (640, 640), (640, 640)) for a, b in feats]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(2)]
+    got = []
+    for rep in range(6):
+        for i, (a, b) in enumerate(feats):
+            with torch.cuda.stream(streams[i % 2]):
+                got.append((i, eng.forward(a, b, p, p, (640, 640), (640, 640))))
+    torch.cuda.synchronize()
+    for i, (b1, b2) in got:
+        assert torch.equal(b1, want[i][0]) and torch.equal(b2, want[i][1])
+    assert len(eng._ws) >= 3          # default stream + the two above
+
+
 def test_drop_in_module_forward_dummy(gpu):
     """OETR.forward_dummy on images: host backbone (torch/MIOpen) + HIP hot
     path, vs the same backbone features pushed through the oracle."""
