@@ -129,10 +129,14 @@ def main():
                     help='GEMM arithmetic: 3 f16 MFMAs per fp32 product (default) or exact f32 MFMA')
     ap.add_argument('--no-trace', action='store_true',
                     help='do not record per-kernel events in the timed region')
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--streams', type=int, default=3,
                     help='HIP streams the consecutive steps (batches) alternate over: a step of 8 '
                          'pairs fills 208 of 256 CUs, the next batch on a second stream fills the '
                          'rest.  1 = strictly serial steps (also always reported)')
+    ap.add_argument('--enc-tile', type=int, default=0, choices=[0, 32, 64],
+                    help='token rows per encoder workgroup (0: 64 while batches overlap on several '
+                         'streams - fewest CU-microseconds per token - and the library default, '
+                         '32 at this size, for the serial / traced passes)')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -201,9 +205,16 @@ def main():
             dt = float(t.item())
         return dt
 
+    split = args.precision == 'f32_split_f16'
+    tile_overlap = args.enc_tile or (64 if (n_streams > 1 and split) else 0)
+    eng.set_encoder_tile(args.enc_tile)
+    for i in range(args.warmup):
+        step(i, 1)
+    eng.set_encoder_tile(tile_overlap)
     for i in range(args.warmup):
         step(i, n_streams)
     elapsed = timed_region(n_streams)     # -> value (no instrumentation)
+    eng.set_encoder_tile(args.enc_tile)
     elapsed_serial = timed_region(1) if n_streams > 1 else elapsed
     kern, elapsed_traced = {}, None
     if not args.no_trace:
@@ -239,11 +250,13 @@ def main():
                                + ' tokens/image, C=256, 8 enc + 2 dec layers, fp32',
                    'pairs_per_gpu': n, 'global_pairs': n_total,
                    'streams': n_streams,
+                   'encoder_tile_rows': tile_overlap or 'auto',
                    'tokens_per_image': hf * hf,
                    'parallelism': f'pairs sharded over {world} rank(s); '
                                   'all-gather of boxes only'},
         'hot_path_tflops': round(value * PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800 / 1e3, 2),
-        # the same K steps strictly one after the other on one stream (batch latency)
+        # the same K steps strictly one after the other on one stream (batch latency;
+        # encoder tile = library default, which is also what the traced pass below runs)
         'serial': {'ms_per_step': round(elapsed_serial / args.steps * 1e3, 4),
                    'pairs_per_s': round(n_total * args.steps / elapsed_serial, 1)},
     }
@@ -251,7 +264,6 @@ def main():
         launches, total_ms = kern[DOMINANT]
         avg_ms = total_ms / launches
         flop = ENC_FLOP_PER_TOKEN * n * (hf * hf + hf2 * hf2)   # tokens of both sides (algorithmic)
-        split = args.precision == 'f32_split_f16'
         # `achieved` is ALGORITHMIC fp32 FLOP/s.  In split mode every algorithmic
         # product costs 3 f16 MFMA products, so the MFMA roof for this scheme is the
         # dense f16 peak / 3; in exact mode it is the f32 MFMA peak.

@@ -120,6 +120,8 @@ struct oetr_ctx {
   oetr_trace* trace = nullptr;
   int device = 0;
   bool split = false;  // OETR_DTYPE_F32_SPLIT_F16
+  int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
+  int num_cus = 256;
   float* dev = nullptr;  // all repacked weights
   size_t dev_floats = 0;
   EncLayerDev enc[OETR_N_ENC];
@@ -169,6 +171,26 @@ bool make_geom(int n, int hf1, int wf1, int hf2, int wf2, Geom* g) {
   g->ntiles = n * (g->nt[0] + g->nt[1]);
   g->rows = n * (g->L[0] + g->L[1]);
   return true;
+}
+
+// Tile bookkeeping of the encoder / decoder-partial side.  The split mode has a
+// 64-token workgroup shape (k_encoder64: every weight fragment feeds two MFMA row
+// tiles; 1.2-1.3x fewer CU-microseconds per token, but half as many workgroups).
+// auto: 64 once the 32-token grid no longer fits the chip in one wave of
+// workgroups; oetr_set_encoder_tile / OETR_ENC_TILE override.  The heads keep TM.
+int encoder_tile_rows(const oetr_ctx* h, const Geom& g) {
+  static const int forced = [] { const char* e = getenv("OETR_ENC_TILE"); return e ? atoi(e) : 0; }();
+  if (!h->split) return TM;
+  const int want = forced ? forced : h->enc_tile;
+  if (want == TM || want == 64) return want;
+  return g.ntiles > h->num_cus ? 64 : TM;
+}
+Geom encoder_geom(const Geom& g, int rows) {
+  Geom e = g;
+  for (int i = 0; i < 2; ++i) e.nt[i] = (g.L[i] + rows - 1) / rows;
+  e.tile0[0] = 0; e.tile0[1] = g.N * e.nt[0];
+  e.ntiles = g.N * (e.nt[0] + e.nt[1]);
+  return e;
 }
 
 Workspace carve(const Geom& g, void* base) {
@@ -248,7 +270,7 @@ struct Scoped {
 // Encoder (+ decoder) shared by forward and feature_correlation.
 DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w) {
   DecLaunch d;
-  d.g = g;
+  d.g = encoder_geom(g, encoder_tile_rows(h, g));  // partials are per ENCODER tile
   for (int i = 0; i < 2; ++i) { d.layer[i] = h->dec[i]; d.qe[i] = h->qe[i]; }
   d.tgt1 = h->dec_tgt1; d.qkv1 = h->dec_qkv1;
   d.att0_part = w.att0; d.z0_part = w.z0; d.dkv1 = w.dkv1; d.dks1 = w.dks1;
@@ -266,7 +288,8 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   TRACED(h, s, K_PREP, launch_prep_tokens(g, feat1, feat2, pos1, pos2, w.x, w.pos, s));
   EncLaunch p;
   memset(&p, 0, sizeof(p));
-  p.g = g;
+  p.tile_rows = encoder_tile_rows(h, g);
+  p.g = encoder_geom(g, p.tile_rows);
 #ifdef OETR_ABLATE
   { const char* e = getenv("OETR_ABLATE"); p.dbg = e ? atoi(e) : 0; }
 #endif
@@ -348,6 +371,7 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   oetr_ctx* h = new oetr_ctx();
   h->device = device;
   h->split = split;
+  h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   Packer pk;
   struct EncOff { size_t wq, wk, wv, wm, w1, w2, wq_l, wk_l, wv_l, wm_l, w1_l, w2_l, v[6]; } eo[OETR_N_ENC];
   for (int l = 0; l < OETR_N_ENC; ++l) {
@@ -875,6 +899,14 @@ void oetr_trace_destroy(oetr_trace_handle t) {
   if (!t) return;
   for (auto& e : t->ev) (void)hipEventDestroy(e);
   delete t;
+}
+
+oetr_status oetr_set_encoder_tile(oetr_handle h, int rows) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_encoder_tile: NULL handle");
+  if (rows != 0 && rows != TM && rows != 64)
+    return fail(OETR_ERR_BAD_ARG, "oetr_set_encoder_tile: rows must be 0 (auto), 32 or 64");
+  h->enc_tile = rows;
+  return OETR_OK;
 }
 
 oetr_status oetr_set_trace(oetr_handle h, oetr_trace_handle t) {

@@ -641,6 +641,8 @@ struct EncLaunch {
   EncLayerDev b;         // layer being finished (phase B), if any
   EncLayerDev a;         // next layer (phase A), TAIL==0
   DecKVDev d;            // TAIL==1
+  int tile_rows;         // token rows per workgroup: 32 (TM) or 64 (split mode, k_encoder64);
+                         // g.nt / g.tile0 / g.ntiles are in units of this tile
   int b_cross;           // phase-B layer is a cross layer
   int dbg;               // ablation flags (OETR_ABLATE builds only)
   long long* tbuf;       // per-phase cycle stamps (OETR_PHASE_TIMING builds only)

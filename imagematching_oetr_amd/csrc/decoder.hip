@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void k_decoder_convp(DecLaunch d, HeatLaunch h
 
 hipError_t launch_decoder_convp(const DecLaunch& d, const HeatLaunch& h, float* P, bool split,
                                 hipStream_t s) {
-  const dim3 grid(2 * d.g.N + d.g.ntiles);
+  const dim3 grid(2 * d.g.N + h.g.ntiles);  // h.g: 32-row tiles (d.g may use the encoder's 64)
   if (split) hipLaunchKernelGGL(k_decoder_convp<true>, grid, dim3(512), 0, s, d, h, P);
   else hipLaunchKernelGGL(k_decoder_convp<false>, grid, dim3(512), 0, s, d, h, P);
   return hipGetLastError();

@@ -514,6 +514,518 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   }
 }
 
+// ===========================================================================
+// 64-token variant of the fused  B(l) ; A(l+1)  kernel (split mode, 8 waves).
+//
+// With 32-token tiles a workgroup streams 2 MB of weight fragments per launch for
+// 32 rows, and that stream (per-CU L2->register rate) bounds the GEMM phases.
+// Here every fragment feeds TWO 32-row MFMA tiles, so the same stream serves 64
+// tokens and the GEMM phases become MFMA/stream balanced.  LDS (160 KB) does not
+// hold the 32-token layout twice, so:
+//   * the residual stream lives in registers only (xacc[2]); LayerNorm input is
+//     staged as an f32 tile in region R1 and normalised IN PLACE into the f16
+//     planes of the same region (one extra barrier, no extra LDS);
+//   * the MLP runs in two hidden halves of 256: MLP1a -> R2, MLP2a (K = 256),
+//     MLP1b -> R2, MLP2b, so the hidden tile needs one region instead of two.
+//   R1: f32 [64][260]  or  planes hi|lo [64][264]      (LN staging / GEMM A operand)
+//   R2: f32 [64][260] (phi(Q))  or  planes (kv input, hidden half)
+// The per-wave weight stream (WStream2) is a ring of 6 k16-steps of B fragments
+// (5 in flight) running ahead across GEMM calls like WStream.
+// ===========================================================================
+constexpr int RT = 64;                                   // token rows per workgroup
+constexpr int R_FLOATS = (2 * RT * LDAH * 2 + 3) / 4;    // 16896 >= RT * LDA = 16640
+static_assert(R_FLOATS >= RT * LDA, "region holds the f32 tile too");
+constexpr int E2_R1 = 0;
+constexpr int E2_R2 = R_FLOATS;
+constexpr int E2_KSUM = 2 * R_FLOATS;
+constexpr int E2_Z = E2_KSUM + C;
+constexpr int E2_LNP = E2_Z + RT * NH;
+constexpr int E2_SMEM = E2_LNP + 6 * C;                  // 36096 floats = 141 KB
+
+struct Planes2 {  // two f16 planes [RT][LDAH] (hi, lo*2^11) in one region
+  _Float16 *h, *l;
+  __device__ __forceinline__ explicit Planes2(float* base)
+      : h(reinterpret_cast<_Float16*>(base)), l(reinterpret_cast<_Float16*>(base) + RT * LDAH) {}
+  __device__ __forceinline__ void put4(int row, int c, const f32x4& v) const {
+    store_split4(h + row * LDAH, l + row * LDAH, c, v);
+  }
+  __device__ __forceinline__ void put_acc(int mt, int col0, int lane, const f32x16& acc) const {
+    acc_to_lds_split<1>(h + mt * 32 * LDAH, l + mt * 32 * LDAH, LDAH, col0, lane,
+                        *reinterpret_cast<const f32x16(*)[1]>(&acc));
+  }
+};
+
+struct WStream2 {
+  static constexpr int D = 6, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
+  struct BStep { f32x4 bh, bl; };
+  struct AStep { f32x4 ah[2], al[2]; };
+  BStep ring[D];
+  static constexpr int adv(int P) { return (P + NS) % D; }
+
+  template <int SLOT>
+  __device__ __forceinline__ void fetch(const f32x4* wh, const f32x4* wl, int step) {
+    ring[SLOT].bh = wh[step * 64];
+    ring[SLOT].bl = wl[step * 64];
+  }
+  template <int P, int J>
+  __device__ __forceinline__ void fetch_first(const f32x4* wh, const f32x4* wl) {
+    if constexpr (J < PRE) {
+      fetch<(P + J) % D>(wh, wl, J);
+      fetch_first<P, J + 1>(wh, wl);
+    }
+  }
+  // First PRE steps of the weight slab (n-tile nt0, k16-steps from ks0) of a matrix
+  // packed with KTOT/16 steps per n-tile.
+  template <int KTOT, int P>
+  __device__ __forceinline__ void prime(const f32x4* W, const f32x4* Wl, int nt0, int ks0, int lane) {
+    const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64 + lane;
+    fetch_first<P, 0>(W + off, Wl + off);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ static void load_a(AStep& a, const _Float16* ah_ptr, const _Float16* al_ptr,
+                                                int step) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      a.ah[mt] = *reinterpret_cast<const f32x4*>(ah_ptr + mt * 32 * LDAH + step * 16);
+      a.al[mt] = *reinterpret_cast<const f32x4*>(al_ptr + mt * 32 * LDAH + step * 16);
+    }
+  }
+  template <int P, bool HAS_NEXT, int CI>
+  __device__ __forceinline__ void step(const _Float16* ah_ptr, const _Float16* al_ptr,
+                                       const f32x4* wh, const f32x4* wl, const f32x4* nwh,
+                                       const f32x4* nwl, AStep (&a)[2], f32x16 (&acc)[2],
+                                       f32x16 (&cross)[2]) {
+    if constexpr (CI < NS) {
+      constexpr int PF = CI + PRE;
+      if constexpr (PF < NS) fetch<(P + PF) % D>(wh, wl, PF);
+      else if constexpr (HAS_NEXT) fetch<(P + PF) % D>(nwh, nwl, PF - NS);
+      if constexpr (CI + 1 < NS) load_a(a[(CI + 1) & 1], ah_ptr, al_ptr, CI + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const BStep& b = ring[(P + CI) % D];
+      const f16x8 bh = __builtin_bit_cast(f16x8, b.bh), bl = __builtin_bit_cast(f16x8, b.bl);
+      const f16x8 a0h = __builtin_bit_cast(f16x8, a[CI & 1].ah[0]), a1h = __builtin_bit_cast(f16x8, a[CI & 1].ah[1]);
+      const f16x8 a0l = __builtin_bit_cast(f16x8, a[CI & 1].al[0]), a1l = __builtin_bit_cast(f16x8, a[CI & 1].al[1]);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[1], 0, 0, 0);
+      cross[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[0], 0, 0, 0);
+      cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[1], 0, 0, 0);
+      cross[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[0], 0, 0, 0);
+      cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      step<P, HAS_NEXT, CI + 1>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross);
+    }
+  }
+  // acc[mt] += A[32*mt .. 32*mt+31][0..255] . Wslab^T  for this wave's n-tile.  The first
+  // PRE steps of the slab are already in the ring; HAS_NEXT: the next GEMM's slab
+  // (nW, nWl, nnt0, nks0 of a matrix with NKTOT/16 steps per n-tile) is primed meanwhile.
+  template <int KTOT, int P, bool HAS_NEXT, int NKTOT>
+  __device__ __forceinline__ void gemm(const Planes2& A, const f32x4* W, const f32x4* Wl, int nt0,
+                                       int ks0, int lane, f32x16 (&acc)[2], const f32x4* nW,
+                                       const f32x4* nWl, int nnt0, int nks0) {
+    const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64 + lane;
+    const size_t noff = ((size_t)nnt0 * (NKTOT / 16) + nks0) * 64 + lane;
+    const int a_off = (lane & 31) * LDAH + 8 * (lane >> 5);
+    const _Float16* ah_ptr = A.h + a_off;
+    const _Float16* al_ptr = A.l + a_off;
+    AStep a[2];
+    load_a(a[0], ah_ptr, al_ptr, 0);
+    f32x16 cross[2] = {f32x16{0}, f32x16{0}};
+    step<P, HAS_NEXT, 0>(ah_ptr, al_ptr, W + off, Wl + off, HAS_NEXT ? nW + noff : nullptr,
+                         HAS_NEXT ? nWl + noff : nullptr, a, acc, cross);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(cross[mt][r], SPLIT_INV, acc[mt][r]);
+  }
+};
+
+// phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
+__device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x16 (&accV)[2],
+                                            int S_len, int nvalid, int half, f32x16& kv,
+                                            float& ksum) {
+  // Branch-free phi (max(x,0) + exp(min(x,0)) == elu(x)+1 bit for bit: exp_neg(0) == 1) on
+  // scalars, four at a time: as a select hipcc branches per element (and, on the
+  // accumulator tuples, copies whole 16-register tuples around the branch); unfenced,
+  // it schedules all 32 exps at once and spills.
+  const float inv_len = 1.0f / (float)S_len;
+  kv = f32x16{0};
+  ksum = 0.f;
+  // (laundered: the row-validity tests are otherwise CSE'd with the residual loads' row
+  //  clamps at the top of the kernel and 32 values live - spilled - until here)
+  int nv2 = nvalid - 4 * half;
+  asm volatile("" : "+v"(nv2));
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+      float k[4], v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m = 32 * mt + crow(r0 + j, 0) < nv2 ? 1.0f : 0.0f;
+        const float x = accK[mt][r0 + j];
+        k[j] = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+        v[j] = accV[mt][r0 + j] * (inv_len * m);
+        ksum += k[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  ksum += __shfl_xor(ksum, 32, 64);
+}
+__device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int lane, int wave,
+                                               float* __restrict__ kv_out,
+                                               float* __restrict__ ks_out, int slot) {
+  f32x4* dst = reinterpret_cast<f32x4*>(kv_out) + ((size_t)slot * NH + wave) * 4 * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 o = {kv[4 * q], kv[4 * q + 1], kv[4 * q + 2], kv[4 * q + 3]};
+    dst[q * 64] = o;
+  }
+  if (lane < 32) ks_out[(size_t)slot * C + wave * HD + lane] = ksum;
+}
+
+template <bool HAS_B, int TAIL>
+__global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
+  constexpr int THREADS = 512, TPR = 8, F4 = 8;
+  __shared__ __attribute__((aligned(16))) float smem[E2_SMEM];
+  float* R1f = smem + E2_R1;
+  float* R2f = smem + E2_R2;
+  const Planes2 P1(R1f), P2(R2f);
+  float* ksum_s = smem + E2_KSUM;
+  float* z_s = smem + E2_Z;
+  float* lnp_s = smem + E2_LNP;
+  using WS = WStream2;
+  WS ws;
+  constexpr int P_MERGE = 0;
+  constexpr int P_1A = WS::adv(P_MERGE), P_2A = WS::adv(P_1A), P_1B = WS::adv(P_2A), P_2B = WS::adv(P_1B);
+  constexpr int P_T0 = HAS_B ? WS::adv(P_2B) : 0;
+  constexpr int P_T1 = WS::adv(P_T0), P_T2 = WS::adv(P_T1), P_T3 = WS::adv(P_T2);
+
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int wcol = 32 * wave;
+  const int lrow = tid / TPR, lpart = tid % TPR;
+
+  const int logical = xcd_remap(blockIdx.x, g.ntiles);
+  const int per = g.nt[0] + g.nt[1];
+  const int n = logical / per;
+  const int rem = logical - n * per;
+  const int side = rem >= g.nt[0];
+  const int t_idx = side ? rem - g.nt[0] : rem;
+  const int L = g.L[side];
+  const int l0 = t_idx * RT;
+  const int nvalid = min(RT, L - l0);
+  const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
+  const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
+
+  for (int i = tid; i < 6 * C; i += THREADS) {
+    const int which = i >> 8, c = i & (C - 1);
+    const float* src = which == 0 ? p.b.ln2_w : which == 1 ? p.b.ln2_b : which == 2 ? p.a.lnq_w
+                     : which == 3 ? p.a.lnq_b : which == 4 ? p.a.lnkv_w : p.a.lnkv_b;
+    const bool used = which < 2 ? HAS_B : TAIL == 0;
+    if (used) lnp_s[i] = src[c];
+  }
+  // position rows of this tile for the tail (issued early: nothing waits on them yet)
+  const f32x4* pos = reinterpret_cast<const f32x4*>(
+                         p.pos + (size_t)(g.prow0[side] + l0 + min(lrow, nvalid - 1)) * C) + lpart;
+
+  f32x16 xacc[2];  // residual stream of this wave's 32 columns, both row tiles (C layout)
+  PHASE_STAMP(p, 0);
+
+  if (HAS_B) {
+    const int ss = p.b_cross ? 1 - side : side;
+    const int S_len = g.L[ss];
+    const int nts = g.nt[ss];
+    const int src_slot0 = g.tile0[ss] + n * g.nt[ss];
+
+    // phi(Q) tile -> R2 (f32)
+#pragma unroll
+    for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {
+      const int idx = tid + THREADS * i;
+      const int r = idx >> 6, c4 = idx & 63;
+      *reinterpret_cast<f32x4*>(R2f + r * LDA + 4 * c4) =
+          reinterpret_cast<const f32x4*>(p.qp + (row_base + min(r, nvalid - 1)) * C)[c4];
+    }
+    // reduce the source image's partial KV states (fixed order) into B-operand order
+    f32x4 kvB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kvB[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int KVR = 7;
+      const f32x4* kvp = reinterpret_cast<const f32x4*>(p.kv_in) +
+                         ((size_t)src_slot0 * NH + wave) * 256 + lane;
+      const float* ksp = p.ks_in + (size_t)src_slot0 * C + (tid & (C - 1));
+      float ks = 0.f;
+      for (int ti0 = 0; ti0 < nts; ti0 += KVR) {
+        f32x4 tmp[KVR][4];
+        float kt[KVR];
+#pragma unroll
+        for (int u = 0; u < KVR; ++u) {
+          const int ti = min(ti0 + u, nts - 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tmp[u][e] = kvp[(size_t)ti * (NH * 256) + e * 64];
+          kt[u] = ksp[(size_t)ti * C];
+        }
+#pragma unroll
+        for (int u = 0; u < KVR; ++u)
+          if (ti0 + u < nts) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kvB[e] += tmp[u][e];
+            ks += kt[u];
+          }
+      }
+      if (tid < C) ksum_s[tid] = ks;
+    }
+    // residual x in accumulator layout (after the reduction: its 112 in-flight registers are free)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(32 * mt + crow(r, half), nvalid - 1);
+        xacc[mt][r] = p.x[(row_base + row) * C + wcol + col];
+      }
+    ws.template prime<C, P_MERGE>(p.b.wmerge, p.b.wmerge_l, wave, 0, lane);
+    __syncthreads();
+    PHASE_STAMP(p, 1);
+
+    {  // Z[row][h] = 1 / (phi(Q)[row,h,:] . Ksum[h,:] + eps): 64 rows x 8 heads = 512 threads
+      const int r = tid >> 3, h = tid & 7;
+      const f32x4* qrow = reinterpret_cast<const f32x4*>(R2f + r * LDA + h * HD);
+      const f32x4* kk = reinterpret_cast<const f32x4*>(ksum_s + h * HD);
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 a = qrow[i], b = kk[i];
+        dot += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+      }
+      z_s[r * NH + h] = 1.0f / (dot + ATTN_EPS);
+    }
+    __syncthreads();
+
+    // message = (phi(Q) . KV) * Z * S for head = wave -> R1 planes
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float zr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zr[r] = z_s[(32 * mt + crow(r, half)) * NH + wave];
+      f32x16 macc = {0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(R2f + (32 * mt + col) * LDA + wave * HD +
+                                                        4 * half + ks * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[ks][j], macc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) macc[r] = macc[r] * zr[r] * (float)S_len;
+      P1.put_acc(mt, wcol, lane, macc);
+    }
+    __syncthreads();
+    PHASE_STAMP(p, 2);
+
+    // x1 = x + message . Wmerge^T
+    ws.template gemm<C, P_MERGE, true, C>(P1, p.b.wmerge, p.b.wmerge_l, wave, 0, lane, xacc,
+                                          p.b.w1, p.b.w1_l, wave, 0);
+    __syncthreads();  // every wave is done reading the message planes
+    PHASE_STAMP(p, 3);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      acc_to_lds<1>(R1f + mt * 32 * LDA, LDA, wcol, lane, *reinterpret_cast<f32x16(*)[1]>(&xacc[mt]));
+    __syncthreads();
+    {  // LN2(x1), in place: f32 rows -> registers | barrier | f16 planes
+      f32x4 xn[F4];
+      ln_rows<TPR, F4>(R1f, tid, xn, 0);
+      __syncthreads();
+      const f32x4* gw = reinterpret_cast<const f32x4*>(lnp_s) + lpart;
+      const f32x4* gb = reinterpret_cast<const f32x4*>(lnp_s + C) + lpart;
+#pragma unroll
+      for (int i = 0; i < F4; ++i) P1.put4(lrow, 4 * (i * TPR + lpart), xn[i] * gw[i * TPR] + gb[i * TPR]);
+    }
+    __syncthreads();
+
+    PHASE_STAMP(p, 4);
+    // MLP in two hidden halves: hidden_h = gelu(LN2(x1) . W1[h]^T) -> R2 ; x += hidden_h . W2[:,h]^T
+    {
+      f32x16 hacc[2] = {f32x16{0}, f32x16{0}};
+      ws.template gemm<C, P_1A, true, FF>(P1, p.b.w1, p.b.w1_l, wave, 0, lane, hacc, p.b.w2,
+                                          p.b.w2_l, wave, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[mt][r] = gelu_erf(hacc[mt][r]);
+        P2.put_acc(mt, wcol, lane, hacc[mt]);
+      }
+    }
+    __syncthreads();
+    PHASE_STAMP(p, 5);
+    ws.template gemm<FF, P_2A, true, C>(P2, p.b.w2, p.b.w2_l, wave, 0, lane, xacc, p.b.w1, p.b.w1_l,
+                                        8 + wave, 0);
+    __syncthreads();  // hidden half a consumed
+    PHASE_STAMP(p, 6);
+    {
+      f32x16 hacc[2] = {f32x16{0}, f32x16{0}};
+      ws.template gemm<C, P_1B, true, FF>(P1, p.b.w1, p.b.w1_l, 8 + wave, 0, lane, hacc, p.b.w2,
+                                          p.b.w2_l, wave, 16);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[mt][r] = gelu_erf(hacc[mt][r]);
+        P2.put_acc(mt, wcol, lane, hacc[mt]);
+      }
+    }
+    __syncthreads();
+    PHASE_STAMP(p, 7);
+    ws.template gemm<FF, P_2B, (TAIL != 2), C>(P2, p.b.w2, p.b.w2_l, wave, 16, lane, xacc,
+                                               TAIL == 0 ? p.a.wq : p.d.wk[0],
+                                               TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], wave, 0);
+    {
+      // (pointer laundered: otherwise the 32 store addresses are CSE'd with the residual
+      //  loads' at the top of the kernel and live - spilled - across every GEMM)
+      int l2 = lane;
+      asm volatile("" : "+v"(l2));
+      float* xs = p.x + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
+      const int nv2 = nvalid - 4 * (l2 >> 5);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * mt + crow(r, 0);   // compile-time constant
+          if (row < nv2) xs[row * C] = xacc[mt][r];
+        }
+    }
+    PHASE_STAMP(p, 8);
+    if (TAIL == 2) return;
+    // (R1 planes were last read by MLP1b, which every wave finished before the barrier above)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      acc_to_lds<1>(R1f + mt * 32 * LDA, LDA, wcol, lane, *reinterpret_cast<f32x16(*)[1]>(&xacc[mt]));
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {  // first launch: x from HBM
+      const int idx = tid + THREADS * i;
+      const int r = idx >> 6, c4 = idx & 63;
+      *reinterpret_cast<f32x4*>(R1f + r * LDA + 4 * c4) =
+          reinterpret_cast<const f32x4*>(p.x + (row_base + min(r, nvalid - 1)) * C)[c4];
+    }
+    if (TAIL == 0) ws.template prime<C, P_T0>(p.a.wq, p.a.wq_l, wave, 0, lane);
+    if (TAIL == 1) ws.template prime<C, P_T0>(p.d.wk[0], p.d.wk_l[0], wave, 0, lane);
+    __syncthreads();
+  }
+
+  if (TAIL == 0) {
+    // ================= phase A: start layer l+1 =================
+    {
+      f32x4 xn[F4], ps[F4];
+#pragma unroll
+      for (int i = 0; i < F4; ++i) ps[i] = pos[i * TPR];
+      ln_rows<TPR, F4>(R1f, tid, xn, 0);
+      __syncthreads();
+      const f32x4* qw = reinterpret_cast<const f32x4*>(lnp_s + 2 * C) + lpart;
+      const f32x4* qb = reinterpret_cast<const f32x4*>(lnp_s + 3 * C) + lpart;
+      const f32x4* kw = reinterpret_cast<const f32x4*>(lnp_s + 4 * C) + lpart;
+      const f32x4* kb = reinterpret_cast<const f32x4*>(lnp_s + 5 * C) + lpart;
+#pragma unroll
+      for (int i = 0; i < F4; ++i) {
+        P1.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * qw[i * TPR] + qb[i * TPR]) + ps[i]);
+        P2.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * kw[i * TPR] + kb[i * TPR]) + ps[i]);
+      }
+    }
+    __syncthreads();
+    PHASE_STAMP(p, 9);
+    {  // phi(Q) -> HBM
+      f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+      ws.template gemm<C, P_T0, true, C>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, acc, p.a.wk, p.a.wk_l,
+                                         wave, 0);
+      int l2 = lane;  // laundered like the x store: no address CSE across the kernel
+      asm volatile("" : "+v"(l2));
+      float* qs = p.qp + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
+      const int nv2 = nvalid - 4 * (l2 >> 5);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * mt + crow(r, 0);
+          if (row < nv2) qs[row * C] = elu1(acc[mt][r]);
+        }
+    }
+    PHASE_STAMP(p, 10);
+    f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
+    ws.template gemm<C, P_T1, true, C>(P2, p.a.wk, p.a.wk_l, wave, 0, lane, accK, p.a.wv, p.a.wv_l,
+                                       wave, 0);
+    ws.template gemm<C, P_T2, false, C>(P2, p.a.wv, p.a.wv_l, wave, 0, lane, accV, nullptr, nullptr,
+                                        0, 0);
+    PHASE_STAMP(p, 11);
+    f32x16 kv;
+    float ksum;
+    kv_state_64(accK, accV, L, nvalid, half, kv, ksum);
+    kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
+    PHASE_STAMP(p, 12);
+  } else if (TAIL == 1) {
+    // ============ decoder preparation (transformer.py:240-246) ============
+    float bias_k[2], bias_v[2];
+#pragma unroll
+    for (int dl = 0; dl < 2; ++dl) {
+      bias_k[dl] = p.d.bk[dl][wcol + col];
+      bias_v[dl] = p.d.bv[dl][wcol + col];
+    }
+    {
+      f32x4 xv[F4], ps[F4];
+      const f32x4* src = reinterpret_cast<const f32x4*>(R1f + lrow * LDA) + lpart;
+#pragma unroll
+      for (int i = 0; i < F4; ++i) { xv[i] = src[i * TPR]; ps[i] = pos[i * TPR]; }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < F4; ++i) {
+        P1.put4(lrow, 4 * (i * TPR + lpart), xv[i] + ps[i]);  // k input: memory + pos
+        P2.put4(lrow, 4 * (i * TPR + lpart), xv[i]);          // v input: memory
+      }
+    }
+    __syncthreads();
+    auto dec_layer = [&](auto DL) {
+      constexpr int dl = decltype(DL)::value;
+      constexpr int PK = dl == 0 ? P_T0 : P_T2, PV = dl == 0 ? P_T1 : P_T3;
+      f32x16 accK[2], accV[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accK[mt][r] = bias_k[dl]; accV[mt][r] = bias_v[dl]; }
+      ws.template gemm<C, PK, true, C>(P1, p.d.wk[dl], p.d.wk_l[dl], wave, 0, lane, accK, p.d.wv[dl],
+                                       p.d.wv_l[dl], wave, 0);
+      // (no run-ahead across the state epilogue below: K, V, the state and the exp
+      //  temporaries already fill the register file; layer 1's K slab is primed after it)
+      ws.template gemm<C, PV, false, C>(P2, p.d.wv[dl], p.d.wv_l[dl], wave, 0, lane, accV, nullptr,
+                                        nullptr, 0, 0);
+      f32x16 kv;
+      float ksum;
+      kv_state_64(accK, accV, L, nvalid, half, kv, ksum);
+      if constexpr (dl == 1) {
+        kv_state_write(kv, ksum, lane, wave, p.dkv1_out, p.dks1_out, slot);
+      } else {
+        // partial message / normaliser of decoder layer 0's cross-attention (see k_encoder)
+        const float* q0 = p.dec_q0 + side * C + wave * HD;
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += q0[crow(r, half)] * kv[r];
+        a += __shfl_xor(a, 32, 64);
+        float z = q0[col] * ksum;
+        z += __shfl_xor(z, 1, 64);
+        z += __shfl_xor(z, 2, 64);
+        z += __shfl_xor(z, 4, 64);
+        z += __shfl_xor(z, 8, 64);
+        z += __shfl_xor(z, 16, 64);
+        if (half == 0) p.att0_out[(size_t)slot * C + wave * HD + col] = a;
+        if (lane == 0) p.z0_out[(size_t)slot * NH + wave] = z;
+        ws.template prime<C, P_T2>(p.d.wk[1], p.d.wk_l[1], wave, 0, lane);
+      }
+    };
+    dec_layer(std::integral_constant<int, 0>{});
+    dec_layer(std::integral_constant<int, 1>{});
+  }
+}
+
 #ifndef OETR_SPLIT_WAVES
 #define OETR_SPLIT_WAVES 8
 #endif
@@ -523,6 +1035,20 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 
 hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, bool split, hipStream_t s) {
   const dim3 grid(p.g.ntiles);
+  if (split && p.tile_rows == RT) {
+#define OETR_LAUNCH64(B, T) hipLaunchKernelGGL((k_encoder64<B, T>), grid, dim3(512), 0, s, p)
+    if (has_b) {
+      if (tail == 0) OETR_LAUNCH64(true, 0);
+      else if (tail == 1) OETR_LAUNCH64(true, 1);
+      else OETR_LAUNCH64(true, 2);
+    } else {
+      if (tail == 0) OETR_LAUNCH64(false, 0);
+      else if (tail == 1) OETR_LAUNCH64(false, 1);
+      else return hipErrorInvalidValue;
+    }
+#undef OETR_LAUNCH64
+    return hipGetLastError();
+  }
 #define OETR_LAUNCH(B, T)                                                                      \
   do {                                                                                         \
     if (split)                                                                                 \

@@ -68,7 +68,7 @@ EXPORTS = (
     'oetr_full_attention', 'oetr_trace_create', 'oetr_trace_destroy',
     'oetr_set_trace', 'oetr_trace_summary', 'oetr_neck_create',
     'oetr_neck_destroy', 'oetr_neck_workspace_bytes', 'oetr_neck_forward',
-    'oetr_neck_set_trace')
+    'oetr_neck_set_trace', 'oetr_set_encoder_tile')
 
 
 def hot_path_keys():
@@ -166,6 +166,8 @@ def load_library(path=None):
     lib.oetr_trace_summary.restype = i
     lib.oetr_trace_summary.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_char_p),
                                        C.POINTER(i), C.POINTER(C.c_float)]
+    lib.oetr_set_encoder_tile.restype = i
+    lib.oetr_set_encoder_tile.argtypes = [vp, i]
     lib.oetr_neck_create.restype = i
     lib.oetr_neck_create.argtypes = [C.POINTER(_NeckWeights), i, C.POINTER(vp)]
     lib.oetr_neck_destroy.restype = None
@@ -217,10 +219,11 @@ class HotPathEngine:
     #: GEMM arithmetic modes (oetr_dtype in the header)
     PRECISIONS = {'f32': 0, 'f32_split_f16': 1}
 
-    def __init__(self, weights, device=None, precision='f32_split_f16'):
+    def __init__(self, weights, device=None, precision='f32_split_f16', enc_tile=None):
         """``precision``: 'f32' = exact fp32 MFMA products; 'f32_split_f16' =
         fp32-class results from 3 f16 MFMAs per product (default; same parity
-        tolerances, ~2x faster)."""
+        tolerances, ~2x faster).  ``enc_tile``: token rows per encoder
+        workgroup, None = auto, 32 or 64 (``oetr_set_encoder_tile``)."""
         self.lib = load_library()
         if precision not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {sorted(self.PRECISIONS)}')
@@ -282,6 +285,8 @@ class HotPathEngine:
                                               C.byref(handle)), 'oetr_create')
         self._h = handle
         self._ws = {}
+        if enc_tile is not None:
+            self.set_encoder_tile(enc_tile)
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -290,6 +295,11 @@ class HotPathEngine:
                 self.lib.oetr_destroy(h)
             except Exception:
                 pass
+
+    def set_encoder_tile(self, rows):
+        """0/None = auto, 32 or 64 token rows per encoder workgroup."""
+        _check(self.lib, self.lib.oetr_set_encoder_tile(self._h, int(rows or 0)),
+               'oetr_set_encoder_tile')
 
     # ------------------------------------------------------------ helpers
     def workspace(self, n, hf1, wf1, hf2, wf2):

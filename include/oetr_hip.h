@@ -124,6 +124,15 @@ oetr_status oetr_create(const oetr_weights *w, oetr_dtype dtype, int device,
                         oetr_handle *out);
 void oetr_destroy(oetr_handle h);
 
+/* Token rows per encoder workgroup: 0 = auto (default), 32 or 64.  64 exists in
+ * the OETR_DTYPE_F32_SPLIT_F16 mode only (ignored otherwise): fewer
+ * CU-microseconds per token, half as many workgroups - the better shape once the
+ * grid exceeds the chip (auto), or when several batches are in flight on
+ * different streams.  Results do not depend on it beyond fp32 summation order
+ * of the per-tile partial states.  Mutates the handle: call it outside
+ * concurrent forward calls. */
+oetr_status oetr_set_encoder_tile(oetr_handle h, int rows);
+
 /* Bytes of workspace a forward call needs for this shape (256-B aligned
  * device buffer).  Returns 0 on invalid shape. */
 size_t oetr_workspace_bytes(oetr_handle h, int n_pairs, int hf1, int wf1,

@@ -51,7 +51,9 @@ def check_stages(out, ref, note=''):
         assert (iou[area > 1] >= 1 - 1e-3).all(), f'{note} IoU {iou}'
 
 
-PRECISIONS = ['f32_split_f16', 'f32']   # default (3 f16 MFMAs per product) and exact-f32 MFMA
+# default (3 f16 MFMAs per product; encoder tile auto = 32 rows at these sizes), the same with
+# the 64-row encoder workgroups forced, and exact-f32 MFMA
+PRECISIONS = ['f32_split_f16', 'f32_split_f16@64', 'f32']
 
 
 @pytest.fixture(scope='module')
@@ -62,8 +64,9 @@ def engines(gpu):
     def get(seed, sharpen, precision='f32_split_f16'):
         key = (seed, sharpen, precision)
         if key not in cache:
-            cache[key] = HotPathEngine(orc.make_hot_weights(seed, sharpen=sharpen),
-                                       device=gpu, precision=precision)
+            prec, _, tile = precision.partition('@')
+            cache[key] = HotPathEngine(orc.make_hot_weights(seed, sharpen=sharpen), device=gpu,
+                                       precision=prec, enc_tile=int(tile) if tile else None)
         return cache[key]
     return get
 

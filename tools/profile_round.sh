@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-e2e --no-trace --steps 50 --warmup 5"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-e2e --no-trace --streams 1 --steps 50 --warmup 5"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 # PMC in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
