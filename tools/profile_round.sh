@@ -16,6 +16,8 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o pmc -- $BENCH > $OUT/pmc_lds.log 2>&1
+# the default (value) mode of bench.py: batches overlapped on 3 streams, 64-row encoder tiles
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/overlap_trace -o trace -- python $ROOT/bench.py --no-cpu-baseline --no-e2e --no-trace --steps 50 --warmup 5 > $OUT/overlap_trace.log 2>&1
 # neck: 16 backbone maps of 40x40 through the HIP neck
 NECK="python $ROOT/tools/neck_bench.py 16 40"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/neck_trace -o trace -- $NECK > $OUT/neck_trace.log 2>&1
@@ -24,7 +26,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/neck_pmc_write -o 
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/neck_pmc_lds -o pmc -- $NECK > $OUT/neck_pmc_lds.log 2>&1
 cd $ROOT
 # summarise on the box; the raw rocpd databases are too big to carry back
-for d in trace neck_trace; do
+for d in trace overlap_trace neck_trace; do
   db=$(find $OUT/$d -name "*.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_summary.py $db $OUT/${d}_kernel_stats.csv > /dev/null
 done
 for d in pmc_fetch pmc_write pmc_sq pmc_lds neck_pmc_fetch neck_pmc_write neck_pmc_lds; do
