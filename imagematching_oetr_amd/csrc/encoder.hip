@@ -555,8 +555,11 @@ struct Planes2 {  // two f16 planes [RT][LDAH] (hi, lo*2^11) in one region
   }
 };
 
+#ifndef OETR_RING2
+#define OETR_RING2 4   // k16 steps of B fragments in the ring (one being consumed)
+#endif
 struct WStream2 {
-  static constexpr int D = 6, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
+  static constexpr int D = OETR_RING2, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
   struct BStep { f32x4 bh, bl; };
   struct AStep { f32x4 ah[2], al[2]; };
   BStep ring[D];
@@ -854,7 +857,11 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[mt][r] = gelu_erf(hacc[mt][r]);
+        for (int r0 = 0; r0 < 16; r0 += 4) {  // four at a time: bounded register pressure
+#pragma unroll
+          for (int r = r0; r < r0 + 4; ++r) hacc[mt][r] = gelu_erf(hacc[mt][r]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         P2.put_acc(mt, wcol, lane, hacc[mt]);
       }
     }
@@ -871,7 +878,11 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[mt][r] = gelu_erf(hacc[mt][r]);
+        for (int r0 = 0; r0 < 16; r0 += 4) {  // four at a time: bounded register pressure
+#pragma unroll
+          for (int r = r0; r < r0 + 4; ++r) hacc[mt][r] = gelu_erf(hacc[mt][r]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         P2.put_acc(mt, wcol, lane, hacc[mt]);
       }
     }
