@@ -12,11 +12,19 @@ With N > 1 (torchrun, one rank per GPU) every rank runs its own batch of 8
 (weak scaling) and each step ends with the RCCL all-gather of the per-pair
 boxes - the only collective on the path.
 
-Rank 0 prints ONE JSON line (see README/DESIGN.md §6 for the fields).
-``roofline`` describes the dominant kernel (k_encoder<B,A>, 7 of the 13
-launches of a step): durations come from HIP events recorded by the library
-on its launch stream during the timed region.  ``cpu_baseline`` is the oracle
-(torch CPU restatement of the reference) timed on this box's host cores.
+The K timed steps are run three times:
+  1. ``value`` / ``ms_per_step``: consecutive steps alternate over ``--streams``
+     HIP streams (default 3) with 64-token encoder workgroups, so the next
+     batch's kernels fill the CUs a batch of 8 pairs leaves idle.  Every step
+     still pushes its whole batch through the whole path inside the region.
+  2. ``serial``: the same steps strictly one after the other on one stream
+     (library-default tile shape) - the batch latency.
+  3. the traced pass: serial, with HIP events recorded by the library around
+     every launch on its launch stream -> ``roofline`` for the dominant kernel
+     (k_encoder<B,A>, 7 of the 13 launches of a step) and ``kernels_us``.
+
+Rank 0 prints ONE JSON line.  ``cpu_baseline`` is the oracle (torch CPU
+restatement of the reference) timed on this box's host cores.
 """
 import argparse
 import json
@@ -255,6 +263,9 @@ def main():
                    'parallelism': f'pairs sharded over {world} rank(s); '
                                   'all-gather of boxes only'},
         'hot_path_tflops': round(value * PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800 / 1e3, 2),
+        'hot_path_frac_of_mfma_peak': round(
+            value * PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800 / 1e3
+            / (F16_MFMA_PEAK_TFLOPS / 3 if args.precision == 'f32_split_f16' else F32_MFMA_PEAK_TFLOPS), 4),
         # the same K steps strictly one after the other on one stream (batch latency;
         # encoder tile = library default, which is also what the traced pass below runs)
         'serial': {'ms_per_step': round(elapsed_serial / args.steps * 1e3, 4),

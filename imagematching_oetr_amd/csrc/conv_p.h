@@ -54,4 +54,66 @@ __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restri
   }
 }
 
+// 64-token variant (split mode): every weight fragment of the 9 taps (2.3 MB per
+// workgroup) feeds two MFMA row tiles, and the weight stream runs ahead from tap to
+// tap.  Tiles are 64 consecutive tokens of one image: tile index over
+// N x (ceil(L0/64) + ceil(L1/64)), pair-major like the encoder's.
+__device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __restrict__ P, int tile,
+                                              float* smem) {
+  static_assert(WStream2::D == 4, "tap loop below assumes a ring phase of 0 after every GEMM");
+  constexpr int THREADS = 512, TPR = THREADS / RT, F4 = 64 / TPR;
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
+  const int logical = xcd_remap(tile, g.N * (nt0 + nt1));
+  const int per = nt0 + nt1;
+  const int n = logical / per;
+  const int rem = logical - n * per;
+  const int side = rem >= nt0;
+  const int t_idx = side ? rem - nt0 : rem;
+  const int L = g.L[side];
+  const int l0 = t_idx * RT;
+  const int nvalid = min(RT, L - l0);
+  const float* mem = p.mem[side] + ((size_t)n * L + l0) * C;
+  const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
+
+  const Planes2 A(smem);
+  {
+    const int r = tid / TPR, part = tid % TPR;
+    const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)min(r, nvalid - 1) * C) + part;
+#pragma unroll
+    for (int i = 0; i < F4; ++i) A.put4(r, 4 * (i * TPR + part), mp[i * TPR]);
+  }
+  WStream2 ws;
+  ws.template prime<C, 0>(p.w.conv_w, p.w.conv_w_l, wave, 0, lane);
+  __syncthreads();
+  constexpr size_t TAP_UNITS = (size_t)C * C / 8;
+  float* dst0 = P + row_base * C + 32 * wave + col + (size_t)4 * half * C;
+  const int nv2 = nvalid - 4 * half;
+  auto store = [&](int tap, const f32x16 (&acc)[2]) {
+    float* dst = dst0 + (size_t)tap * g.rows * C;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * mt + crow(r, 0);
+        if (row < nv2) dst[(size_t)row * C] = acc[mt][r];
+      }
+  };
+#pragma unroll 1
+  for (int tap = 0; tap < 8; ++tap) {
+    f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+    const f32x4* w = p.w.conv_w + tap * TAP_UNITS;
+    const f32x4* wl = p.w.conv_w_l + tap * TAP_UNITS;
+    ws.template gemm<C, 0, true, C>(A, w, wl, wave, 0, lane, acc, w + TAP_UNITS, wl + TAP_UNITS, wave, 0);
+    store(tap, acc);
+  }
+  {
+    f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+    ws.template gemm<C, 0, false, C>(A, p.w.conv_w + 8 * TAP_UNITS, p.w.conv_w_l + 8 * TAP_UNITS, wave,
+                                     0, lane, acc, nullptr, nullptr, 0, 0);
+    store(8, acc);
+  }
+}
+
 }  // namespace oetr

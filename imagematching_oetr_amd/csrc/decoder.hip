@@ -423,20 +423,27 @@ hipError_t launch_decoder(const DecLaunch& p, hipStream_t s) {
 // Decoder (blocks [0, 2N)) and conv P tiles (blocks [2N, 2N + ntiles)) in one
 // launch: the decoder occupies 2N CUs for ~50 us while the P GEMMs fill the rest
 // of the chip; decoder blocks come first in the grid so they are dispatched first.
-template <bool SPLIT>
+template <bool SPLIT, bool T64>
 __global__ __launch_bounds__(512) void k_decoder_convp(DecLaunch d, HeatLaunch h, float* P) {
-  constexpr int LDS_FLOATS = DecSmem<512>::TOTAL > TILE_FLOATS ? DecSmem<512>::TOTAL : TILE_FLOATS;
+  constexpr int TILE = T64 ? R_FLOATS : TILE_FLOATS;
+  constexpr int LDS_FLOATS = DecSmem<512>::TOTAL > TILE ? DecSmem<512>::TOTAL : TILE;
   __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
   const int nd = 2 * d.g.N;
   if ((int)blockIdx.x < nd) decoder_body<512>(d, blockIdx.x, smem);
+  else if constexpr (T64) conv_p_body64(h, P, blockIdx.x - nd, smem);
   else conv_p_body<SPLIT>(h, P, blockIdx.x - nd, smem);
 }
 
 hipError_t launch_decoder_convp(const DecLaunch& d, const HeatLaunch& h, float* P, bool split,
                                 hipStream_t s) {
-  const dim3 grid(2 * d.g.N + h.g.ntiles);  // h.g: 32-row tiles (d.g may use the encoder's 64)
-  if (split) hipLaunchKernelGGL(k_decoder_convp<true>, grid, dim3(512), 0, s, d, h, P);
-  else hipLaunchKernelGGL(k_decoder_convp<false>, grid, dim3(512), 0, s, d, h, P);
+  // conv-P tiles: 64 tokens in split mode when the encoder runs 64-token workgroups too
+  // (d.g carries the encoder's tile bookkeeping), else TM tokens (h.g)
+  const bool t64 = split && d.g.ntiles != h.g.ntiles;
+  const int ptiles = t64 ? h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT) : h.g.ntiles;
+  const dim3 grid(2 * d.g.N + ptiles);
+  if (t64) hipLaunchKernelGGL((k_decoder_convp<true, true>), grid, dim3(512), 0, s, d, h, P);
+  else if (split) hipLaunchKernelGGL((k_decoder_convp<true, false>), grid, dim3(512), 0, s, d, h, P);
+  else hipLaunchKernelGGL((k_decoder_convp<false, false>), grid, dim3(512), 0, s, d, h, P);
   return hipGetLastError();
 }
 

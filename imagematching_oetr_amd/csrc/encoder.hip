@@ -532,115 +532,12 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 // The per-wave weight stream (WStream2) is a ring of 6 k16-steps of B fragments
 // (5 in flight) running ahead across GEMM calls like WStream.
 // ===========================================================================
-constexpr int RT = 64;                                   // token rows per workgroup
-constexpr int R_FLOATS = (2 * RT * LDAH * 2 + 3) / 4;    // 16896 >= RT * LDA = 16640
-static_assert(R_FLOATS >= RT * LDA, "region holds the f32 tile too");
 constexpr int E2_R1 = 0;
 constexpr int E2_R2 = R_FLOATS;
 constexpr int E2_KSUM = 2 * R_FLOATS;
 constexpr int E2_Z = E2_KSUM + C;
 constexpr int E2_LNP = E2_Z + RT * NH;
 constexpr int E2_SMEM = E2_LNP + 6 * C;                  // 36096 floats = 141 KB
-
-struct Planes2 {  // two f16 planes [RT][LDAH] (hi, lo*2^11) in one region
-  _Float16 *h, *l;
-  __device__ __forceinline__ explicit Planes2(float* base)
-      : h(reinterpret_cast<_Float16*>(base)), l(reinterpret_cast<_Float16*>(base) + RT * LDAH) {}
-  __device__ __forceinline__ void put4(int row, int c, const f32x4& v) const {
-    store_split4(h + row * LDAH, l + row * LDAH, c, v);
-  }
-  __device__ __forceinline__ void put_acc(int mt, int col0, int lane, const f32x16& acc) const {
-    acc_to_lds_split<1>(h + mt * 32 * LDAH, l + mt * 32 * LDAH, LDAH, col0, lane,
-                        *reinterpret_cast<const f32x16(*)[1]>(&acc));
-  }
-};
-
-#ifndef OETR_RING2
-#define OETR_RING2 4   // k16 steps of B fragments in the ring (one being consumed)
-#endif
-struct WStream2 {
-  static constexpr int D = OETR_RING2, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
-  struct BStep { f32x4 bh, bl; };
-  struct AStep { f32x4 ah[2], al[2]; };
-  BStep ring[D];
-  static constexpr int adv(int P) { return (P + NS) % D; }
-
-  template <int SLOT>
-  __device__ __forceinline__ void fetch(const f32x4* wh, const f32x4* wl, int step) {
-    ring[SLOT].bh = wh[step * 64];
-    ring[SLOT].bl = wl[step * 64];
-  }
-  template <int P, int J>
-  __device__ __forceinline__ void fetch_first(const f32x4* wh, const f32x4* wl) {
-    if constexpr (J < PRE) {
-      fetch<(P + J) % D>(wh, wl, J);
-      fetch_first<P, J + 1>(wh, wl);
-    }
-  }
-  // First PRE steps of the weight slab (n-tile nt0, k16-steps from ks0) of a matrix
-  // packed with KTOT/16 steps per n-tile.
-  template <int KTOT, int P>
-  __device__ __forceinline__ void prime(const f32x4* W, const f32x4* Wl, int nt0, int ks0, int lane) {
-    const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64 + lane;
-    fetch_first<P, 0>(W + off, Wl + off);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __device__ __forceinline__ static void load_a(AStep& a, const _Float16* ah_ptr, const _Float16* al_ptr,
-                                                int step) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      a.ah[mt] = *reinterpret_cast<const f32x4*>(ah_ptr + mt * 32 * LDAH + step * 16);
-      a.al[mt] = *reinterpret_cast<const f32x4*>(al_ptr + mt * 32 * LDAH + step * 16);
-    }
-  }
-  template <int P, bool HAS_NEXT, int CI>
-  __device__ __forceinline__ void step(const _Float16* ah_ptr, const _Float16* al_ptr,
-                                       const f32x4* wh, const f32x4* wl, const f32x4* nwh,
-                                       const f32x4* nwl, AStep (&a)[2], f32x16 (&acc)[2],
-                                       f32x16 (&cross)[2]) {
-    if constexpr (CI < NS) {
-      constexpr int PF = CI + PRE;
-      if constexpr (PF < NS) fetch<(P + PF) % D>(wh, wl, PF);
-      else if constexpr (HAS_NEXT) fetch<(P + PF) % D>(nwh, nwl, PF - NS);
-      if constexpr (CI + 1 < NS) load_a(a[(CI + 1) & 1], ah_ptr, al_ptr, CI + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const BStep& b = ring[(P + CI) % D];
-      const f16x8 bh = __builtin_bit_cast(f16x8, b.bh), bl = __builtin_bit_cast(f16x8, b.bl);
-      const f16x8 a0h = __builtin_bit_cast(f16x8, a[CI & 1].ah[0]), a1h = __builtin_bit_cast(f16x8, a[CI & 1].ah[1]);
-      const f16x8 a0l = __builtin_bit_cast(f16x8, a[CI & 1].al[0]), a1l = __builtin_bit_cast(f16x8, a[CI & 1].al[1]);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[1], 0, 0, 0);
-      cross[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[0], 0, 0, 0);
-      cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[1], 0, 0, 0);
-      cross[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[0], 0, 0, 0);
-      cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      step<P, HAS_NEXT, CI + 1>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross);
-    }
-  }
-  // acc[mt] += A[32*mt .. 32*mt+31][0..255] . Wslab^T  for this wave's n-tile.  The first
-  // PRE steps of the slab are already in the ring; HAS_NEXT: the next GEMM's slab
-  // (nW, nWl, nnt0, nks0 of a matrix with NKTOT/16 steps per n-tile) is primed meanwhile.
-  template <int KTOT, int P, bool HAS_NEXT, int NKTOT>
-  __device__ __forceinline__ void gemm(const Planes2& A, const f32x4* W, const f32x4* Wl, int nt0,
-                                       int ks0, int lane, f32x16 (&acc)[2], const f32x4* nW,
-                                       const f32x4* nWl, int nnt0, int nks0) {
-    const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64 + lane;
-    const size_t noff = ((size_t)nnt0 * (NKTOT / 16) + nks0) * 64 + lane;
-    const int a_off = (lane & 31) * LDAH + 8 * (lane >> 5);
-    const _Float16* ah_ptr = A.h + a_off;
-    const _Float16* al_ptr = A.l + a_off;
-    AStep a[2];
-    load_a(a[0], ah_ptr, al_ptr, 0);
-    f32x16 cross[2] = {f32x16{0}, f32x16{0}};
-    step<P, HAS_NEXT, 0>(ah_ptr, al_ptr, W + off, Wl + off, HAS_NEXT ? nW + noff : nullptr,
-                         HAS_NEXT ? nWl + noff : nullptr, a, acc, cross);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(cross[mt][r], SPLIT_INV, acc[mt][r]);
-  }
-};
 
 // phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
 __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x16 (&accV)[2],
