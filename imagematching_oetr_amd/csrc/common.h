@@ -164,6 +164,47 @@ __device__ __forceinline__ float gelu_erf(float x) {
 #endif
 }
 
+// Two GELUs per instruction stream: the polynomial chains run as v_pk_fma_f32
+// (packed fp32, 2 lanes of work per VALU slot); same operations in the same order
+// as gelu_erf (results agree to the last rounding of the packed/scalar code paths).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+#ifdef OETR_OCML_ERF
+  return f32x2{gelu_erf(v[0]), gelu_erf(v[1])};
+#else
+  const f32x2 x = v * splat2(0.70710678118654752440f);
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 t = __builtin_elementwise_min(ax, splat2(4.0f));
+  const f32x2 s = x * x;
+  f32x2 p = splat2(8.404849575e-05f);
+  p = __builtin_elementwise_fma(p, s, splat2(-8.151340561e-04f));
+  p = __builtin_elementwise_fma(p, s, splat2(5.201837672e-03f));
+  p = __builtin_elementwise_fma(p, s, splat2(-2.685974483e-02f));
+  p = __builtin_elementwise_fma(p, s, splat2(1.128370225e-01f));
+  p = __builtin_elementwise_fma(p, s, splat2(-3.761263422e-01f));
+  p = __builtin_elementwise_fma(p, s, splat2(1.283791667e-01f));
+  const f32x2 small_v = __builtin_elementwise_fma(x, p, x);
+  f32x2 r = splat2(4.358980029e-07f);
+  r = __builtin_elementwise_fma(r, t, splat2(-7.196586003e-06f));
+  r = __builtin_elementwise_fma(r, t, splat2(2.439359676e-05f));
+  r = __builtin_elementwise_fma(r, t, splat2(3.708157171e-04f));
+  r = __builtin_elementwise_fma(r, t, splat2(-5.214545892e-03f));
+  r = __builtin_elementwise_fma(r, t, splat2(3.451753623e-02f));
+  r = __builtin_elementwise_fma(r, t, splat2(-1.537478043e-01f));
+  r = __builtin_elementwise_fma(r, t, splat2(-9.159608808e-01f));
+  r = __builtin_elementwise_fma(r, t, splat2(-1.628399401e+00f));
+  const f32x2 tr = t * r;
+  f32x2 e;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float large_v = copysignf(1.0f - __builtin_amdgcn_exp2f(tr[i]), x[i]);
+    e[i] = ax[i] <= 0.92f ? small_v[i] : large_v;
+  }
+  return (splat2(0.5f) * v) * (splat2(1.0f) + e);
+#endif
+}
+
 // XCD-aware bijective remap: hardware block b runs on XCD b % 8; give each
 // XCD a contiguous run of logical tiles so tiles of one image pair share an L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

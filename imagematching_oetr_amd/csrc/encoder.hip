@@ -356,7 +356,12 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[t][r] = ABL(p.dbg, ABL_GELU) ? hacc[t][r] : gelu_erf(hacc[t][r]);
+        for (int r = 0; r < 16; r += 2) {
+          if (ABL(p.dbg, ABL_GELU)) continue;
+          const f32x2 ge = gelu_erf2(f32x2{hacc[t][r], hacc[t][r + 1]});
+          hacc[t][r] = ge[0];
+          hacc[t][r + 1] = ge[1];
+        }
       Hh.template put_acc<NT>(2 * wcol, lane, hacc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) hacc[t] = f32x16{0};
@@ -365,7 +370,12 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[t][r] = ABL(p.dbg, ABL_GELU) ? hacc[t][r] : gelu_erf(hacc[t][r]);
+        for (int r = 0; r < 16; r += 2) {
+          if (ABL(p.dbg, ABL_GELU)) continue;
+          const f32x2 ge = gelu_erf2(f32x2{hacc[t][r], hacc[t][r + 1]});
+          hacc[t][r] = ge[0];
+          hacc[t][r + 1] = ge[1];
+        }
       Hh.template put_acc<NT>(2 * wcol + WC, lane, hacc);
     }
     __syncthreads();
@@ -756,7 +766,11 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 4) {  // four at a time: bounded register pressure
 #pragma unroll
-          for (int r = r0; r < r0 + 4; ++r) hacc[mt][r] = gelu_erf(hacc[mt][r]);
+          for (int r = r0; r < r0 + 4; r += 2) {
+            const f32x2 ge = gelu_erf2(f32x2{hacc[mt][r], hacc[mt][r + 1]});
+            hacc[mt][r] = ge[0];
+            hacc[mt][r + 1] = ge[1];
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         P2.put_acc(mt, wcol, lane, hacc[mt]);
@@ -777,7 +791,11 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 4) {  // four at a time: bounded register pressure
 #pragma unroll
-          for (int r = r0; r < r0 + 4; ++r) hacc[mt][r] = gelu_erf(hacc[mt][r]);
+          for (int r = r0; r < r0 + 4; r += 2) {
+            const f32x2 ge = gelu_erf2(f32x2{hacc[mt][r], hacc[mt][r + 1]});
+            hacc[mt][r] = ge[0];
+            hacc[mt][r + 1] = ge[1];
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         P2.put_acc(mt, wcol, lane, hacc[mt]);

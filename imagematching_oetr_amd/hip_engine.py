@@ -474,7 +474,7 @@ class NeckEngine:
         _check(self.lib, self.lib.oetr_neck_create(C.byref(w), device.index, C.byref(handle)),
                'oetr_neck_create')
         self._h = handle
-        self._ws = None
+        self._ws = {}
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -494,11 +494,13 @@ class NeckEngine:
         need = self.lib.oetr_neck_workspace_bytes(self._h, n, hb, wb)
         if need == 0:
             raise ValueError(f'invalid neck shape n={n} grid {hb}x{wb}')
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        key = torch.cuda.current_stream(self.device).cuda_stream   # one workspace per stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         feat = torch.empty(n, D_MODEL, hb // 2, wb // 2, device=self.device)
         _check(self.lib, self.lib.oetr_neck_forward(
-            self._h, x.data_ptr(), n, hb, wb, self._ws.data_ptr(), self._ws.numel(),
+            self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
             feat.data_ptr(), _stream()), 'oetr_neck_forward')
         return feat
 

@@ -75,6 +75,7 @@ def test_neck_workspace_query_and_errors_need_no_gpu():
 
 def test_null_arguments_are_rejected_not_crashed():
     lib = pkg.load_library()
+    assert lib.oetr_set_encoder_tile(None, 64) == 1 and b'NULL' in lib.oetr_last_error()
     st = lib.oetr_forward(None, None, None, None, None, 1, 20, 20, 20, 20, 640,
                           640, 640, 640, None, 0, None, None, None)
     assert st == 1 and b'NULL' in lib.oetr_last_error()
