@@ -15,11 +15,12 @@ engines = {}
 bad = 0
 for case in range(ncase):
     wseed, sharp = rng.randrange(4), rng.random() < 0.5
-    prec = rng.choice(['f32_split_f16', 'f32'])
+    prec = rng.choice(['f32_split_f16', 'f32_split_f16@64', 'f32'])
     key = (wseed, sharp, prec)
     w = orc.make_hot_weights(wseed, sharpen=sharp)
     if key not in engines:
-        engines[key] = pkg.HotPathEngine(w, device=dev, precision=prec)
+        pr, _, tile = prec.partition('@')
+        engines[key] = pkg.HotPathEngine(w, device=dev, precision=pr, enc_tile=int(tile) if tile else None)
     eng = engines[key]
     n = rng.randrange(1, 6)
     g1 = (rng.randrange(1, 41), rng.randrange(1, 41))
