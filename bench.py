@@ -294,7 +294,7 @@ def main():
             'traced_ms_per_step': round(elapsed_traced / args.steps * 1e3, 4)}
         out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
                              for k, v in kern.items()}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # host-core baseline: rank 0 at N=1 only
         base, ref_boxes = cpu_baseline(weights, feat1, feat2, args.size, size2)
         out['cpu_baseline'] = base
         from oracle import oetr_oracle as orc
@@ -303,7 +303,7 @@ def main():
                          orc.bbox_iou_aligned(mine[1].cpu(), ref_boxes[1])])
         out['iou_vs_cpu_min'] = round(float(iou.min()), 6)
         out['speedup_vs_cpu'] = round(value / base['value'], 1)
-    if not args.no_e2e:
+    if not args.no_e2e and world == 1:
         try:     # whole forward_dummy incl. the PyTorch/MIOpen backbone (host code)
             model = model.to(device)
             g = torch.Generator().manual_seed(2)
