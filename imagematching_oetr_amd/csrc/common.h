@@ -672,7 +672,14 @@ struct WStream2 {
   struct BStep { f32x4 bh, bl; };
   struct AStep { f32x4 ah[2], al[2]; };
   BStep ring[D];
+  // false: the tile has <= 32 valid rows (ragged last tile of an image) and the MFMAs of
+  // the second row tile are skipped; its accumulators keep their finite initial values,
+  // which every consumer masks by row validity.  Wave-uniform (an SGPR branch).
+  bool two = true;
   static constexpr int adv(int P) { return (P + NS) % D; }
+  __device__ __forceinline__ void set_rows(int nvalid) {
+    two = __builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0) != 0;
+  }
 
   template <int SLOT>
   __device__ __forceinline__ void fetch(const f32x4* wh, const f32x4* wl, int step) {
@@ -718,11 +725,11 @@ struct WStream2 {
       const f16x8 a0h = __builtin_bit_cast(f16x8, a[CI & 1].ah[0]), a1h = __builtin_bit_cast(f16x8, a[CI & 1].ah[1]);
       const f16x8 a0l = __builtin_bit_cast(f16x8, a[CI & 1].al[0]), a1l = __builtin_bit_cast(f16x8, a[CI & 1].al[1]);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[1], 0, 0, 0);
+      if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[1], 0, 0, 0);
       cross[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[0], 0, 0, 0);
-      cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[1], 0, 0, 0);
+      if (two) cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[1], 0, 0, 0);
       cross[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[0], 0, 0, 0);
-      cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[1], 0, 0, 0);
+      if (two) cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       step<P, HAS_NEXT, CI + 1>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross);
     }

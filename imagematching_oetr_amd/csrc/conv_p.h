@@ -85,6 +85,7 @@ __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __rest
     for (int i = 0; i < F4; ++i) A.put4(r, 4 * (i * TPR + part), mp[i * TPR]);
   }
   WStream2 ws;
+  ws.set_rows(nvalid);
   ws.template prime<C, 0>(p.w.conv_w, p.w.conv_w_l, wave, 0, lane);
   __syncthreads();
   constexpr size_t TAP_UNITS = (size_t)C * C / 8;

@@ -628,6 +628,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
   const int nvalid = min(RT, L - l0);
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
+  ws.set_rows(nvalid);
 
   for (int i = tid; i < 6 * C; i += THREADS) {
     const int which = i >> 8, c = i & (C - 1);
