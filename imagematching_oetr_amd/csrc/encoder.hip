@@ -551,7 +551,7 @@ constexpr int E2_SMEM = E2_LNP + 6 * C;                  // 36096 floats = 141 K
 
 // phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
 __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x16 (&accV)[2],
-                                            int S_len, int nvalid, int half, f32x16& kv,
+                                            int S_len, int nvalid, int half, bool two, f32x16& kv,
                                             float& ksum) {
   // Branch-free phi (max(x,0) + exp(min(x,0)) == elu(x)+1 bit for bit: exp_neg(0) == 1) on
   // scalars, four at a time: as a select hipcc branches per element (and, on the
@@ -565,7 +565,8 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
   int nv2 = nvalid - 4 * half;
   asm volatile("" : "+v"(nv2));
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < 2; ++mt) {
+    if (mt == 1 && !two) break;  // no valid row in the second row tile
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += 4) {
       float k[4], v[4];
@@ -581,6 +582,7 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
       for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
   ksum += __shfl_xor(ksum, 32, 64);
 }
 __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int lane, int wave,
@@ -717,6 +719,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     // message = (phi(Q) . KV) * Z * S for head = wave -> R1 planes
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+      if (mt == 1 && !ws.two) break;  // ragged tile: rows 32.. are never stored
       float zr[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) zr[r] = z_s[(32 * mt + crow(r, half)) * NH + wave];
@@ -764,6 +767,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
                                           p.b.w2_l, wave, 0);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !ws.two) break;  // (hidden rows 32.. stay unwritten: never consumed)
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 4) {  // four at a time: bounded register pressure
 #pragma unroll
@@ -789,6 +793,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
                                           p.b.w2_l, wave, 16);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !ws.two) break;  // (hidden rows 32.. stay unwritten: never consumed)
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 4) {  // four at a time: bounded register pressure
 #pragma unroll
@@ -871,12 +876,14 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
       float* qs = p.qp + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
       const int nv2 = nvalid - 4 * (l2 >> 5);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !ws.two) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = 32 * mt + crow(r, 0);
           if (row < nv2) qs[row * C] = elu1(acc[mt][r]);
         }
+      }
     }
     PHASE_STAMP(p, 10);
     f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     PHASE_STAMP(p, 11);
     f32x16 kv;
     float ksum;
-    kv_state_64(accK, accV, L, nvalid, half, kv, ksum);
+    kv_state_64(accK, accV, L, nvalid, half, ws.two, kv, ksum);
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
   } else if (TAIL == 1) {
@@ -927,7 +934,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
                                         nullptr, 0, 0);
       f32x16 kv;
       float ksum;
-      kv_state_64(accK, accV, L, nvalid, half, kv, ksum);
+      kv_state_64(accK, accV, L, nvalid, half, ws.two, kv, ksum);
       if constexpr (dl == 1) {
         kv_state_write(kv, ksum, lane, wave, p.dkv1_out, p.dks1_out, slot);
       } else {
