@@ -113,21 +113,32 @@ struct EncCfg {
   static constexpr int F4 = 64 / TPR;       // float4 per thread per row
 };
 
-// phi(K) and V/S in place (rows past the image end zeroed); returns sum_rows phi(K).
-// values / v_length (linear_attention.py:44) is a multiply by the reciprocal:
-// <= 1 ulp from the division, 1 instruction instead of ~10.
-__device__ __forceinline__ float phi_k_scale_v(f32x16& accK, f32x16& accV, bool skip_phi,
-                                               int S_len, int nvalid, int half) {
+// phi(K)^T (V/S) (32x32, one head) and the per-lane partial of sum phi(K) for one 32-row
+// tile, straight from the K and V accumulators.  phi branch-free (max(x,0) + exp(min(x,0))
+// == elu(x)+1 bit for bit) on scalars, four at a time between sched_barriers: as a select
+// hipcc branches per element (with whole-tuple copies when done in place), unfenced it
+// schedules all exps at once and spills.
+__device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& accV, bool skip_phi,
+                                            int S_len, int nvalid, int half, f32x16& kv,
+                                            float& ksum) {
   const float inv_len = 1.0f / (float)S_len;
-  float ksum = 0.f;
+  kv = f32x16{0};
+  ksum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const bool ok = crow(r, half) < nvalid;
-    accK[r] = ok ? (skip_phi ? accK[r] : elu1(accK[r])) : 0.f;
-    accV[r] = ok ? accV[r] * inv_len : 0.f;
-    ksum += accK[r];
+  for (int r0 = 0; r0 < 16; r0 += 4) {
+    float k[4], v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float m = crow(r0 + j, half) < nvalid ? 1.0f : 0.0f;
+      const float x = accK[r0 + j];
+      k[j] = (skip_phi ? x : fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+      v[j] = accV[r0 + j] * (inv_len * m);
+      ksum += k[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  return ksum;
 }
 
 // phi(K)^T (V/S) for this wave's heads straight from the K and V accumulators,
@@ -140,11 +151,9 @@ __device__ __forceinline__ void kv_state_store(f32x16 (&accK)[NT], f32x16 (&accV
   const int half = lane >> 5;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    float ksum = phi_k_scale_v(accK[t], accV[t], skip_phi, S_len, nvalid, half);
-    f32x16 kv = {0};
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      kv = __builtin_amdgcn_mfma_f32_32x32x2f32(accK[t][r], accV[t][r], kv, 0, 0, 0);
+    float ksum;
+    f32x16 kv;
+    kv_state_32(accK[t], accV[t], skip_phi, S_len, nvalid, half, kv, ksum);
     const int h = NT * wave + t;
     f32x4* dst = reinterpret_cast<f32x4*>(kv_out) + ((size_t)slot * NH + h) * 4 * 64 + lane;
 #pragma unroll
@@ -497,11 +506,9 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int h = NT * wave + t;
-          float ksum = phi_k_scale_v(accK[t], accV[t], false, L, nvalid, half);
-          f32x16 kv = {0};
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(accK[t][r], accV[t][r], kv, 0, 0, 0);
+          float ksum;
+          f32x16 kv;
+          kv_state_32(accK[t], accV[t], false, L, nvalid, half, kv, ksum);
           const float* q0 = p.dec_q0 + side * C + h * HD;
           float a = 0.f;
 #pragma unroll
