@@ -256,12 +256,13 @@ def test_split_mode_is_fp32_class(gpu, engines):
         assert err <= max(8 * drift32, floor), (key, err, drift32)
 
 
-def test_properties_at_bench_size(gpu, engines):
-    """N=8, 640x640 (BASELINE configs[1]): size-independent properties.
-    Pairs are independent, so permuting / slicing the batch permutes / slices
-    the boxes bit-exactly; swapping the two sides with the query embeddings
-    untouched is NOT symmetric, so only per-side checks are made."""
-    eng = engines(3, True)
+@pytest.mark.parametrize('precision', ['f32_split_f16', 'f32_split_f16@64'])
+def test_properties_at_bench_size(gpu, engines, precision):
+    """N=8, 640x640 (BASELINE configs[1]), both encoder workgroup shapes:
+    size-independent properties.  Pairs are independent, so permuting / slicing the
+    batch permutes / slices the boxes bit-exactly; swapping the two sides with the
+    query embeddings untouched is NOT symmetric, so only per-side checks are made."""
+    eng = engines(3, True, precision)
     n = 8
     f1, f2 = orc.make_features(41, n, 20, 20).to(gpu), orc.make_features(42, n, 20, 20).to(gpu)
     p = orc.position_table(20, 20).to(gpu)
