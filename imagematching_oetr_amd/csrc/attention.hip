@@ -72,23 +72,19 @@ __global__ __launch_bounds__(256) void k_lin_apply(const float* __restrict__ q,
   }
 }
 
-static float* g_lin_state = nullptr;  // scratch for the stand-alone entry
-static size_t g_lin_state_floats = 0;
-
 hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n, int L,
                                    int S, float* out, hipStream_t s) {
-  // The stand-alone test entry keeps a small device scratch (n*8 states of 1056 floats).
+  // The stand-alone test entry needs n*8 states of 1056 floats between its two kernels:
+  // a stream-ordered temporary (no global state, nothing outlives the call).
+  float* state = nullptr;
   const size_t need = (size_t)n * NH * (HD * HD + HD);
-  if (need > g_lin_state_floats) {
-    if (g_lin_state) (void)hipFree(g_lin_state);
-    hipError_t e = hipMalloc(&g_lin_state, need * sizeof(float));
-    if (e != hipSuccess) { g_lin_state = nullptr; g_lin_state_floats = 0; return e; }
-    g_lin_state_floats = need;
-  }
-  hipLaunchKernelGGL(k_lin_state, dim3(n * NH), dim3(256), 0, s, k, v, S, g_lin_state);
-  hipLaunchKernelGGL(k_lin_apply, dim3((L + 63) / 64, n * NH), dim3(256), 0, s, q, g_lin_state,
-                     L, S, out);
-  return hipGetLastError();
+  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&state), need * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_lin_state, dim3(n * NH), dim3(256), 0, s, k, v, S, state);
+  hipLaunchKernelGGL(k_lin_apply, dim3((L + 63) / 64, n * NH), dim3(256), 0, s, q, state, L, S, out);
+  e = hipGetLastError();
+  const hipError_t e2 = hipFreeAsync(state, s);
+  return e != hipSuccess ? e : e2;
 }
 
 // -------------------------------------------------------------------- full

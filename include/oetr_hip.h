@@ -200,8 +200,9 @@ oetr_status oetr_box_tlbr_to_xyxy(const float *cxy, const float *tlbr, int n,
 /* Replaces: LinearAttention.forward (reference
  * src/models/linear_attention.py:22-50), masks None.  Stand-alone entry for
  * parity tests of the attention core.  q [N][L][8][32], k,v [N][S][8][32],
- * out [N][L][8][32].  (Unlike the forward entry points this test entry keeps
- * a lazily grown internal scratch of n*8 states: not graph-capturable.) */
+ * out [N][L][8][32].  (Unlike the forward entry points this test entry takes
+ * no workspace: it uses a stream-ordered temporary, hipMallocAsync/hipFreeAsync
+ * on `stream`, for its n*8 states.) */
 oetr_status oetr_linear_attention(const float *q, const float *k,
                                   const float *v, int n, int L, int S,
                                   float *out, void *stream);
