@@ -115,6 +115,8 @@ class OETR(nn.Module):
         self.softmax_temperature = 1
         #: GEMM arithmetic of the HIP hot path: 'f32_split_f16' (default) or 'f32'
         self.hip_precision = 'f32_split_f16'
+        #: token rows per encoder workgroup: None = auto, 32 or 64 (HotPathEngine.set_encoder_tile)
+        self.hip_enc_tile = None
         #: run input_proj -> PatchMerging -> input_proj2 as HIP kernels when the
         #: features are on a GPU (False: the torch modules, as on CPU)
         self.hip_neck = True
@@ -157,7 +159,8 @@ class OETR(nn.Module):
         """HIP engine bound to the current hot-path weights; rebuilt when a
         weight tensor was replaced or written in place."""
         params = [self.get_parameter(k) for k in hot_path_keys()]
-        key = (self.hip_precision,) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (self.hip_precision, self.hip_enc_tile) + tuple(
+            (p.data_ptr(), p._version) for p in params)
         if self._engine is None or key != self._engine_key:
             dev = params[0].device
             if dev.type != 'cuda':
@@ -165,7 +168,8 @@ class OETR(nn.Module):
                     'OETR hot path needs the model on a GPU (HIP) device; '
                     f'weights are on {dev}. There is no CPU implementation.')
             self._engine = HotPathEngine(self.hot_path_state(), device=dev,
-                                         precision=self.hip_precision)
+                                         precision=self.hip_precision,
+                                         enc_tile=self.hip_enc_tile)
             self._engine_key = key
         return self._engine
 
