@@ -13,6 +13,12 @@ GOLDEN = REPO / 'tests' / 'golden'
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the '
                             'driver with `-m gpu` on the GPU box)')
+    # The oracle runs on torch CPU.  On a small shared build container OpenMP teams get
+    # their vCPUs preempted mid-barrier and a 40 s suite turns into 7 minutes; the
+    # tensors are small, so one thread is both the fastest and the only predictable
+    # choice there.  The GPU box (hundreds of idle cores) keeps a modest team.
+    import torch
+    torch.set_num_threads(8 if torch.cuda.is_available() else 1)
 
 
 @pytest.fixture(scope='session')
