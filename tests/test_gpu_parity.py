@@ -283,10 +283,11 @@ def test_properties_at_bench_size(gpu, engines, precision):
     assert (orc.bbox_iou_aligned(b2.cpu(), r2) >= 1 - 1e-3).all()
 
 
-def test_forward_is_hipgraph_capturable(gpu, engines):
+@pytest.mark.parametrize('precision', ['f32_split_f16', 'f32_split_f16@64'])
+def test_forward_is_hipgraph_capturable(gpu, engines, precision):
     """The ABI promises enqueue-only calls (no allocation / sync inside): a
     forward captured into a HIP graph must replay bit-identically."""
-    eng = engines(1, True)
+    eng = engines(1, True, precision)
     n = 4
     f1, f2 = orc.make_features(61, n, 20, 20).to(gpu), orc.make_features(62, n, 15, 12).to(gpu)
     p1, p2 = orc.position_table(20, 20).to(gpu), orc.position_table(15, 12).to(gpu)
@@ -312,7 +313,7 @@ def test_batches_on_two_streams_overlap_safely(gpu, engines):
     """One engine, consecutive batches alternating over two HIP streams (one
     workspace per stream): every batch must equal its single-stream result bit
     for bit, however the launches interleave on the chip."""
-    eng = engines(1, True)
+    eng = engines(1, True, 'f32_split_f16@64')   # the shape the overlapped bench mode uses
     n = 8
     feats = [(orc.make_features(70 + i, n, 20, 20).to(gpu), orc.make_features(80 + i, n, 20, 20).to(gpu))
              for i in range(4)]
