@@ -1,39 +1,53 @@
 #!/usr/bin/env python
 """Benchmark of the OETR hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--precision P]
 
 A *step* is one pass of the hot path (feature maps -> overlap boxes:
 feature-correlation transformer + centre/size heads, reference
 ``src/model.py:239-252``) over one batch of synthetic 640x640 pairs per GPU,
-with the backbone feature maps already resident in HBM.  Workload = BASELINE
-configs[1]: batch of 8 pairs, 640x640 (20x20 = 400 tokens per image), fp32.
-With N > 1 (torchrun, one rank per GPU) every rank runs its own batch of 8
-(weak scaling) and each step ends with the RCCL all-gather of the per-pair
-boxes - the only collective on the path.
+with the backbone feature maps already resident in HBM.  Default workload =
+BASELINE configs[1]: batch of 8 pairs, 640x640 (20x20 = 400 tokens per image),
+fp32 (``--precision f32_split_f16``: fp32-class products from f16 MFMAs).
+``--precision bf16`` is the per-GPU share of configs[2] (64 pairs over 8 GPUs,
+"bf16 MFMA attention"), ``--precision f16 --size2 1280`` that of configs[4].
 
-The K timed steps are run three times:
+N > 1: one rank per GPU.  Started WITHOUT a launcher (``python bench.py --gpus
+4``) the script re-executes itself under ``torch.distributed.run`` with N ranks;
+started under torchrun it checks WORLD_SIZE == N.  It exits non-zero rather than
+report fewer GPUs than asked for.  Every rank runs its own batch (weak scaling)
+and each step ends with the RCCL all-gather of the per-pair boxes - the only
+collective on the path; ``n_gpus`` in the output is the process group's size.
+
+Timed regions (each: barrier + synchronize, exactly K steps, barrier +
+synchronize, max over ranks) are repeated ``--repeats`` times and the MEDIAN
+region is reported (min / max alongside): a 20-step region lasts ~7 ms, too
+short to be stable alone.  Regions:
   1. ``value`` / ``ms_per_step``: consecutive steps alternate over ``--streams``
      HIP streams (default 3) with 64-token encoder workgroups, so the next
      batch's kernels fill the CUs a batch of 8 pairs leaves idle.  Every step
      still pushes its whole batch through the whole path inside the region.
   2. ``serial``: the same steps strictly one after the other on one stream
-     (library-default tile shape) - the batch latency.
-  3. the traced pass: serial, with HIP events recorded by the library around
-     every launch on its launch stream -> ``roofline`` for the dominant kernel
-     (k_encoder<B,A>, 7 of the 13 launches of a step) and ``kernels_us``.
+     (library-default tile shape, 32 token rows at this size) - batch latency.
+  3. traced passes (serial, HIP events recorded by the library around every
+     launch on its launch stream): ``roofline`` describes the dominant kernel
+     IN THE SHAPE THAT PRODUCED ``value`` (64-token workgroups); the 32-token
+     kernel of the serial mode is under ``serial.roofline``.
+  4. ``exact_f32``: the same workload on an OETR_DTYPE_F32 handle (true fp32 MFMA
+     products), timed the same way, so the strict-fp32 figure is driver-timed too.
 
 Rank 0 prints ONE JSON line.  ``cpu_baseline`` is the oracle (torch CPU
-restatement of the reference) timed on this box's host cores.
+restatement of the reference) timed on this box's host cores (rank 0, N=1).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import torch
 
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
@@ -43,11 +57,84 @@ ENC_FLOP_PER_TOKEN = 16 * 256 * 256 + 4 * 256 * 32   # one B;A l
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 DOMINANT = 'k_encoder<B,A>'
+MODE_ID = {'f32': 0, 'f32_split_f16': 1, 'f16': 2, 'bf16': 3}
+
+# MFMA products executed per algorithmic product, and the pipe they run on
+MFMA_COST = {'f32': (1, F32_MFMA_PEAK_TFLOPS, 'f32 MFMA (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s'),
+             'f32_split_f16': (3, F16_MFMA_PEAK_TFLOPS,
+                               'dense f16 MFMA 2500 TFLOP/s / 3 MFMA products per fp32-class product'),
+             'f16': (1, F16_MFMA_PEAK_TFLOPS, 'dense f16 MFMA 2500 TFLOP/s'),
+             'bf16': (1, F16_MFMA_PEAK_TFLOPS, 'dense bf16 MFMA 2500 TFLOP/s')}
+GEMM_MODE_TEXT = {
+    'f32': 'exact fp32 MFMA',
+    'f32_split_f16': 'fp32-class products from 3 f16 MFMAs (a=ah+al/2^11 split), fp32 accumulate',
+    'f16': 'GEMM operands rounded to f16, one MFMA per product, fp32 accumulate / LN / softmax / residual',
+    'bf16': 'GEMM operands rounded to bf16, one MFMA per product, fp32 accumulate / LN / softmax / residual'}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--repeats', type=int, default=9,
+                    help='timed regions of --steps steps each; the median region is reported')
+    ap.add_argument('--pairs-per-gpu', type=int, default=8)
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--size2', type=int, default=None,
+                    help='side of image2 (default: same as --size); BASELINE configs[4] = 1280')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true')
+    ap.add_argument('--no-exact-f32', action='store_true',
+                    help='skip the exact-fp32 comparison leg (N=1, default precision only)')
+    ap.add_argument('--precision', default='f32_split_f16', choices=sorted(MODE_ID),
+                    help='GEMM arithmetic: 3 f16 MFMAs per fp32 product (default, fp32-class), exact '
+                         'f32 MFMA, or operands rounded to f16 / bf16 (one MFMA per product)')
+    ap.add_argument('--no-trace', action='store_true',
+                    help='do not record per-kernel events (no roofline block)')
+    ap.add_argument('--streams', type=int, default=3,
+                    help='HIP streams the consecutive steps (batches) alternate over: a step of 8 '
+                         'pairs fills 208 of 256 CUs, the next batch on a second stream fills the '
+                         'rest.  1 = strictly serial steps (also always reported)')
+    ap.add_argument('--enc-tile', type=int, default=0, choices=[0, 32, 64],
+                    help='token rows per encoder workgroup (0: 64 while batches overlap on several '
+                         'streams - fewest CU-microseconds per token - and the library default, '
+                         '32 at this size, for the serial pass)')
+    ap.add_argument('--kernel', default=None, choices=[None, 'full_attention'],
+                    help='micro-benchmark of one stand-alone kernel instead of the hot path')
+    ap.add_argument('--L', type=int, default=1024, help='--kernel full_attention: tokens per image')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks ourselves."""
+    import torch
+    backend = os.environ.get('OETR_BENCH_BACKEND', 'nccl')
+    have = torch.cuda.device_count()
+    if backend == 'nccl' and have < args.gpus:
+        print(f'[bench] --gpus {args.gpus} but only {have} GPU(s) visible: refusing to run a '
+              f'smaller job under that label', file=sys.stderr)
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def synthetic_inputs(pairs, size, size2, device):
     """Random-init weights of the architecture + uniform features with the
     spread of the real extraction path (std ~0.29).  No oracle involved."""
+    import torch
     import imagematching_oetr_amd as pkg
     torch.manual_seed(0)
     model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
@@ -66,6 +153,7 @@ def cpu_baseline(weights, feat1, feat2, size, size2, budget_s=12.0):
     torch's intra-op pool is tried at a few sizes first (small tensors stop
     scaling long before a 100+-core host is full; more threads only add
     synchronisation cost) and the fastest one is used and reported."""
+    import torch
     from oracle import oetr_oracle as orc
     f1, f2 = feat1.cpu(), feat2.cpu()
     w = {k: v.cpu() for k, v in weights.items()}
@@ -93,71 +181,139 @@ def cpu_baseline(weights, feat1, feat2, size, size2, budget_s=12.0):
                 cores=best_t, kind='port',
                 sample=f'{iters} batches of {f1.shape[0]} pairs @ {size}x{size}'
                        + (f' vs {size2}x{size2} ' if size2 != size else ' ')
-                       +
-                       f'(hot path only, features precomputed) in {dt:.1f} s; '
+                       + f'(hot path only, features precomputed) in {dt:.1f} s; '
                        f'oracle/oetr_oracle.py on torch CPU, {best_t} intra-op '
                        f'threads (best of 4..64 on a {ncpu}-CPU host)'), boxes
 
 
-def pmc_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the latest committed
-    rocprofv3 PMC passes (profiles/*_pmc_fetch.csv / *_pmc_write.csv, made by
-    tools/profile_round.sh with this same bench command; counters cannot be
-    read from inside the process).  Per MI355X_MICROARCH.md §HBM: FETCH_SIZE
-    and WRITE_SIZE are in KiB and FETCH_SIZE under-reports wide coalesced
-    reads by 2x on gfx950, so bytes = (2*FETCH + WRITE) * 1024."""
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the latest COMMITTED rocprofv3 PMC passes
+    (profiles/*_pmc_fetch.csv / *_pmc_write.csv, made by tools/profile_round.sh with this
+    bench command on the same workload; the counters cannot be read from inside the
+    process, so this is the builder's measurement replayed - `traffic_source` names the
+    files).  Per MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB and
+    FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, so
+    bytes = (2*FETCH + WRITE) * 1024.  Returns (bytes, source) or (None, None)."""
     import csv
     import glob
-    out = {}
+    out, src = {}, []
     for kind in ('fetch', 'write'):
         files = sorted(glob.glob(str(REPO / 'profiles' / f'*_pmc_{kind}.csv')))
         if not files:
-            return None
+            return None, None
         with open(files[-1]) as f:
             for row in csv.DictReader(f):
                 if kernel_substr in row['kernel']:
                     out[kind] = float(row['FETCH_SIZE' if kind == 'fetch' else 'WRITE_SIZE'])
+        src.append('profiles/' + Path(files[-1]).name)
     if len(out) != 2:
+        return None, None
+    return int((2 * out['fetch'] + out['write']) * 1024), ' + '.join(src)
+
+
+def mangled_encoder(tile, mode_id):
+    """Substring of the B;A encoder kernel's mangled name in rocprofv3 CSVs."""
+    if tile == 64:
+        return f'k_encoder64ILb1ELi0ELi{mode_id}EE'
+    return f'k_encoderILb1ELi0ELi{mode_id}ELi{4 if mode_id == 0 else 8}EE'
+
+
+def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload):
+    if not kern or DOMINANT not in kern:
         return None
-    return int((2 * out['fetch'] + out['write']) * 1024)
+    launches, total_ms = kern[DOMINANT]
+    avg_ms = total_ms / launches
+    flop = ENC_FLOP_PER_TOKEN * tokens            # algorithmic, both sides
+    cost, pipe_peak, basis = MFMA_COST[precision]
+    # `achieved` is ALGORITHMIC FLOP/s; the MFMA roof for a scheme that spends `cost`
+    # MFMA products per algorithmic product is the pipe's dense peak / cost.
+    peak = pipe_peak / cost
+    ach = flop / (avg_ms * 1e-3) / 1e12
+    block = {
+        'kernel': ('k_encoder64<B,A>' if tile == 64 else 'k_encoder<B,A>') + f' [{precision}]',
+        'tile_rows': tile, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1),
+        'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'peak_basis': basis,
+        'executed_mfma_tflops': round(ach * cost, 2),
+        'avg_launch_us': round(avg_ms * 1e3, 2), 'launches': launches, 'flop_per_launch': flop,
+        'share_of_step': round(total_ms / (traced_s * 1e3), 4),
+        'traced_ms_per_step': round(traced_s / steps * 1e3, 4)}
+    traffic, src = (pmc_traffic(mangled_encoder(tile, MODE_ID[precision]))
+                    if standard_workload else (None, None))
+    block['traffic'] = traffic
+    if traffic is not None:
+        block['traffic_source'] = src + ' (committed rocprofv3 PMC passes of this command, not read in-run)'
+    return block
+
+
+def bench_full_attention(args, device):
+    """--kernel full_attention: the stand-alone flash-style FullAttention kernel
+    (reference src/models/linear_attention.py:53-87), n = --pairs-per-gpu images, L = S."""
+    import torch
+    import imagematching_oetr_amd as pkg
+    n, L = args.pairs_per_gpu, args.L
+    g = torch.Generator().manual_seed(5)
+    q = ((torch.rand(n, L, 8, 32, generator=g) - 0.5) * 4).to(device)
+    k = ((torch.rand(n, L, 8, 32, generator=g) - 0.5) * 4).to(device)
+    v = ((torch.rand(n, L, 8, 32, generator=g) - 0.5) * 2).to(device)
+    flop = 4.0 * n * 8 * L * L * 32          # QK^T + PV, 2*MAC
+    out = {'metric': f'FullAttention (all-pairs {L}x{L} softmax(QK^T)V, 8 heads x 32) launches/s',
+           'unit': 'TFLOP/s (algorithmic)', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+           'higher_is_better': True, 'data': 'synthetic', 'vs_baseline': None,
+           'config': {'workload': f'{n} images, L=S={L}, 8 heads, D=32, fp32 in/out'}}
+    variants = {}
+    for name in pkg.FULL_ATTENTION_VARIANTS:
+        fn = lambda: pkg.full_attention(q, k, v, variant=name)
+        for _ in range(args.warmup):
+            fn()
+        regions = []
+        for _ in range(args.repeats):
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(args.steps):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            regions.append(ev0.elapsed_time(ev1) / args.steps)
+        ms = statistics.median(regions)
+        cost, pipe_peak, basis = MFMA_COST['f32' if name == 'f32' else 'f32_split_f16']
+        ach = flop / (ms * 1e-3) / 1e12
+        variants[name] = {'avg_launch_us': round(ms * 1e3, 2), 'achieved': round(ach, 2),
+                          'peak': round(pipe_peak / cost, 1), 'frac': round(ach / (pipe_peak / cost), 4),
+                          'unit': 'TFLOP/s', 'bound': 'mfma', 'peak_basis': basis}
+    best = max(variants, key=lambda k_: variants[k_]['achieved'])
+    out['value'] = variants[best]['achieved']
+    out['ms_per_step'] = variants[best]['avg_launch_us'] / 1e3
+    out['dtype'] = 'f32'
+    out['roofline'] = dict(kernel=f'k_full_attention [{best}]', **variants[best])
+    out['variants'] = variants
+    print(json.dumps(out))
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--pairs-per-gpu', type=int, default=8)
-    ap.add_argument('--size', type=int, default=640)
-    ap.add_argument('--size2', type=int, default=None,
-                    help='side of image2 (default: same as --size); BASELINE configs[4] = 1280')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-e2e', action='store_true')
-    ap.add_argument('--precision', default='f32_split_f16', choices=['f32_split_f16', 'f32'],
-                    help='GEMM arithmetic: 3 f16 MFMAs per fp32 product (default) or exact f32 MFMA')
-    ap.add_argument('--no-trace', action='store_true',
-                    help='do not record per-kernel events in the timed region')
-    ap.add_argument('--streams', type=int, default=3,
-                    help='HIP streams the consecutive steps (batches) alternate over: a step of 8 '
-                         'pairs fills 208 of 256 CUs, the next batch on a second stream fills the '
-                         'rest.  1 = strictly serial steps (also always reported)')
-    ap.add_argument('--enc-tile', type=int, default=0, choices=[0, 32, 64],
-                    help='token rows per encoder workgroup (0: 64 while batches overlap on several '
-                         'streams - fewest CU-microseconds per token - and the library default, '
-                         '32 at this size, for the serial / traced passes)')
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
 
+    import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus and rank == 0:
-        print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with '
-              f'torchrun --nproc-per-node {args.gpus}', file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with '
+                  f'`python bench.py --gpus {args.gpus}` (self-spawning) or torchrun '
+                  f'--nproc-per-node {args.gpus}', file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
     # (dry runs of the N>1 logic on a 1-GPU box: OETR_BENCH_BACKEND=gloo maps every
     #  rank onto the GPUs that exist; the real launch is one rank per GPU over RCCL)
     backend = os.environ.get('OETR_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and torch.cuda.device_count() < world:
+        if rank == 0:
+            print(f'[bench] {world} ranks but {torch.cuda.device_count()} GPU(s)', file=sys.stderr)
+        sys.exit(2)
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
@@ -167,42 +323,46 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()          # what actually came up
+    torch.set_grad_enabled(False)
+
+    if args.kernel == 'full_attention':
+        return bench_full_attention(args, device)
 
     import imagematching_oetr_amd as pkg
     from imagematching_oetr_amd.parallel import BoxGatherer
-    torch.set_grad_enabled(False)
     n = args.pairs_per_gpu
     size2 = args.size2 or args.size
     model, weights, feat1, feat2, pos, pos2, hf, hf2 = synthetic_inputs(n, args.size, size2, device)
-    eng = pkg.HotPathEngine(weights, device=device, precision=args.precision)
     hw, hw2 = (args.size, args.size), (size2, size2)
     n_total = n * world
+    tokens = n * (hf * hf + hf2 * hf2)
+    standard = (n, args.size, size2) == (8, 640, 640)
 
     gatherer = BoxGatherer() if world > 1 else None
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
-
-    def step(i=0, ns=1):
-        # consecutive steps alternate over the streams (one workspace per stream in
-        # the engine); every step is a full batch of n pairs through the whole path
-        with torch.cuda.stream(streams[i % ns]):
-            b1, b2 = eng.forward(feat1, feat2, pos, pos2, hw, hw2)
-            if gatherer is not None:
-                # the all-gather of this batch's boxes runs on RCCL's stream under the
-                # next batch's kernels; it is completed at the next submit / the flush
-                gatherer.submit(b1, b2)
-        return b1, b2
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region(ns):
+    def run_mode(eng, ns):
+        """One timed region: exactly --steps steps over `ns` streams."""
+        def step(i):
+            # consecutive steps alternate over the streams (one workspace per stream in
+            # the engine); every step is a full batch of n pairs through the whole path
+            with torch.cuda.stream(streams[i % ns]):
+                b1, b2 = eng.forward(feat1, feat2, pos, pos2, hw, hw2)
+                if gatherer is not None:
+                    # the all-gather of this batch's boxes runs on RCCL's stream under the
+                    # next batch's kernels; it is completed at the next submit / the flush
+                    gatherer.submit(b1, b2)
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(i, ns)
+            step(i)
         if gatherer is not None:
             gatherer.flush()            # last batch's gather is inside the timed region
         barrier()
@@ -213,87 +373,126 @@ def main():
             dt = float(t.item())
         return dt
 
-    split = args.precision == 'f32_split_f16'
-    tile_overlap = args.enc_tile or (64 if (n_streams > 1 and split) else 0)
-    eng.set_encoder_tile(args.enc_tile)
-    for i in range(args.warmup):
-        step(i, 1)
-    eng.set_encoder_tile(tile_overlap)
-    for i in range(args.warmup):
-        step(i, n_streams)
-    elapsed = timed_region(n_streams)     # -> value (no instrumentation)
-    eng.set_encoder_tile(args.enc_tile)
-    elapsed_serial = timed_region(1) if n_streams > 1 else elapsed
-    kern, elapsed_traced = {}, None
-    if not args.no_trace:
-        # Same K steps again, on ONE stream (kernel durations are only meaningful
-        # when launches do not share the chip), with the library's per-kernel HIP
-        # events recorded on its launch stream.  The events themselves cost ~9% of
-        # a step, so this pass feeds `roofline` only; its wall time is reported too.
+    def warm(eng, ns):
+        saved, args.steps = args.steps, max(1, args.warmup)
+        run_mode(eng, ns)
+        args.steps = saved
+
+    def repeated(eng, ns):
+        regions = sorted(run_mode(eng, ns) for _ in range(max(1, args.repeats)))
+        return statistics.median(regions), regions[0], regions[-1]
+
+    def traced(eng):
         with pkg.KernelTrace(eng, max_launches=16 * args.steps + 64) as trace:
-            elapsed_traced = timed_region(1)
-        kern = trace.summary()
+            dt = run_mode(eng, 1)
+        return trace.summary(), dt
+
+    def measure(precision, with_serial_trace):
+        eng = pkg.HotPathEngine(weights, device=device, precision=precision)
+        half = precision != 'f32'
+        tile_overlap = args.enc_tile or (64 if (n_streams > 1 and half) else 0)
+        res = {'tile_overlap': tile_overlap, 'engine': eng}
+        eng.set_encoder_tile(args.enc_tile)
+        warm(eng, 1)
+        eng.set_encoder_tile(tile_overlap)
+        warm(eng, n_streams)
+        res['overlap'] = repeated(eng, n_streams)            # -> value (no instrumentation)
+        if not args.no_trace:
+            # same K steps on ONE stream (kernel durations only mean something when launches
+            # do not share the chip), in the tile shape that produced `value`, with the
+            # library's per-kernel HIP events recorded on its launch stream
+            res['trace_overlap_shape'] = traced(eng)
+        eng.set_encoder_tile(args.enc_tile)
+        res['serial'] = repeated(eng, 1) if n_streams > 1 else res['overlap']
+        if not args.no_trace and with_serial_trace and tile_overlap != (args.enc_tile or 0):
+            res['trace_serial_shape'] = traced(eng)
+        return res
+
+    main_res = measure(args.precision, with_serial_trace=True)
+    eng = main_res['engine']
+    exact_res = None
+    if args.precision == 'f32_split_f16' and not args.no_exact_f32:
+        exact_res = measure('f32', with_serial_trace=False)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    elapsed, e_min, e_max = main_res['overlap']
     ms_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
+    cost, pipe_peak, _ = MFMA_COST[args.precision]
+    pair_gflop = PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800
+    tile_overlap = main_res['tile_overlap']
+    dtype = {'f32': 'f32', 'f32_split_f16': 'f32', 'f16': 'f16', 'bf16': 'bf16'}[args.precision]
+    tag = ''
+    if standard and args.precision in ('f32', 'f32_split_f16'):
+        tag = 'BASELINE configs[1]: '
+    elif standard and args.precision == 'bf16':
+        tag = 'BASELINE configs[2] per-GPU share (64 pairs / 8 GPUs): '
+    elif (n, args.size, size2) == (8, 640, 1280) and args.precision == 'f16':
+        tag = 'BASELINE configs[4] per-GPU share: '
     out = {
         'metric': f'image-pairs/sec @{args.size}x{args.size} (OETR hot path: '
                   'feature correlation + overlap regression, features resident in HBM)',
         'value': round(value, 1), 'unit': 'image-pairs/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-        'gemm_mode': ('fp32-class products from 3 f16 MFMAs (a=ah+al/2^11 split), fp32 accumulate'
-                      if args.precision == 'f32_split_f16' else 'exact fp32 MFMA'),
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype,
+        'gemm_mode': GEMM_MODE_TEXT[args.precision],
         'data': 'synthetic',
-        'config': {'workload': (f'BASELINE configs[1]: ' if (n, args.size, size2) == (8, 640, 640) else '')
-                               + f'batch={n} pairs/GPU, {args.size}x{args.size}'
+        'timing': {'repeats': args.repeats, 'statistic': 'median region of --steps steps',
+                   'ms_per_step_min': round(e_min / args.steps * 1e3, 4),
+                   'ms_per_step_max': round(e_max / args.steps * 1e3, 4)},
+        'config': {'workload': tag + f'batch={n} pairs/GPU, {args.size}x{args.size}'
                                + (f' vs {size2}x{size2}' if size2 != args.size else '')
                                + f' -> {hf}x{hf}' + (f' / {hf2}x{hf2}' if hf2 != hf else '')
-                               + ' tokens/image, C=256, 8 enc + 2 dec layers, fp32',
+                               + f' tokens/image, C=256, 8 enc + 2 dec layers, {args.precision}',
                    'pairs_per_gpu': n, 'global_pairs': n_total,
                    'streams': n_streams,
                    'encoder_tile_rows': tile_overlap or 'auto',
                    'tokens_per_image': hf * hf,
                    'parallelism': f'pairs sharded over {world} rank(s); '
                                   'all-gather of boxes only'},
-        'hot_path_tflops': round(value * PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800 / 1e3, 2),
-        'hot_path_frac_of_mfma_peak': round(
-            value * PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800 / 1e3
-            / (F16_MFMA_PEAK_TFLOPS / 3 if args.precision == 'f32_split_f16' else F32_MFMA_PEAK_TFLOPS), 4),
-        # the same K steps strictly one after the other on one stream (batch latency;
-        # encoder tile = library default, which is also what the traced pass below runs)
-        'serial': {'ms_per_step': round(elapsed_serial / args.steps * 1e3, 4),
-                   'pairs_per_s': round(n_total * args.steps / elapsed_serial, 1)},
+        'hot_path_tflops': round(value * pair_gflop / 1e3, 2),
+        'hot_path_frac_of_mfma_peak': round(value * pair_gflop / 1e3 / (pipe_peak / cost), 4),
     }
-    if kern and DOMINANT in kern:
-        launches, total_ms = kern[DOMINANT]
-        avg_ms = total_ms / launches
-        flop = ENC_FLOP_PER_TOKEN * n * (hf * hf + hf2 * hf2)   # tokens of both sides (algorithmic)
-        # `achieved` is ALGORITHMIC fp32 FLOP/s.  In split mode every algorithmic
-        # product costs 3 f16 MFMA products, so the MFMA roof for this scheme is the
-        # dense f16 peak / 3; in exact mode it is the f32 MFMA peak.
-        peak = F16_MFMA_PEAK_TFLOPS / 3 if split else F32_MFMA_PEAK_TFLOPS
-        ach = flop / (avg_ms * 1e-3) / 1e12
-        out['roofline'] = {
-            'kernel': DOMINANT, 'bound': 'mfma', 'achieved': round(ach, 2),
-            'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'peak_basis': ('dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 product'
-                           if split else 'f32 MFMA (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s'),
-            'executed_mfma_tflops': round(ach * (3 if split else 1), 2),
-            'frac_of_f32_mfma_peak': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-            'traffic': pmc_traffic_bytes('k_encoderILb1ELi0E') if (n, args.size, size2) == (8, 640, 640) else None,
-            'avg_launch_us': round(avg_ms * 1e3, 2), 'launches': launches,
-            'flop_per_launch': flop,
-            'share_of_step': round(total_ms / (elapsed_traced * 1e3), 4),
-            'traced_ms_per_step': round(elapsed_traced / args.steps * 1e3, 4)}
-        out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
-                             for k, v in kern.items()}
+    s_med, s_min, s_max = main_res['serial']
+    # the same K steps strictly one after the other on one stream (batch latency;
+    # encoder tile = library default)
+    out['serial'] = {'ms_per_step': round(s_med / args.steps * 1e3, 4),
+                     'pairs_per_s': round(n_total * args.steps / s_med, 1),
+                     'ms_per_step_min': round(s_min / args.steps * 1e3, 4),
+                     'ms_per_step_max': round(s_max / args.steps * 1e3, 4)}
+    if 'trace_overlap_shape' in main_res:
+        kern, t_s = main_res['trace_overlap_shape']
+        rb = roofline_block(kern, args.precision, tokens, tile_overlap or 32, args.steps, t_s, standard)
+        if rb:
+            out['roofline'] = rb
+            out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
+                                 for k, v in kern.items()}
+    if 'trace_serial_shape' in main_res:
+        kern, t_s = main_res['trace_serial_shape']
+        rb = roofline_block(kern, args.precision, tokens, args.enc_tile or 32, args.steps, t_s, standard)
+        if rb:
+            out['serial']['roofline'] = rb
+            out['serial']['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
+                                           for k, v in kern.items()}
+    if exact_res is not None:
+        x_med, x_min, x_max = exact_res['overlap']
+        xs_med = exact_res['serial'][0]
+        out['exact_f32'] = {'gemm_mode': GEMM_MODE_TEXT['f32'],
+                            'pairs_per_s': round(n_total * args.steps / x_med, 1),
+                            'ms_per_step': round(x_med / args.steps * 1e3, 4),
+                            'ms_per_step_min': round(x_min / args.steps * 1e3, 4),
+                            'ms_per_step_max': round(x_max / args.steps * 1e3, 4),
+                            'serial_pairs_per_s': round(n_total * args.steps / xs_med, 1)}
+        if 'trace_overlap_shape' in exact_res:
+            kern, t_s = exact_res['trace_overlap_shape']
+            rb = roofline_block(kern, 'f32', tokens, 32, args.steps, t_s, standard)
+            if rb:
+                out['exact_f32']['roofline'] = rb
     if not args.no_cpu_baseline and world == 1:   # host-core baseline: rank 0 at N=1 only
         base, ref_boxes = cpu_baseline(weights, feat1, feat2, args.size, size2)
         out['cpu_baseline'] = base
@@ -303,9 +502,12 @@ def main():
                          orc.bbox_iou_aligned(mine[1].cpu(), ref_boxes[1])])
         out['iou_vs_cpu_min'] = round(float(iou.min()), 6)
         out['speedup_vs_cpu'] = round(value / base['value'], 1)
+    if eng.precision in eng.F16_RANGE:
+        out['f16_range_flag'] = eng.query_flags()
     if not args.no_e2e and world == 1:
         try:     # whole forward_dummy incl. the PyTorch/MIOpen backbone (host code)
             model = model.to(device)
+            model.hip_precision = args.precision
             g = torch.Generator().manual_seed(2)
             im1 = torch.rand(n, args.size, args.size, 3, generator=g).to(device)
             im2 = torch.rand(n, size2, size2, 3, generator=g).to(device)

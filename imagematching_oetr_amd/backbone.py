@@ -104,8 +104,11 @@ class ResnetEncoder(nn.Module):
         x = image_nhwc.permute(0, 3, 1, 2).contiguous()
         if self.cfg.NORM_INPUT:
             x = (x - 0.45) / 0.225
-        x = self.layer3(self.layer2(self.layer1(self.layer0(x))))
-        if self.cfg.BACKBONE.LAYER == 'layer4':
+        x = self.layer2(self.layer1(self.layer0(x)))
+        layer = self.cfg.BACKBONE.LAYER       # reference backbone.py:168-172: layer3 only runs
+        if layer in ('layer3', 'layer4'):     # for 'layer3' / 'layer4'
+            x = self.layer3(x)
+        if layer == 'layer4':
             x = self.layer4(x)
         return x
 

@@ -1,6 +1,7 @@
 // C ABI of liboetr_hip.so (declared in include/oetr_hip.h): weight repacking,
 // workspace layout and launch orchestration.  No torch types, no hidden
 // allocation or synchronisation inside forward calls.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -54,17 +55,27 @@ struct Packer {
           }
     return off;
   }
-  // W [nout][k] -> two f16 planes (hi, lo*2^11) in f16 MFMA B-fragment order
-  // (common.h: gemm_rows32_h); returns offsets (in floats) of both planes.
-  void frag_h(const float* W, int nout, int k, size_t* hi_off, size_t* lo_off, int ld = -1,
-              int stride_k = 1) {
+  // float -> bf16 bit pattern, round to nearest even (host side)
+  static uint16_t bf16_bits(float w) {
+    uint32_t u;
+    memcpy(&u, &w, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+  // W [nout][k] -> 16-bit planes in MFMA B-fragment order (common.h: gemm_rows32_h):
+  // GM_SPLIT two f16 planes (hi, lo*2^11); GM_F16 / GM_BF16 one plane (RNE), lo_off = hi_off.
+  // Returns offsets (in floats) of the planes.
+  void frag_h(int mode, const float* W, int nout, int k, size_t* hi_off, size_t* lo_off,
+              int ld = -1, int stride_k = 1) {
     if (ld < 0) ld = k;
     const int ks_n = k / 16;
     const size_t plane_floats = (size_t)nout * k / 2;
     *hi_off = reserve_aligned(plane_floats);
-    *lo_off = reserve_aligned(plane_floats);
+    *lo_off = mode == GM_SPLIT ? reserve_aligned(plane_floats) : *hi_off;
     _Float16* hi = reinterpret_cast<_Float16*>(buf.data() + *hi_off);
     _Float16* lo = reinterpret_cast<_Float16*>(buf.data() + *lo_off);
+    uint16_t* hb = reinterpret_cast<uint16_t*>(hi);
     for (int nt = 0; nt < nout / 32; ++nt)
       for (int ks = 0; ks < ks_n; ++ks)
         for (int lane = 0; lane < 64; ++lane)
@@ -72,16 +83,17 @@ struct Packer {
             const int n = nt * 32 + (lane & 31);
             const int kk = ks * 16 + 8 * (lane >> 5) + j;
             const float w = W[(size_t)n * ld + (size_t)kk * stride_k];
-            const _Float16 h = (_Float16)w;
             const size_t idx = (((size_t)nt * ks_n + ks) * 64 + lane) * 8 + j;
+            if (mode == GM_BF16) { hb[idx] = bf16_bits(w); continue; }
+            const _Float16 h = (_Float16)w;
             hi[idx] = h;
-            lo[idx] = (_Float16)((w - (float)h) * SPLIT_SCALE);
+            if (mode == GM_SPLIT) lo[idx] = (_Float16)((w - (float)h) * SPLIT_SCALE);
           }
   }
   // one GEMM weight in the representation of the chosen mode
-  void gemm_weight(bool split, const float* W, int nout, int k, size_t* a, size_t* b, int ld = -1,
+  void gemm_weight(int mode, const float* W, int nout, int k, size_t* a, size_t* b, int ld = -1,
                    int stride_k = 1) {
-    if (split) frag_h(W, nout, k, a, b, ld, stride_k);
+    if (gm_half(mode)) frag_h(mode, W, nout, k, a, b, ld, stride_k);
     else { *a = frag(W, nout, k, ld, stride_k); *b = *a; }
   }
   // W [nout][k] -> transposed [k][nout]
@@ -119,11 +131,12 @@ struct oetr_trace {
 struct oetr_ctx {
   oetr_trace* trace = nullptr;
   int device = 0;
-  bool split = false;  // OETR_DTYPE_F32_SPLIT_F16
+  int mode = GM_SPLIT;  // oetr_dtype == GM_* (common.h)
   int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
   int num_cus = 256;
   float* dev = nullptr;  // all repacked weights
   size_t dev_floats = 0;
+  uint32_t* flags = nullptr;  // device status word (OETR_FLAG_*), set by kernels with atomicOr
   EncLayerDev enc[OETR_N_ENC];
   DecKVDev dkv;
   DecLayerDev dec[OETR_N_DEC];
@@ -136,6 +149,7 @@ struct oetr_neck_ctx {
   oetr_trace* trace = nullptr;
   int device = 0;
   float* dev = nullptr;  // all repacked weights
+  uint32_t* flags = nullptr;  // device status word (OETR_FLAG_*)
   const f32x4 *proj_wh[2], *proj_wl[2];
   const float *proj_b, *ln_w, *ln_b;
   const f32x4 *conv_wh[3], *conv_wl[3];
@@ -177,11 +191,10 @@ bool make_geom(int n, int hf1, int wf1, int hf2, int wf2, Geom* g) {
 // 64-token workgroup shape (k_encoder64: every weight fragment feeds two MFMA row
 // tiles; 1.2-1.3x fewer CU-microseconds per token, but half as many workgroups).
 // auto: 64 once the 32-token grid no longer fits the chip in one wave of
-// workgroups; oetr_set_encoder_tile / OETR_ENC_TILE override.  The heads keep TM.
+// workgroups; oetr_set_encoder_tile overrides.  The heads keep TM.
 int encoder_tile_rows(const oetr_ctx* h, const Geom& g) {
-  static const int forced = [] { const char* e = getenv("OETR_ENC_TILE"); return e ? atoi(e) : 0; }();
-  if (!h->split) return TM;
-  const int want = forced ? forced : h->enc_tile;
+  if (!gm_half(h->mode)) return TM;
+  const int want = h->enc_tile;
   if (want == TM || want == 64) return want;
   return g.ntiles > h->num_cus ? 64 : TM;
 }
@@ -246,6 +259,7 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.tlbr[0] = p.tlbr[1] = nullptr;   // stand-alone centre estimation: no fused tail
   p.box[0] = p.box[1] = nullptr;
   p.img_w[0] = p.img_w[1] = 0;
+  p.flags = h->flags;
   return p;
 }
 
@@ -302,9 +316,10 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   }
 #endif
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
+  p.flags = h->flags;
   p.a = h->enc[0];
   p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];
-  TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, h->split, s));
+  TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, h->mode, s));
   for (int l = 0; l < enc_layers; ++l) {
     p.b = h->enc[l];
     p.b_cross = l & 1;
@@ -323,13 +338,40 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
       tail = 2;
     }
     TRACED(h, s, tail == 0 ? K_ENC_BA : tail == 1 ? K_ENC_BDEC : K_ENC_B,
-           launch_encoder(p, true, tail, h->split, s));
+           launch_encoder(p, true, tail, h->mode, s));
   }
   if (enc_layers == OETR_N_ENC && with_decoder) {
     DecLaunch d = dec_launch(h, g, w);
     TRACED(h, s, K_DECODER, launch_decoder(d, s));
   }
   return OETR_OK;
+}
+
+// Weights must be finite, and representable by the mode's operand type: the f16-based
+// modes (split, f16) need |w| < 65504 in every GEMM weight (common.h: Range guards the
+// activations at run time; weights are checked once, here).
+oetr_status check_weight(const char* name, const float* w, size_t n, bool f16_range) {
+  for (size_t i = 0; i < n; ++i) {
+    const float a = fabsf(w[i]);
+    if (!(a <= 3.4028234e38f))
+      return fail(OETR_ERR_UNSUPPORTED, std::string(name) + ": non-finite weight at index " + std::to_string(i));
+    if (f16_range && a >= 65504.0f)
+      return fail(OETR_ERR_UNSUPPORTED, std::string(name) + ": |w| = " + std::to_string(a) +
+                  " at index " + std::to_string(i) + " exceeds the f16 range of this dtype; use "
+                  "OETR_DTYPE_BF16 or OETR_DTYPE_F32");
+  }
+  return OETR_OK;
+}
+#define CHECK_W(name, ptr, n, f16r)                                      \
+  do {                                                                   \
+    oetr_status rc__ = check_weight(name, ptr, n, f16r);                 \
+    if (rc__) return rc__;                                               \
+  } while (0)
+
+hipError_t alloc_flags(uint32_t** flags) {
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(flags), 256);
+  if (e == hipSuccess) e = hipMemset(*flags, 0, 256);
+  return e;
 }
 
 oetr_status copy_out(float* dst, const float* src, size_t floats, hipStream_t s) {
@@ -349,9 +391,12 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   if (!w || !out) return fail(OETR_ERR_BAD_ARG, "oetr_create: NULL argument");
   if (w->struct_size != sizeof(oetr_weights) || w->abi_version != OETR_ABI_VERSION)
     return fail(OETR_ERR_BAD_ARG, "oetr_create: oetr_weights size/ABI mismatch");
-  if (dtype != OETR_DTYPE_F32 && dtype != OETR_DTYPE_F32_SPLIT_F16)
-    return fail(OETR_ERR_UNSUPPORTED, "dtype must be OETR_DTYPE_F32 or OETR_DTYPE_F32_SPLIT_F16");
-  const bool split = dtype == OETR_DTYPE_F32_SPLIT_F16;
+  static_assert(OETR_DTYPE_F32 == GM_F32 && OETR_DTYPE_F32_SPLIT_F16 == GM_SPLIT &&
+                    OETR_DTYPE_F16 == GM_F16 && OETR_DTYPE_BF16 == GM_BF16, "oetr_dtype == GM_*");
+  if (dtype != OETR_DTYPE_F32 && dtype != OETR_DTYPE_F32_SPLIT_F16 && dtype != OETR_DTYPE_F16 &&
+      dtype != OETR_DTYPE_BF16)
+    return fail(OETR_ERR_UNSUPPORTED, "dtype must be one of OETR_DTYPE_{F32,F32_SPLIT_F16,F16,BF16}");
+  const int split = (int)dtype;  // GEMM mode (name kept: selects the weight representation)
   {  // every pointer must be set
     const float* const* p = reinterpret_cast<const float* const*>(&w->enc[0]);
     const size_t n = (sizeof(oetr_weights) - offsetof(oetr_weights, enc)) / sizeof(float*);
@@ -368,9 +413,56 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
     return fail(OETR_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName +
                                         ", this library is built for gfx950 only");
 
+  {
+    const bool f16r = split == GM_SPLIT || split == GM_F16;
+    for (int l = 0; l < OETR_N_ENC; ++l) {
+      const oetr_encoder_layer_weights& e = w->enc[l];
+      const std::string pre = "encoder." + std::to_string(l) + ".";
+      CHECK_W((pre + "q_proj").c_str(), e.q_proj, (size_t)C * C, f16r);
+      CHECK_W((pre + "k_proj").c_str(), e.k_proj, (size_t)C * C, f16r);
+      CHECK_W((pre + "v_proj").c_str(), e.v_proj, (size_t)C * C, f16r);
+      CHECK_W((pre + "merge").c_str(), e.merge, (size_t)C * C, f16r);
+      CHECK_W((pre + "mlp.0").c_str(), e.mlp0, (size_t)FF * C, f16r);
+      CHECK_W((pre + "mlp.2").c_str(), e.mlp2, (size_t)FF * C, f16r);
+      const float* vecs[6] = {e.pre_norm_q_w, e.pre_norm_q_b, e.pre_norm_kv_w, e.pre_norm_kv_b,
+                              e.norm2_w, e.norm2_b};
+      for (int i = 0; i < 6; ++i) CHECK_W((pre + "norm").c_str(), vecs[i], C, false);
+    }
+    for (int l = 0; l < OETR_N_DEC; ++l) {
+      const oetr_decoder_layer_weights& d = w->dec[l];
+      const std::string pre = "decoder.layers." + std::to_string(l) + ".";
+      const oetr_mha_weights* mh[2] = {&d.self_attn, &d.multihead_attn};
+      for (int a = 0; a < 2; ++a) {
+        const bool gemm = a == 1;  // the cross-attention k/v projections run as MFMA GEMMs
+        CHECK_W((pre + "attn.q_proj").c_str(), mh[a]->q_proj_w, (size_t)C * C, false);
+        CHECK_W((pre + "attn.k_proj").c_str(), mh[a]->k_proj_w, (size_t)C * C, gemm && f16r);
+        CHECK_W((pre + "attn.v_proj").c_str(), mh[a]->v_proj_w, (size_t)C * C, gemm && f16r);
+        CHECK_W((pre + "attn.merge").c_str(), mh[a]->merge, (size_t)C * C, false);
+        CHECK_W((pre + "attn.q_bias").c_str(), mh[a]->q_proj_b, C, false);
+        CHECK_W((pre + "attn.k_bias").c_str(), mh[a]->k_proj_b, C, false);
+        CHECK_W((pre + "attn.v_bias").c_str(), mh[a]->v_proj_b, C, false);
+      }
+      CHECK_W((pre + "mlp.0").c_str(), d.mlp0, (size_t)FF * C, false);
+      CHECK_W((pre + "mlp.2").c_str(), d.mlp2, (size_t)FF * C, false);
+      const float* nv[6] = {d.norm1_w, d.norm1_b, d.norm2_w, d.norm2_b, d.norm3_w, d.norm3_b};
+      for (int i = 0; i < 6; ++i) CHECK_W((pre + "norm").c_str(), nv[i], C, false);
+    }
+    CHECK_W("query_embed1", w->query_embed1, C, false);
+    CHECK_W("query_embed2", w->query_embed2, C, false);
+    CHECK_W("tlbr_reg.0", w->tlbr0_w, (size_t)C * C, false);
+    CHECK_W("tlbr_reg.2.weight", w->tlbr2_w, 4 * C, false);
+    CHECK_W("tlbr_reg.2.bias", w->tlbr2_b, 4, false);
+    CHECK_W("heatmap_conv.0.weight", w->heat_conv_w, (size_t)C * C * 9, f16r);
+    CHECK_W("heatmap_conv.0.bias", w->heat_conv_b, C, false);
+    CHECK_W("heatmap_conv.1.weight", w->heat_gn_w, C, false);
+    CHECK_W("heatmap_conv.1.bias", w->heat_gn_b, C, false);
+    CHECK_W("heatmap_conv.3.weight", w->heat_out_w, C, false);
+    CHECK_W("heatmap_conv.3.bias", w->heat_out_b, 1, false);
+  }
+
   oetr_ctx* h = new oetr_ctx();
   h->device = device;
-  h->split = split;
+  h->mode = split;
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   Packer pk;
   struct EncOff { size_t wq, wk, wv, wm, w1, w2, wq_l, wk_l, wv_l, wm_l, w1_l, w2_l, v[6]; } eo[OETR_N_ENC];
@@ -413,7 +505,7 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   // (taps are consecutive: f32 mode one array of 9 matrices; split mode all 9 hi
   //  planes then all 9 lo planes)
   size_t conv_off = 0, conv_off_l = 0;
-  if (!split) {
+  if (!gm_half(split)) {
     for (int tap = 0; tap < 9; ++tap) {
       const size_t o = pk.frag(w->heat_conv_w + tap, C, C, /*ld=*/C * 9, /*stride_k=*/9);
       if (tap == 0) conv_off = o;
@@ -422,13 +514,14 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   } else {
     std::vector<size_t> hi(9), lo(9);
     Packer tmp;  // pack per tap, then lay the planes out contiguously per kind
-    for (int tap = 0; tap < 9; ++tap) tmp.frag_h(w->heat_conv_w + tap, C, C, &hi[tap], &lo[tap], C * 9, 9);
+    for (int tap = 0; tap < 9; ++tap) tmp.frag_h(split, w->heat_conv_w + tap, C, C, &hi[tap], &lo[tap], C * 9, 9);
     const size_t plane = (size_t)C * C / 2;
     conv_off = pk.reserve_aligned(9 * plane);
-    conv_off_l = pk.reserve_aligned(9 * plane);
+    conv_off_l = split == GM_SPLIT ? pk.reserve_aligned(9 * plane) : conv_off;
     for (int tap = 0; tap < 9; ++tap) {
       memcpy(pk.buf.data() + conv_off + tap * plane, tmp.buf.data() + hi[tap], plane * sizeof(float));
-      memcpy(pk.buf.data() + conv_off_l + tap * plane, tmp.buf.data() + lo[tap], plane * sizeof(float));
+      if (split == GM_SPLIT)
+        memcpy(pk.buf.data() + conv_off_l + tap * plane, tmp.buf.data() + lo[tap], plane * sizeof(float));
     }
   }
   const size_t conv_b = pk.copy(w->heat_conv_b, C), gn_w = pk.copy(w->heat_gn_w, C),
@@ -444,9 +537,11 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   if (e == hipSuccess) e = hipMalloc(&h->dev, pk.buf.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(h->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = alloc_flags(&h->flags);
   (void)hipSetDevice(prev);
   if (e != hipSuccess) {
     if (h->dev) (void)hipFree(h->dev);
+    if (h->flags) (void)hipFree(h->flags);
     delete h;
     return hip_fail(e, "oetr_create: uploading weights");
   }
@@ -491,6 +586,7 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
     (void)hipSetDevice(prev);
     if (ce != hipSuccess) {
       (void)hipFree(h->dev);
+      (void)hipFree(h->flags);
       delete h;
       return hip_fail(ce, "oetr_create: decoder constant folding");
     }
@@ -511,6 +607,7 @@ void oetr_destroy(oetr_handle h) {
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(h->device);
     (void)hipFree(h->dev);
+    if (h->flags) (void)hipFree(h->flags);
     (void)hipSetDevice(prev);
   }
   delete h;
@@ -573,7 +670,7 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
   hp.box[0] = box1; hp.box[1] = box2;
   hp.img_w[0] = img_w1; hp.img_w[1] = img_w2;
   // decoder || P_tap = W_tap.memory in one launch, then the att-weighted combine
-  TRACED(h, s, K_DEC_CONVP, launch_decoder_convp(dec_launch(h, g, w), hp, w.convp, h->split, s));
+  TRACED(h, s, K_DEC_CONVP, launch_decoder_convp(dec_launch(h, g, w), hp, w.convp, h->mode, s));
   TRACED(h, s, K_HEAT_COMBINE, launch_heat_combine(hp, w.convp, s));
   TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));  // + size regression + boxes
   if (st) {
@@ -638,7 +735,7 @@ oetr_status oetr_center_estimation(oetr_handle h, const float* hs1, const float*
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HeatLaunch hp = heat_launch(h, g, w, memory1, memory2, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
-  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, h->split, s));
+  TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, h->mode, s));
   TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));
   return OETR_OK;
 }
@@ -767,16 +864,27 @@ oetr_status oetr_neck_create(const oetr_neck_weights* w, int device, oetr_neck_h
   if (!strstr(prop.gcnArchName, "gfx950"))
     return fail(OETR_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName +
                                         ", this library is built for gfx950 only");
+  CHECK_W("input_proj.weight", w->input_proj_w, (size_t)C * BBC, true);
+  CHECK_W("input_proj.bias", w->input_proj_b, C, false);
+  CHECK_W("patchmerging.norm.weight", w->norm_w, C, false);
+  CHECK_W("patchmerging.norm.bias", w->norm_b, C, false);
+  for (int i = 0; i < 3; ++i) {
+    const NeckConvShape& cs = kNeckConv[i];
+    CHECK_W("patchmerging.reductions.weight", w->reduction_w[i], (size_t)cs.cout * C * cs.ks * cs.ks, true);
+    CHECK_W("patchmerging.reductions.bias", w->reduction_b[i], cs.cout, false);
+  }
+  CHECK_W("input_proj2.weight", w->input_proj2_w, (size_t)C * 2 * C, true);
+  CHECK_W("input_proj2.bias", w->input_proj2_b, C, false);
   Packer pk;
   size_t pwh[2], pwl[2], cwh[3], cwl[3], cb[3], owh, owl;
   for (int kh = 0; kh < 2; ++kh)  // input_proj, K halves [256][512] of the [256][1024] matrix
-    pk.frag_h(w->input_proj_w + kh * 512, C, 512, &pwh[kh], &pwl[kh], BBC);
+    pk.frag_h(GM_SPLIT, w->input_proj_w + kh * 512, C, 512, &pwh[kh], &pwl[kh], BBC);
   const size_t pb = pk.copy(w->input_proj_b, C), lw = pk.copy(w->norm_w, C), lb = pk.copy(w->norm_b, C);
   for (int i = 0; i < 3; ++i) {
     pack_conv(pk, w->reduction_w[i], kNeckConv[i], &cwh[i], &cwl[i]);
     cb[i] = pk.copy(w->reduction_b[i], kNeckConv[i].cout);
   }
-  pk.frag_h(w->input_proj2_w, C, 2 * C, &owh, &owl);
+  pk.frag_h(GM_SPLIT, w->input_proj2_w, C, 2 * C, &owh, &owl);
   const size_t ob = pk.copy(w->input_proj2_b, C);
 
   oetr_neck_ctx* h = new oetr_neck_ctx();
@@ -787,9 +895,11 @@ oetr_status oetr_neck_create(const oetr_neck_weights* w, int device, oetr_neck_h
   if (e == hipSuccess) e = hipMalloc(&h->dev, pk.buf.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(h->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = alloc_flags(&h->flags);
   (void)hipSetDevice(prev);
   if (e != hipSuccess) {
     if (h->dev) (void)hipFree(h->dev);
+    if (h->flags) (void)hipFree(h->flags);
     delete h;
     return hip_fail(e, "oetr_neck_create: uploading weights");
   }
@@ -810,6 +920,7 @@ void oetr_neck_destroy(oetr_neck_handle h) {
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(h->device);
     (void)hipFree(h->dev);
+    if (h->flags) (void)hipFree(h->flags);
     (void)hipSetDevice(prev);
   }
   delete h;
@@ -845,6 +956,7 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
   for (int kh = 0; kh < 2; ++kh) { pp.wh[kh] = h->proj_wh[kh]; pp.wl[kh] = h->proj_wl[kh]; }
   pp.bias = h->proj_b; pp.ln_w = h->ln_w; pp.ln_b = h->ln_b;
   pp.xh = w.xh; pp.xl = w.xl;
+  pp.flags = h->flags;
   TRACED(h, s, K_NECK_PROJ, launch_neck_proj(pp, s));
 
   NeckConvLaunch cp;
@@ -872,8 +984,34 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
   for (int i = 0; i < 3; ++i) { op.part[i] = w.part[i]; op.nsplit[i] = kNeckConv[i].nsplit; op.bias[i] = h->conv_b[i]; }
   op.wh = h->out_wh; op.wl = h->out_wl; op.bias2 = h->out_b;
   op.feat = feat_out;
+  op.flags = h->flags;
   TRACED(h, s, K_NECK_OUT, launch_neck_out(op, s));
   return OETR_OK;
+}
+
+namespace {
+oetr_status query_flags(int device, uint32_t* dev_flags, void* stream, uint32_t* flags, int clear) {
+  if (!flags) return fail(OETR_ERR_BAD_ARG, "oetr_query_flags: NULL output");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMemcpyAsync(flags, dev_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && clear) e = hipMemsetAsync(dev_flags, 0, sizeof(uint32_t), s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) return hip_fail(e, "oetr_query_flags");
+  return OETR_OK;
+}
+}  // namespace
+
+oetr_status oetr_query_flags(oetr_handle h, void* stream, uint32_t* flags, int clear) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_query_flags: NULL handle");
+  return query_flags(h->device, h->flags, stream, flags, clear);
+}
+oetr_status oetr_neck_query_flags(oetr_neck_handle h, void* stream, uint32_t* flags, int clear) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_query_flags: NULL handle");
+  return query_flags(h->device, h->flags, stream, flags, clear);
 }
 
 oetr_status oetr_neck_set_trace(oetr_neck_handle h, oetr_trace_handle t) {

@@ -43,6 +43,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// Arithmetic of the GEMM-shaped stages (values == oetr_dtype in include/oetr_hip.h).
+// Everything that is not a GEMM operand (LayerNorm, phi, normalisers, softmax,
+// residual stream, accumulators) is fp32 in every mode.
+//   GM_F32   exact fp32 products on v_mfma_f32_32x32x2_f32
+//   GM_SPLIT fp32-class: a = ah + al/2^11 in f16, 3 v_mfma_f32_32x32x16_f16 per product
+//   GM_F16   one v_mfma_f32_32x32x16_f16 per product (operands rounded to f16, RNE)
+//   GM_BF16  one v_mfma_f32_32x32x16_bf16 per product (operands rounded to bf16, RNE)
+enum { GM_F32 = 0, GM_SPLIT = 1, GM_F16 = 2, GM_BF16 = 3 };
+constexpr bool gm_half(int m) { return m != GM_F32; }          // operands are 16-bit planes
+constexpr int gm_planes(int m) { return m == GM_SPLIT ? 2 : 1; }  // planes per operand
 
 // "f32 via split f16" GEMM mode: a = ah + al/2^11 with ah = f16(a),
 // al = f16((a - ah) * 2^11); a*b ~= ah*bh + (ah*bl + al*bh)/2^11 on
@@ -284,7 +297,7 @@ __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda
   }
 }
 
-// ---- split-f16 GEMM core -------------------------------------------------
+// ---- 16-bit-plane GEMM core (GM_SPLIT / GM_F16 / GM_BF16) -----------------
 // hi/lo halves of two floats: (hi0,hi1) and (lo0,lo1) packed as f16x2.
 __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
   // v_cvt_pkrtz converts two floats per instruction.  Truncation of hi is
@@ -294,40 +307,99 @@ __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
   lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((a - (float)hi[0]) * SPLIT_SCALE,
                                                             (b - (float)hi[1]) * SPLIT_SCALE));
 }
-// Store 4 consecutive floats of a row as 4 hi halves + 4 lo halves (8-byte stores).
+// Range guard of the f16-based modes (GM_SPLIT, GM_F16): every activation that is
+// converted into a GEMM operand updates a per-thread max |x| (one v_max3_f32 per two
+// values - noise next to the conversion itself); a kernel ends with range_report(),
+// which sets FLAG_F16_RANGE in the handle's device flag word (one atomicOr, only when
+// violated) if any operand was >= 65504 (or inf) and so could not be represented.
+// The host reads the word with oetr_query_flags().  Weights are checked at create.
+constexpr uint32_t FLAG_F16_RANGE = 1u;   // == OETR_FLAG_F16_RANGE
+constexpr float F16_MAX = 65504.0f;
+constexpr bool gm_f16_range(int m) { return m == GM_SPLIT || m == GM_F16; }
+struct Range {
+  float amax = 0.f;
+  __device__ __forceinline__ void see(float a, float b) {
+    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+  }
+};
+template <int M>
+__device__ __forceinline__ void range_report(const Range& rg, uint32_t* flags) {
+  if constexpr (gm_f16_range(M)) {
+    if (rg.amax >= F16_MAX) atomicOr(flags, FLAG_F16_RANGE);
+  }
+}
+// Two floats -> the mode's operand representation: `hi` = the (only, or high) plane's two
+// 16-bit values, `lo` = the low plane's (GM_SPLIT only).  Single-plane modes round to
+// nearest even (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32).
+template <int M>
+__device__ __forceinline__ void cvt_planes2(float a, float b, uint32_t& hi, uint32_t& lo, Range& rg) {
+  if constexpr (gm_f16_range(M)) rg.see(a, b);
+  if constexpr (M == GM_SPLIT) {
+    f16x2 h, l;
+    split2(a, b, h, l);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+  } else if constexpr (M == GM_F16) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+    lo = 0;
+  } else {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    lo = 0;
+  }
+}
+// One 32x32x16 MFMA on raw 16-byte fragments in the mode's element type.
+template <int M>
+__device__ __forceinline__ f32x16 mma16(const f32x4& a, const f32x4& b, const f32x16& c) {
+  if constexpr (M == GM_BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// Store 4 consecutive floats of a row as 4 16-bit values per plane (8-byte stores).
+// Planes are typed _Float16* for storage only (bf16 bit patterns in GM_BF16).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int M>
+__device__ __forceinline__ void store_planes4(_Float16* hi_row, _Float16* lo_row, int c,
+                                              const f32x4& v, Range& rg) {
+  uint32_t h0, l0, h1, l1;
+  cvt_planes2<M>(v[0], v[1], h0, l0, rg);
+  cvt_planes2<M>(v[2], v[3], h1, l1, rg);
+  *reinterpret_cast<u32x2*>(hi_row + c) = u32x2{h0, h1};
+  if constexpr (gm_planes(M) == 2) *reinterpret_cast<u32x2*>(lo_row + c) = u32x2{l0, l1};
+}
 __device__ __forceinline__ void store_split4(_Float16* hi_row, _Float16* lo_row, int c,
-                                             const f32x4& v) {
-  f16x2 h0, l0, h1, l1;
-  split2(v[0], v[1], h0, l0);
-  split2(v[2], v[3], h1, l1);
-  *reinterpret_cast<f16x4*>(hi_row + c) = f16x4{h0[0], h0[1], h1[0], h1[1]};
-  *reinterpret_cast<f16x4*>(lo_row + c) = f16x4{l0[0], l0[1], l1[0], l1[1]};
+                                             const f32x4& v, Range& rg) {
+  store_planes4<GM_SPLIT>(hi_row, lo_row, c, v, rg);
 }
 
-template <int NT, int U>
+template <int M, int NT, int U>
 struct GemmRegsH {
-  f32x4 bh[U][NT], bl[U][NT];  // 8 halves each (raw 16-byte fragments)
-  f32x4 ah[U], al[U];
+  f32x4 bh[U][NT], bl[U][gm_planes(M) == 2 ? NT : 1];  // 8 halves each (raw 16-byte fragments)
+  f32x4 ah[U], al[gm_planes(M) == 2 ? U : 1];
 };
 
-// acc[t] += A[32 x K] * W_tile(nt0 + t) with both operands split (see above).
-//   Ahi/Alo: LDS f16 planes, row stride lda halves.
-//   Whi/Wlo: weights in f16 fragment order: 16-byte unit ((ntile*K/16 + ks)*64 + lane)
+// acc[t] += A[32 x K] * W_tile(nt0 + t), operands in the mode's 16-bit planes.
+//   Ahi/Alo: LDS planes, row stride lda halves (Alo: GM_SPLIT only).
+//   Whi/Wlo: weights in 16-bit fragment order: 16-byte unit ((ntile*K/16 + ks)*64 + lane)
 //            holds, for output column n = 32*ntile + (lane&31), inputs
 //            k = 16*ks + 8*(lane>>5) + {0..7}.
-//   acc = main + cross/2^11 is formed at the end; `acc` enters as the initial main part.
+//   GM_SPLIT: acc = main + cross/2^11 is formed at the end; `acc` enters as the initial
+//   main part.
 #ifndef OETR_SPLIT_DEPTH
 #define OETR_SPLIT_DEPTH 3   // register buffers in the weight/activation prefetch ring
 #endif
 #ifndef OETR_SPLIT_U1
 #define OETR_SPLIT_U1 2   // chunk depth (k16 steps) when a wave owns one n-tile (8-wave shape)
 #endif
-template <int K, int NT, int U = (NT == 1 ? OETR_SPLIT_U1 : 4)>
+template <int M, int K, int NT, int U = (NT == 1 ? OETR_SPLIT_U1 : 4)>
 __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
                                               const _Float16* __restrict__ Alo, int lda,
                                               const f32x4* __restrict__ Whi,
                                               const f32x4* __restrict__ Wlo, int nt0, int lane,
                                               f32x16 (&acc)[NT]) {
+  constexpr bool TWO = gm_planes(M) == 2;
   constexpr int KS = K / 16;
   constexpr int NCH = KS / U;
   static_assert(KS % (2 * U) == 0, "K must be a multiple of 32*U");
@@ -343,35 +415,36 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
   }
   // two cross accumulators per tile: three independent MFMA chains per k-step
   // (a single one makes every other MFMA wait on its predecessor's result)
-  f32x16 cross[NT], cross2[NT];
+  f32x16 cross[TWO ? NT : 1], cross2[TWO ? NT : 1];
+  if constexpr (TWO) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { cross[t] = f32x16{0}; cross2[t] = f32x16{0}; }
+    for (int t = 0; t < NT; ++t) { cross[t] = f32x16{0}; cross2[t] = f32x16{0}; }
+  }
 
-  auto fetch = [&](GemmRegsH<NT, U>& r, int chunk) {
+  auto fetch = [&](GemmRegsH<M, NT, U>& r, int chunk) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         r.bh[u][t] = wh_ptr[t][(chunk * U + u) * 64];
-        r.bl[u][t] = wl_ptr[t][(chunk * U + u) * 64];
+        if constexpr (TWO) r.bl[u][t] = wl_ptr[t][(chunk * U + u) * 64];
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       r.ah[u] = *reinterpret_cast<const f32x4*>(ah_ptr + (chunk * U + u) * 16);
-      r.al[u] = *reinterpret_cast<const f32x4*>(al_ptr + (chunk * U + u) * 16);
+      if constexpr (TWO) r.al[u] = *reinterpret_cast<const f32x4*>(al_ptr + (chunk * U + u) * 16);
     }
   };
-  auto mma = [&](const GemmRegsH<NT, U>& r) {
+  auto mma = [&](const GemmRegsH<M, NT, U>& r) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const f16x8 ah = __builtin_bit_cast(f16x8, r.ah[u]), al = __builtin_bit_cast(f16x8, r.al[u]);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f16x8 bh = __builtin_bit_cast(f16x8, r.bh[u][t]);
-        const f16x8 bl = __builtin_bit_cast(f16x8, r.bl[u][t]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-        cross[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cross[t], 0, 0, 0);
-        cross2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cross2[t], 0, 0, 0);
+        acc[t] = mma16<M>(r.ah[u], r.bh[u][t], acc[t]);
+        if constexpr (TWO) {
+          cross[t] = mma16<M>(r.ah[u], r.bl[u][t], cross[t]);
+          cross2[t] = mma16<M>(r.al[u], r.bh[u][t], cross2[t]);
+        }
       }
     }
   };
@@ -380,7 +453,7 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
   // ring of three register buffers: two chunks of fragments in flight while the
   // third is consumed (per-CU weight streaming is latency-bound: ~2000 cycles per
   // L2 round trip under the all-workgroups-read-the-same-lines load)
-  GemmRegsH<NT, U> r0, r1, r2;
+  GemmRegsH<M, NT, U> r0, r1, r2;
   fetch(r0, 0);
   fetch(r1, 1);
   for (int c = 0; c < NCH; c += 3) {
@@ -402,7 +475,7 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
     }
   }
 #else
-  GemmRegsH<NT, U> r0, r1;
+  GemmRegsH<M, NT, U> r0, r1;
   fetch(r0, 0);
   for (int c = 0; c < NCH; c += 2) {
     fetch(r1, c + 1);
@@ -415,26 +488,30 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
     __builtin_amdgcn_sched_barrier(0);
   }
 #endif
+  if constexpr (TWO) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(cross[t][r] + cross2[t][r], SPLIT_INV, acc[t][r]);
+      for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(cross[t][r] + cross2[t][r], SPLIT_INV, acc[t][r]);
+  }
 }
 
-// Accumulator tiles -> split f16 planes (columns col0 + 32*t + lane&31).
-template <int NT>
-__device__ __forceinline__ void acc_to_lds_split(_Float16* Shi, _Float16* Slo, int lds, int col0,
-                                                 int lane, const f32x16 (&acc)[NT]) {
+// Accumulator tiles -> 16-bit planes (columns col0 + 32*t + lane&31).
+template <int M, int NT>
+__device__ __forceinline__ void acc_to_lds_planes(_Float16* Shi, _Float16* Slo, int lds, int col0,
+                                                  int lane, const f32x16 (&acc)[NT], Range& rg) {
   const int half = lane >> 5, c = col0 + (lane & 31);
+  uint16_t* H = reinterpret_cast<uint16_t*>(Shi);
+  uint16_t* Lo = reinterpret_cast<uint16_t*>(Slo);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      f16x2 hi, lo;
-      split2(acc[t][r], acc[t][r + 1], hi, lo);
+      uint32_t hi, lo;
+      cvt_planes2<M>(acc[t][r], acc[t][r + 1], hi, lo, rg);
       const int o0 = crow(r, half) * lds + c + 32 * t, o1 = crow(r + 1, half) * lds + c + 32 * t;
-      Shi[o0] = hi[0]; Shi[o1] = hi[1];
-      Slo[o0] = lo[0]; Slo[o1] = lo[1];
+      H[o0] = (uint16_t)hi; H[o1] = (uint16_t)(hi >> 16);
+      if constexpr (gm_planes(M) == 2) { Lo[o0] = (uint16_t)lo; Lo[o1] = (uint16_t)(lo >> 16); }
     }
 }
 
@@ -455,29 +532,33 @@ constexpr int TILE_FLOATS = (2 * TM * LDAH * 2 + 3) / 4;    // 8448 >= TM*LDA = 
 constexpr int HID_FLOATS = (2 * TM * LDHH * 2 + 3) / 4;     // 16640 >= TM*LDH = 16512
 static_assert(TILE_FLOATS >= TM * LDA && HID_FLOATS >= TM * LDH, "region sizes");
 
-// A GEMM A-operand tile in LDS, in either representation.
-template <bool SPLIT>
+// A GEMM A-operand tile in LDS, in the representation of mode M: an f32 tile
+// (GM_F32) or one / two 16-bit planes.  (Single-plane modes keep the two-plane
+// footprint: the regions are shared with the f32 staging tiles anyway.)
+template <int M>
 struct ATile {
+  static constexpr bool HALF = gm_half(M);
   float* f;        // f32 mode
-  _Float16 *h, *l; // split mode planes
+  _Float16 *h, *l; // 16-bit planes (l: GM_SPLIT only)
   int ldf, ldh;
-  __device__ __forceinline__ ATile(float* base, int ldf_, int ldh_)
+  Range* rg;       // the thread's range guard (see Range)
+  __device__ __forceinline__ ATile(float* base, int ldf_, int ldh_, Range* rg_)
       : f(base), h(reinterpret_cast<_Float16*>(base)),
-        l(reinterpret_cast<_Float16*>(base) + TM * ldh_), ldf(ldf_), ldh(ldh_) {}
+        l(reinterpret_cast<_Float16*>(base) + TM * ldh_), ldf(ldf_), ldh(ldh_), rg(rg_) {}
   // 4 consecutive values of one row
   __device__ __forceinline__ void put4(int row, int c, const f32x4& v) const {
-    if (SPLIT) store_split4(h + row * ldh, l + row * ldh, c, v);
+    if constexpr (HALF) store_planes4<M>(h + row * ldh, l + row * ldh, c, v, *rg);
     else *reinterpret_cast<f32x4*>(f + row * ldf + c) = v;
   }
   template <int NT>
   __device__ __forceinline__ void put_acc(int col0, int lane, const f32x16 (&acc)[NT]) const {
-    if (SPLIT) acc_to_lds_split<NT>(h, l, ldh, col0, lane, acc);
+    if constexpr (HALF) acc_to_lds_planes<M, NT>(h, l, ldh, col0, lane, acc, *rg);
     else acc_to_lds<NT>(f, ldf, col0, lane, acc);
   }
   template <int K, int NT>
   __device__ __forceinline__ void gemm(const f32x4* w, const f32x4* w_lo, int nt0, int lane,
                                        f32x16 (&acc)[NT], int dbg) const {
-    if (SPLIT) gemm_rows32_h<K, NT>(h, l, ldh, w, w_lo, nt0, lane, acc);
+    if constexpr (HALF) gemm_rows32_h<M, K, NT>(h, l, ldh, w, w_lo, nt0, lane, acc);
     else gemm_rows32<K, NT>(f, ldf, w, nt0, lane, acc, dbg);
   }
 };
@@ -538,7 +619,7 @@ __device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4]
 #ifndef OETR_RING
 #define OETR_RING 3
 #endif
-template <bool SPLIT, int NT>
+template <int M, int NT, bool STREAMED = (gm_half(M) && NT == 1)>
 struct WStream {
   static constexpr int adv(int, int) { return 0; }
   template <int K, int P>
@@ -552,11 +633,12 @@ struct WStream {
 };
 
 #if OETR_WSTREAM
-template <>
-struct WStream<true, 1> {
+template <int M>
+struct WStream<M, 1, true> {
+  static constexpr bool TWO = gm_planes(M) == 2;
   static constexpr int U = 2, D = OETR_RING, PRE = D - 1;
-  struct BChunk { f32x4 bh[U], bl[U]; };
-  struct AChunk { f32x4 ah[U], al[U]; };
+  struct BChunk { f32x4 bh[U], bl[TWO ? U : 1]; };
+  struct AChunk { f32x4 ah[U], al[TWO ? U : 1]; };
   BChunk ring[D];
 
   static constexpr int adv(int P, int K) { return (P + K / 16 / U) % D; }
@@ -566,7 +648,7 @@ struct WStream<true, 1> {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ring[SLOT].bh[u] = wh[(chunk * U + u) * 64];
-      ring[SLOT].bl[u] = wl[(chunk * U + u) * 64];
+      if constexpr (TWO) ring[SLOT].bl[u] = wl[(chunk * U + u) * 64];
     }
   }
   template <int P, int J>
@@ -598,20 +680,19 @@ struct WStream<true, 1> {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           a[(CI + 1) & 1].ah[u] = *reinterpret_cast<const f32x4*>(ah_ptr + ((CI + 1) * U + u) * 16);
-          a[(CI + 1) & 1].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + ((CI + 1) * U + u) * 16);
+          if constexpr (TWO)
+            a[(CI + 1) & 1].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + ((CI + 1) * U + u) * 16);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       const BChunk& b = ring[(P + CI) % D];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, a[CI & 1].ah[u]);
-        const f16x8 al = __builtin_bit_cast(f16x8, a[CI & 1].al[u]);
-        const f16x8 bh = __builtin_bit_cast(f16x8, b.bh[u]);
-        const f16x8 bl = __builtin_bit_cast(f16x8, b.bl[u]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-        cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cross, 0, 0, 0);
-        cross2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cross2, 0, 0, 0);
+        acc = mma16<M>(a[CI & 1].ah[u], b.bh[u], acc);
+        if constexpr (TWO) {
+          cross = mma16<M>(a[CI & 1].ah[u], b.bl[u], cross);
+          cross2 = mma16<M>(a[CI & 1].al[u], b.bh[u], cross2);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       step<K, P, NK, CI + 1>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross, cross2);
@@ -636,13 +717,15 @@ struct WStream<true, 1> {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       a[0].ah[u] = *reinterpret_cast<const f32x4*>(ah_ptr + u * 16);
-      a[0].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + u * 16);
+      if constexpr (TWO) a[0].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + u * 16);
     }
     f32x16 cross = {0}, cross2 = {0};
     step<K, P, NK, 0>(ah_ptr, al_ptr, W + off, Wl + off, NK ? nW + noff : nullptr,
                       NK ? nWl + noff : nullptr, a, acc[0], cross, cross2);
+    if constexpr (TWO) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = fmaf(cross[r] + cross2[r], SPLIT_INV, acc[0][r]);
+      for (int r = 0; r < 16; ++r) acc[0][r] = fmaf(cross[r] + cross2[r], SPLIT_INV, acc[0][r]);
+    }
   }
 };
 #endif  // OETR_WSTREAM
@@ -651,23 +734,28 @@ struct WStream<true, 1> {
 constexpr int RT = 64;                                   // token rows per workgroup
 constexpr int R_FLOATS = (2 * RT * LDAH * 2 + 3) / 4;    // 16896 >= RT * LDA = 16640
 static_assert(R_FLOATS >= RT * LDA, "region holds the f32 tile too");
-struct Planes2 {  // two f16 planes [RT][LDAH] (hi, lo*2^11) in one region
+template <int M>
+struct PlanesT {  // 16-bit planes [RT][LDAH] (hi, and lo*2^11 in GM_SPLIT) in one region
   _Float16 *h, *l;
-  __device__ __forceinline__ explicit Planes2(float* base)
-      : h(reinterpret_cast<_Float16*>(base)), l(reinterpret_cast<_Float16*>(base) + RT * LDAH) {}
+  Range* rg;
+  __device__ __forceinline__ PlanesT(float* base, Range* rg_)
+      : h(reinterpret_cast<_Float16*>(base)), l(reinterpret_cast<_Float16*>(base) + RT * LDAH), rg(rg_) {}
   __device__ __forceinline__ void put4(int row, int c, const f32x4& v) const {
-    store_split4(h + row * LDAH, l + row * LDAH, c, v);
+    store_planes4<M>(h + row * LDAH, l + row * LDAH, c, v, *rg);
   }
   __device__ __forceinline__ void put_acc(int mt, int col0, int lane, const f32x16& acc) const {
-    acc_to_lds_split<1>(h + mt * 32 * LDAH, l + mt * 32 * LDAH, LDAH, col0, lane,
-                        *reinterpret_cast<const f32x16(*)[1]>(&acc));
+    acc_to_lds_planes<M, 1>(h + mt * 32 * LDAH, l + mt * 32 * LDAH, LDAH, col0, lane,
+                            *reinterpret_cast<const f32x16(*)[1]>(&acc), *rg);
   }
 };
+typedef PlanesT<GM_SPLIT> Planes2;
 
 #ifndef OETR_RING2
 #define OETR_RING2 4   // k16 steps of B fragments in the ring (one being consumed)
 #endif
-struct WStream2 {
+template <int M>
+struct WStream2T {
+  static constexpr bool TWO = gm_planes(M) == 2;
   static constexpr int D = OETR_RING2, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
   struct BStep { f32x4 bh, bl; };
   struct AStep { f32x4 ah[2], al[2]; };
@@ -684,7 +772,7 @@ struct WStream2 {
   template <int SLOT>
   __device__ __forceinline__ void fetch(const f32x4* wh, const f32x4* wl, int step) {
     ring[SLOT].bh = wh[step * 64];
-    ring[SLOT].bl = wl[step * 64];
+    if constexpr (TWO) ring[SLOT].bl = wl[step * 64];
   }
   template <int P, int J>
   __device__ __forceinline__ void fetch_first(const f32x4* wh, const f32x4* wl) {
@@ -706,7 +794,7 @@ struct WStream2 {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       a.ah[mt] = *reinterpret_cast<const f32x4*>(ah_ptr + mt * 32 * LDAH + step * 16);
-      a.al[mt] = *reinterpret_cast<const f32x4*>(al_ptr + mt * 32 * LDAH + step * 16);
+      if constexpr (TWO) a.al[mt] = *reinterpret_cast<const f32x4*>(al_ptr + mt * 32 * LDAH + step * 16);
     }
   }
   template <int P, bool HAS_NEXT, int CI>
@@ -721,15 +809,15 @@ struct WStream2 {
       if constexpr (CI + 1 < NS) load_a(a[(CI + 1) & 1], ah_ptr, al_ptr, CI + 1);
       __builtin_amdgcn_sched_barrier(0);
       const BStep& b = ring[(P + CI) % D];
-      const f16x8 bh = __builtin_bit_cast(f16x8, b.bh), bl = __builtin_bit_cast(f16x8, b.bl);
-      const f16x8 a0h = __builtin_bit_cast(f16x8, a[CI & 1].ah[0]), a1h = __builtin_bit_cast(f16x8, a[CI & 1].ah[1]);
-      const f16x8 a0l = __builtin_bit_cast(f16x8, a[CI & 1].al[0]), a1l = __builtin_bit_cast(f16x8, a[CI & 1].al[1]);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[0], 0, 0, 0);
-      if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[1], 0, 0, 0);
-      cross[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[0], 0, 0, 0);
-      if (two) cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[1], 0, 0, 0);
-      cross[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[0], 0, 0, 0);
-      if (two) cross[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[1], 0, 0, 0);
+      const AStep& ac = a[CI & 1];
+      acc[0] = mma16<M>(ac.ah[0], b.bh, acc[0]);
+      if (two) acc[1] = mma16<M>(ac.ah[1], b.bh, acc[1]);
+      if constexpr (TWO) {
+        cross[0] = mma16<M>(ac.ah[0], b.bl, cross[0]);
+        if (two) cross[1] = mma16<M>(ac.ah[1], b.bl, cross[1]);
+        cross[0] = mma16<M>(ac.al[0], b.bh, cross[0]);
+        if (two) cross[1] = mma16<M>(ac.al[1], b.bh, cross[1]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       step<P, HAS_NEXT, CI + 1>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross);
     }
@@ -738,7 +826,7 @@ struct WStream2 {
   // PRE steps of the slab are already in the ring; HAS_NEXT: the next GEMM's slab
   // (nW, nWl, nnt0, nks0 of a matrix with NKTOT/16 steps per n-tile) is primed meanwhile.
   template <int KTOT, int P, bool HAS_NEXT, int NKTOT>
-  __device__ __forceinline__ void gemm(const Planes2& A, const f32x4* W, const f32x4* Wl, int nt0,
+  __device__ __forceinline__ void gemm(const PlanesT<M>& A, const f32x4* W, const f32x4* Wl, int nt0,
                                        int ks0, int lane, f32x16 (&acc)[2], const f32x4* nW,
                                        const f32x4* nWl, int nnt0, int nks0) {
     const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64 + lane;
@@ -751,12 +839,15 @@ struct WStream2 {
     f32x16 cross[2] = {f32x16{0}, f32x16{0}};
     step<P, HAS_NEXT, 0>(ah_ptr, al_ptr, W + off, Wl + off, HAS_NEXT ? nW + noff : nullptr,
                          HAS_NEXT ? nWl + noff : nullptr, a, acc, cross);
+    if constexpr (TWO) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(cross[mt][r], SPLIT_INV, acc[mt][r]);
+        for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(cross[mt][r], SPLIT_INV, acc[mt][r]);
+    }
   }
 };
+typedef WStream2T<GM_SPLIT> WStream2;
 
 #endif  // __HIPCC__
 
@@ -798,6 +889,7 @@ struct EncLaunch {
   int b_cross;           // phase-B layer is a cross layer
   int dbg;               // ablation flags (OETR_ABLATE builds only)
   long long* tbuf;       // per-phase cycle stamps (OETR_PHASE_TIMING builds only)
+  uint32_t* flags;       // the handle's status word (FLAG_F16_RANGE), see Range
 };
 
 // has_b: run phase B (finish a layer); tail: 0 = phase A of next encoder layer,
@@ -805,7 +897,7 @@ struct EncLaunch {
 hipError_t launch_prep_tokens(const Geom& g, const float* feat1, const float* feat2,
                               const float* pos1, const float* pos2, float* x,
                               float* pos_tok, hipStream_t s);
-hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, bool split, hipStream_t s);
+hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, int mode, hipStream_t s);
 
 struct MhaDev {
   const float *wq_t, *wk_t, *wv_t, *wm_t;  // transposed [in][out]
@@ -858,13 +950,14 @@ struct HeatLaunch {
   float* tlbr[2];          // [N][4] per side, or NULL
   float* box[2];           // [N][4] per side, or NULL
   int img_w[2];
+  uint32_t* flags;         // the handle's status word (FLAG_F16_RANGE)
 };
-hipError_t launch_heat_conv(const HeatLaunch& p, bool split, hipStream_t s);
+hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s);
 // Forward path: decoder (2N workgroups) and the hs-independent part of the heat-map
 // conv, P_tap = W_tap . memory (one workgroup per token tile), in ONE launch so that
 // the 16-CU decoder runs beside the conv GEMMs; then the cheap combine
 // conv_out[l] = b + sum_tap att[l+tap] * P_tap[l+tap].
-hipError_t launch_decoder_convp(const DecLaunch& d, const HeatLaunch& h, float* P, bool split,
+hipError_t launch_decoder_convp(const DecLaunch& d, const HeatLaunch& h, float* P, int mode,
                                 hipStream_t s);
 hipError_t launch_heat_combine(const HeatLaunch& h, const float* P, hipStream_t s);
 hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s);
@@ -888,6 +981,7 @@ struct NeckProjLaunch {
   const f32x4 *wh[2], *wl[2];   // input_proj weight, K halves, f16 fragment planes
   const float *bias, *ln_w, *ln_b;
   _Float16 *xh, *xl;            // [rows_in + 1][256] LayerNorm'ed projection, split planes
+  uint32_t* flags;              // the neck handle's status word (FLAG_F16_RANGE)
 };
 struct NeckConvDesc {
   const f32x4 *wh, *wl;   // [split][nhalf][4 n-tiles][256 k16-steps][64 lanes] 16-byte units
@@ -910,6 +1004,7 @@ struct NeckOutLaunch {
   const f32x4 *wh, *wl;   // input_proj2 weight [256][512]
   const float* bias2;
   float* feat;            // [n_img][256][ho*wo]
+  uint32_t* flags;
 };
 hipError_t launch_neck_proj(const NeckProjLaunch& p, hipStream_t s);
 hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s);

@@ -7,7 +7,7 @@
 
 namespace oetr {
 
-template <bool SPLIT>
+template <int MODE>
 __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restrict__ P, int tile,
                                             float* smem) {
   constexpr int NW = 8, NT = 1, THREADS = 64 * NW, WC = 32 * NT;
@@ -28,7 +28,8 @@ __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restri
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
 
   // the tile's own rows, once (rows past the image end re-read the last valid row)
-  const ATile<SPLIT> A(smem, LDA, LDAH);
+  Range rg;
+  const ATile<MODE> A(smem, LDA, LDAH, &rg);
   {
     const int r = tid / TPR, part = tid % TPR;
     const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)min(r, nvalid - 1) * C) + part;
@@ -36,7 +37,7 @@ __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restri
     for (int i = 0; i < F4; ++i) A.put4(r, 4 * (i * TPR + part), mp[i * TPR]);
   }
   __syncthreads();
-  constexpr size_t TAP_UNITS = SPLIT ? (size_t)C * C / 8 : (size_t)C * C / 4;
+  constexpr size_t TAP_UNITS = gm_half(MODE) ? (size_t)C * C / 8 : (size_t)C * C / 4;
   for (int tap = 0; tap < 9; ++tap) {
     f32x16 acc[NT];
 #pragma unroll
@@ -52,15 +53,17 @@ __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restri
         if (row < nvalid) dst[(size_t)row * C + 32 * t] = acc[t][r];
       }
   }
+  range_report<MODE>(rg, p.flags);
 }
 
 // 64-token variant (split mode): every weight fragment of the 9 taps (2.3 MB per
 // workgroup) feeds two MFMA row tiles, and the weight stream runs ahead from tap to
 // tap.  Tiles are 64 consecutive tokens of one image: tile index over
 // N x (ceil(L0/64) + ceil(L1/64)), pair-major like the encoder's.
+template <int MODE>
 __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __restrict__ P, int tile,
                                               float* smem) {
-  static_assert(WStream2::D == 4, "tap loop below assumes a ring phase of 0 after every GEMM");
+  static_assert(WStream2T<MODE>::D == 4, "tap loop below assumes a ring phase of 0 after every GEMM");
   constexpr int THREADS = 512, TPR = THREADS / RT, F4 = 64 / TPR;
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
@@ -77,14 +80,15 @@ __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __rest
   const float* mem = p.mem[side] + ((size_t)n * L + l0) * C;
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
 
-  const Planes2 A(smem);
+  Range rg;
+  const PlanesT<MODE> A(smem, &rg);
   {
     const int r = tid / TPR, part = tid % TPR;
     const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)min(r, nvalid - 1) * C) + part;
 #pragma unroll
     for (int i = 0; i < F4; ++i) A.put4(r, 4 * (i * TPR + part), mp[i * TPR]);
   }
-  WStream2 ws;
+  WStream2T<MODE> ws;
   ws.set_rows(nvalid);
   ws.template prime<C, 0>(p.w.conv_w, p.w.conv_w_l, wave, 0, lane);
   __syncthreads();
@@ -115,6 +119,7 @@ __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __rest
                                      0, lane, acc, nullptr, nullptr, 0, 0);
     store(8, acc);
   }
+  range_report<MODE>(rg, p.flags);
 }
 
 }  // namespace oetr

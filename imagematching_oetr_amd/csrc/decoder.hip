@@ -423,28 +423,44 @@ hipError_t launch_decoder(const DecLaunch& p, hipStream_t s) {
 // Decoder (blocks [0, 2N)) and conv P tiles (blocks [2N, 2N + ntiles)) in one
 // launch: the decoder occupies 2N CUs for ~50 us while the P GEMMs fill the rest
 // of the chip; decoder blocks come first in the grid so they are dispatched first.
-template <bool SPLIT, bool T64>
+template <int MODE, bool T64>
 __global__ __launch_bounds__(512) void k_decoder_convp(DecLaunch d, HeatLaunch h, float* P) {
   constexpr int TILE = T64 ? R_FLOATS : TILE_FLOATS;
   constexpr int LDS_FLOATS = DecSmem<512>::TOTAL > TILE ? DecSmem<512>::TOTAL : TILE;
   __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
   const int nd = 2 * d.g.N;
   if ((int)blockIdx.x < nd) decoder_body<512>(d, blockIdx.x, smem);
-  else if constexpr (T64) conv_p_body64(h, P, blockIdx.x - nd, smem);
-  else conv_p_body<SPLIT>(h, P, blockIdx.x - nd, smem);
+  else if constexpr (T64) conv_p_body64<MODE>(h, P, blockIdx.x - nd, smem);
+  else conv_p_body<MODE>(h, P, blockIdx.x - nd, smem);
 }
 
-hipError_t launch_decoder_convp(const DecLaunch& d, const HeatLaunch& h, float* P, bool split,
-                                hipStream_t s) {
-  // conv-P tiles: 64 tokens in split mode when the encoder runs 64-token workgroups too
-  // (d.g carries the encoder's tile bookkeeping), else TM tokens (h.g)
-  const bool t64 = split && d.g.ntiles != h.g.ntiles;
+template <int MODE>
+static hipError_t launch_decoder_convp_mode(const DecLaunch& d, const HeatLaunch& h, float* P,
+                                            hipStream_t s) {
+  // conv-P tiles: 64 tokens in the 16-bit-plane modes when the encoder runs 64-token
+  // workgroups too (d.g carries the encoder's tile bookkeeping), else TM tokens (h.g)
+  const bool t64 = gm_half(MODE) && d.g.ntiles != h.g.ntiles;
   const int ptiles = t64 ? h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT) : h.g.ntiles;
   const dim3 grid(2 * d.g.N + ptiles);
-  if (t64) hipLaunchKernelGGL((k_decoder_convp<true, true>), grid, dim3(512), 0, s, d, h, P);
-  else if (split) hipLaunchKernelGGL((k_decoder_convp<true, false>), grid, dim3(512), 0, s, d, h, P);
-  else hipLaunchKernelGGL((k_decoder_convp<false, false>), grid, dim3(512), 0, s, d, h, P);
+  if constexpr (gm_half(MODE)) {
+    if (t64) {
+      hipLaunchKernelGGL((k_decoder_convp<MODE, true>), grid, dim3(512), 0, s, d, h, P);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((k_decoder_convp<MODE, false>), grid, dim3(512), 0, s, d, h, P);
   return hipGetLastError();
+}
+
+hipError_t launch_decoder_convp(const DecLaunch& d, const HeatLaunch& h, float* P, int mode,
+                                hipStream_t s) {
+  switch (mode) {
+    case GM_F32: return launch_decoder_convp_mode<GM_F32>(d, h, P, s);
+    case GM_SPLIT: return launch_decoder_convp_mode<GM_SPLIT>(d, h, P, s);
+    case GM_F16: return launch_decoder_convp_mode<GM_F16>(d, h, P, s);
+    case GM_BF16: return launch_decoder_convp_mode<GM_BF16>(d, h, P, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace oetr

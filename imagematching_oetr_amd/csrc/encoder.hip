@@ -181,19 +181,21 @@ __device__ __forceinline__ void load_tile(float* S, const float* __restrict__ sr
   }
 }
 
-template <bool HAS_B, int TAIL, bool SPLIT, int NW>
+template <bool HAS_B, int TAIL, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
+  constexpr bool SPLIT = gm_half(MODE);  // GEMM operands live in 16-bit LDS planes
   using Cfg = EncCfg<NW>;
   constexpr int NT = Cfg::NT, THREADS = Cfg::THREADS, WC = Cfg::WC, TPR = Cfg::TPR, F4 = Cfg::F4;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* S0 = smem + S0_OFF;
-  const ATile<SPLIT> S1(smem + S1_OFF, LDA, LDAH);
-  const ATile<SPLIT> S2(smem + H_OFF, LDA, LDAH);
-  const ATile<SPLIT> Hh(smem + H_OFF, LDH, LDHH);
+  Range rg;  // f16 range guard of this thread's operand conversions (common.h)
+  const ATile<MODE> S1(smem + S1_OFF, LDA, LDAH, &rg);
+  const ATile<MODE> S2(smem + H_OFF, LDA, LDAH, &rg);
+  const ATile<MODE> Hh(smem + H_OFF, LDH, LDHH, &rg);
   float* ksum_s = smem + KSUM_OFF;
   float* z_s = smem + Z_OFF;
   float* lnp_s = smem + LNP_OFF;
-  using WS = WStream<SPLIT, NT>;
+  using WS = WStream<MODE, NT>;
   WS ws;  // this wave's weight stream (runs ahead across the GEMMs below)
   // ring slot of each GEMM's first chunk
   constexpr int P_MERGE = 0;
@@ -481,8 +483,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
         bias_k[dl][t] = p.d.bk[dl][wcol + 32 * t + col];
         bias_v[dl][t] = p.d.bv[dl][wcol + 32 * t + col];
       }
-    const ATile<SPLIT> S0t(S0, LDA, LDAH);
-    const ATile<SPLIT>& Vin = SPLIT ? S2 : S0t;  // f32 mode reads the memory tile itself
+    const ATile<MODE> S0t(S0, LDA, LDAH, &rg);
+    const ATile<MODE>& Vin = SPLIT ? S2 : S0t;  // f32 mode reads the memory tile itself
     auto dec_layer = [&](auto DL) {
       constexpr int dl = decltype(DL)::value;
       constexpr int PK = dl == 0 ? P_T0 : P_T2, PV = dl == 0 ? P_T1 : P_T3;
@@ -529,6 +531,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     dec_layer(std::integral_constant<int, 0>{});
     dec_layer(std::integral_constant<int, 1>{});
   }
+  range_report<MODE>(rg, p.flags);
 }
 
 // ===========================================================================
@@ -604,17 +607,18 @@ __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int
   if (lane < 32) ks_out[(size_t)slot * C + wave * HD + lane] = ksum;
 }
 
-template <bool HAS_B, int TAIL>
+template <bool HAS_B, int TAIL, int MODE>
 __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
   constexpr int THREADS = 512, TPR = 8, F4 = 8;
   __shared__ __attribute__((aligned(16))) float smem[E2_SMEM];
   float* R1f = smem + E2_R1;
   float* R2f = smem + E2_R2;
-  const Planes2 P1(R1f), P2(R2f);
+  Range rg;
+  const PlanesT<MODE> P1(R1f, &rg), P2(R2f, &rg);
   float* ksum_s = smem + E2_KSUM;
   float* z_s = smem + E2_Z;
   float* lnp_s = smem + E2_LNP;
-  using WS = WStream2;
+  using WS = WStream2T<MODE>;
   WS ws;
   constexpr int P_MERGE = 0;
   constexpr int P_1A = WS::adv(P_MERGE), P_2A = WS::adv(P_1A), P_1B = WS::adv(P_2A), P_2B = WS::adv(P_1B);
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
         }
     }
     PHASE_STAMP(p, 8);
-    if (TAIL == 2) return;
+    if (TAIL == 2) { range_report<MODE>(rg, p.flags); return; }
     // (R1 planes were last read by MLP1b, which every wave finished before the barrier above)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -965,6 +969,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     dec_layer(std::integral_constant<int, 0>{});
     dec_layer(std::integral_constant<int, 1>{});
   }
+  range_report<MODE>(rg, p.flags);
 }
 
 #ifndef OETR_SPLIT_WAVES
@@ -974,31 +979,27 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
 #define OETR_F32_WAVES 4
 #endif
 
-hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, bool split, hipStream_t s) {
+template <int MODE>
+static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, hipStream_t s) {
   const dim3 grid(p.g.ntiles);
-  if (split && p.tile_rows == RT) {
-#define OETR_LAUNCH64(B, T) hipLaunchKernelGGL((k_encoder64<B, T>), grid, dim3(512), 0, s, p)
-    if (has_b) {
-      if (tail == 0) OETR_LAUNCH64(true, 0);
-      else if (tail == 1) OETR_LAUNCH64(true, 1);
-      else OETR_LAUNCH64(true, 2);
-    } else {
-      if (tail == 0) OETR_LAUNCH64(false, 0);
-      else if (tail == 1) OETR_LAUNCH64(false, 1);
-      else return hipErrorInvalidValue;
-    }
+  if constexpr (gm_half(MODE)) {
+    if (p.tile_rows == RT) {
+#define OETR_LAUNCH64(B, T) hipLaunchKernelGGL((k_encoder64<B, T, MODE>), grid, dim3(512), 0, s, p)
+      if (has_b) {
+        if (tail == 0) OETR_LAUNCH64(true, 0);
+        else if (tail == 1) OETR_LAUNCH64(true, 1);
+        else OETR_LAUNCH64(true, 2);
+      } else {
+        if (tail == 0) OETR_LAUNCH64(false, 0);
+        else if (tail == 1) OETR_LAUNCH64(false, 1);
+        else return hipErrorInvalidValue;
+      }
 #undef OETR_LAUNCH64
-    return hipGetLastError();
+      return hipGetLastError();
+    }
   }
-#define OETR_LAUNCH(B, T)                                                                      \
-  do {                                                                                         \
-    if (split)                                                                                 \
-      hipLaunchKernelGGL((k_encoder<B, T, true, OETR_SPLIT_WAVES>), grid,                      \
-                         dim3(64 * OETR_SPLIT_WAVES), 0, s, p);                                \
-    else                                                                                       \
-      hipLaunchKernelGGL((k_encoder<B, T, false, OETR_F32_WAVES>), grid,                       \
-                         dim3(64 * OETR_F32_WAVES), 0, s, p);                                  \
-  } while (0)
+  constexpr int NW = gm_half(MODE) ? OETR_SPLIT_WAVES : OETR_F32_WAVES;
+#define OETR_LAUNCH(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, NW>), grid, dim3(64 * NW), 0, s, p)
   if (has_b) {
     if (tail == 0) OETR_LAUNCH(true, 0);
     else if (tail == 1) OETR_LAUNCH(true, 1);
@@ -1010,6 +1011,16 @@ hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, bool split, 
   }
 #undef OETR_LAUNCH
   return hipGetLastError();
+}
+
+hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, int mode, hipStream_t s) {
+  switch (mode) {
+    case GM_F32: return launch_encoder_mode<GM_F32>(p, has_b, tail, s);
+    case GM_SPLIT: return launch_encoder_mode<GM_SPLIT>(p, has_b, tail, s);
+    case GM_F16: return launch_encoder_mode<GM_F16>(p, has_b, tail, s);
+    case GM_BF16: return launch_encoder_mode<GM_BF16>(p, has_b, tail, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace oetr

@@ -23,7 +23,7 @@ constexpr float GN_EPS = 1e-5f;
 // ---------------------------------------------------------------------------
 // NW waves per workgroup (4 for the exact-f32 mode, 8 for the split mode: see
 // encoder.hip); wave w owns NT = 8/NW 32-column tiles of the 256 outputs.
-template <bool SPLIT, int NW>
+template <int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
   constexpr int NT = 8 / NW, THREADS = 64 * NW, WC = 32 * NT;
   constexpr int TPR = THREADS / TM, F4 = 64 / TPR;  // threads / float4s per row when staging
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
   const int nvalid = min(TM, L - l0);
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
   const float* mem = p.mem[side] + (size_t)n * L * C;
+  Range rg;
   // att[l'] = memory[l'] . hs for the halo rows l0-wf-1 .. l0+TM+wf of this tile,
   // once (not per tap): TPR threads per row, DPP row sums.
   __shared__ float att_s[TM + 2 * (100 + 1) + 6];
@@ -69,9 +70,32 @@ __global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
     }
   }
   __syncthreads();
+  // The conv input memory*att is the largest-magnitude tensor of the path (att is a
+  // 256-term dot product).  conv is linear, so this tile's att weights are divided by a
+  // power of two >= max |att| over its halo (exact) and the GEMM result is multiplied
+  // back: the operands the f16-based modes convert are then bounded by |memory|.
+  __shared__ float attmax_s[THREADS / 64];
+  {
+    float m = 0.f;
+    for (int i = tid; i < nhalo; i += THREADS) m = fmaxf(m, fabsf(att_s[i]));
+    m = wave_max(m);
+    if (lane == 0) attmax_s[wave] = m;
+  }
+  __syncthreads();
+  float att_scale = 1.0f, att_unscale = 1.0f;
+  {
+    float m = attmax_s[0];
+#pragma unroll
+    for (int i = 1; i < THREADS / 64; ++i) m = fmaxf(m, attmax_s[i]);
+    if (m > 0.f && m < INFINITY) {
+      const int e = ilogbf(m) + 1;          // 2^e > m
+      att_scale = ldexpf(1.0f, -e);
+      att_unscale = ldexpf(1.0f, e);
+    }
+  }
 
   // gather + scale one tap tile (TPR threads per row, float4 columns i*TPR + part)
-  auto stage = [&](int tap, const ATile<SPLIT>& S) {
+  auto stage = [&](int tap, const ATile<MODE>& S) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     const int l = l0 + hrow;
     const int y = l / wf, x = l - y * wf;
@@ -80,24 +104,24 @@ __global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
     // unconditional load from a clamped row + select: a guarded load would cost
     // a branch and a vmcnt(0) round trip per row
     const int src_row = ok ? yy * wf + xx : 0;
-    const float att = ok ? att_s[src_row - halo0] : 0.f;
+    const float att = ok ? att_s[src_row - halo0] * att_scale : 0.f;
     const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)src_row * C) + hpart;
 #pragma unroll
     for (int i = 0; i < F4; ++i) S.put4(hrow, 4 * (i * TPR + hpart), mp[i * TPR] * att);
   };
 
   f32x16 acc[NT];
+  float bias[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const float b = p.w.conv_b[WC * wave + 32 * t + col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+    bias[t] = p.w.conv_b[WC * wave + 32 * t + col];
+    acc[t] = f32x16{0};
   }
-  const ATile<SPLIT> buf[2] = {ATile<SPLIT>(smem, LDA, LDAH),
-                              ATile<SPLIT>(smem + TILE_FLOATS, LDA, LDAH)};
+  const ATile<MODE> buf[2] = {ATile<MODE>(smem, LDA, LDAH, &rg),
+                              ATile<MODE>(smem + TILE_FLOATS, LDA, LDAH, &rg)};
   // f32 mode: tap t = [256 out][256 in] of 4-byte values -> C*C/4 float4 units;
   // split mode: f16 values -> C*C/8 16-byte units per plane.
-  constexpr size_t TAP_UNITS = SPLIT ? (size_t)C * C / 8 : (size_t)C * C / 4;
+  constexpr size_t TAP_UNITS = gm_half(MODE) ? (size_t)C * C / 8 : (size_t)C * C / 4;
   stage(0, buf[0]);
   __syncthreads();
   for (int tap = 0; tap < 9; ++tap) {
@@ -106,6 +130,11 @@ __global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
                                       NT * wave, lane, acc, 0);
     __syncthreads();
   }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(acc[t][r], att_unscale, bias[t]);
+  range_report<MODE>(rg, p.flags);
 
   // conv output + per-(tile, group) moments for GroupNorm
 #pragma unroll
@@ -142,9 +171,15 @@ __global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
   }
 }
 
-hipError_t launch_heat_conv(const HeatLaunch& p, bool split, hipStream_t s) {
-  if (split) hipLaunchKernelGGL((k_heat_conv<true, 8>), dim3(p.g.ntiles), dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((k_heat_conv<false, 4>), dim3(p.g.ntiles), dim3(256), 0, s, p);
+hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s) {
+  const dim3 grid(p.g.ntiles);
+  switch (mode) {
+    case GM_F32: hipLaunchKernelGGL((k_heat_conv<GM_F32, 4>), grid, dim3(256), 0, s, p); break;
+    case GM_SPLIT: hipLaunchKernelGGL((k_heat_conv<GM_SPLIT, 8>), grid, dim3(512), 0, s, p); break;
+    case GM_F16: hipLaunchKernelGGL((k_heat_conv<GM_F16, 8>), grid, dim3(512), 0, s, p); break;
+    case GM_BF16: hipLaunchKernelGGL((k_heat_conv<GM_BF16, 8>), grid, dim3(512), 0, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ constexpr int NP_SMEM = NP_PAR_OFF + 2 * C;      // LayerNorm affine
 
 // Stage channels [kh*512, kh*512+512) of 32 positions: NCHW rows (one channel,
 // 32 consecutive positions = 128 B per half-wave) -> LDS [pos][channel] planes.
-__device__ __forceinline__ void proj_stage(const ATile<true>& A, const float* src, int HW,
+__device__ __forceinline__ void proj_stage(const ATile<GM_SPLIT>& A, const float* src, int HW,
                                            int tid) {
   const int pos = tid & 31, cg = tid >> 5;
 #pragma unroll
@@ -49,7 +49,10 @@ __device__ __forceinline__ void proj_stage(const ATile<true>& A, const float* sr
     for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(cb * 8 + j) * HW];
     f16x2 h[4], l[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    for (int j = 0; j < 4; ++j) {
+      A.rg->see(v[2 * j], v[2 * j + 1]);
+      split2(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    }
     const f16x8 hv = {h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
     const f16x8 lv = {l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
     *reinterpret_cast<f16x8*>(A.h + pos * A.ldh + cb * 8) = hv;
@@ -59,7 +62,8 @@ __device__ __forceinline__ void proj_stage(const ATile<true>& A, const float* sr
 
 __global__ __launch_bounds__(512) void k_neck_proj(NeckProjLaunch p) {
   __shared__ __attribute__((aligned(16))) float smem[NP_SMEM];
-  const ATile<true> A(smem, LDH, LDHH);
+  Range rg;
+  const ATile<GM_SPLIT> A(smem, LDH, LDHH, &rg);
   float* S0 = smem + NP_S0_OFF;
   float* par = smem + NP_PAR_OFF;
   const NeckGeom& g = p.g;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(512) void k_neck_proj(NeckProjLaunch p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = b;
   }
-  using WS = WStream<true, 1>;
+  using WS = WStream<GM_SPLIT, 1>;
   WS ws;
   constexpr int P0 = 0, P1 = WS::adv(P0, 512);
   const float* src = p.bb + (size_t)img * BBC * g.HW + p0 + min(tid & 31, nvalid - 1);
@@ -105,8 +109,9 @@ __global__ __launch_bounds__(512) void k_neck_proj(NeckProjLaunch p) {
     const f32x4* gb = reinterpret_cast<const f32x4*>(par + C) + lpart;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      store_split4(p.xh + row * C, p.xl + row * C, 4 * (i * 16 + lpart), xn[i] * gw[i * 16] + gb[i * 16]);
+      store_split4(p.xh + row * C, p.xl + row * C, 4 * (i * 16 + lpart), xn[i] * gw[i * 16] + gb[i * 16], rg);
   }
+  range_report<GM_SPLIT>(rg, p.flags);
 }
 
 hipError_t launch_neck_proj(const NeckProjLaunch& p, hipStream_t s) {
@@ -281,13 +286,14 @@ hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_neck_out(NeckOutLaunch p) {
   __shared__ __attribute__((aligned(16))) float smem[NP_PAR_OFF];
-  const ATile<true> A(smem, LDH, LDHH);
+  Range rg;
+  const ATile<GM_SPLIT> A(smem, LDH, LDHH, &rg);
   float* S0 = smem + NP_S0_OFF;
   const NeckGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31;
   const int r0 = blockIdx.x * TM;
 
-  using WS = WStream<true, 1>;
+  using WS = WStream<GM_SPLIT, 1>;
   WS ws;
   f32x16 acc[1];
   {
@@ -334,6 +340,7 @@ __global__ __launch_bounds__(512) void k_neck_out(NeckOutLaunch p) {
       }
     }
   }
+  range_report<GM_SPLIT>(rg, p.flags);
 }
 
 hipError_t launch_neck_out(const NeckOutLaunch& p, hipStream_t s) {

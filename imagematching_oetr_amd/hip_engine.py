@@ -68,7 +68,10 @@ EXPORTS = (
     'oetr_full_attention', 'oetr_trace_create', 'oetr_trace_destroy',
     'oetr_set_trace', 'oetr_trace_summary', 'oetr_neck_create',
     'oetr_neck_destroy', 'oetr_neck_workspace_bytes', 'oetr_neck_forward',
-    'oetr_neck_set_trace', 'oetr_set_encoder_tile')
+    'oetr_neck_set_trace', 'oetr_set_encoder_tile', 'oetr_query_flags',
+    'oetr_neck_query_flags')
+
+FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
 
 def hot_path_keys():
@@ -178,6 +181,10 @@ def load_library(path=None):
     lib.oetr_neck_forward.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp]
     lib.oetr_neck_set_trace.restype = i
     lib.oetr_neck_set_trace.argtypes = [vp, vp]
+    for name in ('oetr_query_flags', 'oetr_neck_query_flags'):
+        fn = getattr(lib, name)
+        fn.restype = i
+        fn.argtypes = [vp, vp, C.POINTER(C.c_uint32), i]
     if lib.oetr_abi_version() != ABI_VERSION:
         raise RuntimeError(f'{p}: ABI version {lib.oetr_abi_version()} != '
                            f'{ABI_VERSION}')
@@ -190,6 +197,11 @@ class OetrError(RuntimeError):
     pass
 
 
+class OetrRangeError(OetrError):
+    """A GEMM operand left the f16 range of an f16-based precision
+    (``OETR_FLAG_F16_RANGE``): the outputs of that call are invalid."""
+
+
 def _check(lib, status, what):
     if status != 0:
         msg = lib.oetr_last_error().decode(errors='replace')
@@ -197,8 +209,16 @@ def _check(lib, status, what):
         raise exc(f'{what} failed (status {status}): {msg}')
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """torch's current HIP stream ON ``device`` (not on the current device)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _query_flags(lib, fn, handle, device, clear):
+    flags = C.c_uint32(0)
+    with torch.cuda.device(device):
+        _check(lib, fn(handle, _stream(device), C.byref(flags), int(bool(clear))), fn.__name__)
+    return int(flags.value)
 
 
 def _dev(t, name):
@@ -217,13 +237,18 @@ class HotPathEngine:
     fills 208 of 256 CUs, a second stream fills the rest: +23 % throughput)."""
 
     #: GEMM arithmetic modes (oetr_dtype in the header)
-    PRECISIONS = {'f32': 0, 'f32_split_f16': 1}
+    PRECISIONS = {'f32': 0, 'f32_split_f16': 1, 'f16': 2, 'bf16': 3}
+    #: precisions whose GEMM operands are f16 values (|x| < 65504, see query_flags)
+    F16_RANGE = ('f32_split_f16', 'f16')
 
     def __init__(self, weights, device=None, precision='f32_split_f16', enc_tile=None):
         """``precision``: 'f32' = exact fp32 MFMA products; 'f32_split_f16' =
         fp32-class results from 3 f16 MFMAs per product (default; same parity
-        tolerances, ~2x faster).  ``enc_tile``: token rows per encoder
-        workgroup, None = auto, 32 or 64 (``oetr_set_encoder_tile``)."""
+        tolerances, ~2x faster); 'f16' / 'bf16' = GEMM operands rounded to
+        f16 / bf16, one MFMA per product, fp32 accumulate and fp32 everything
+        else (BASELINE configs[4] / configs[2]; reduced parity margin).
+        ``enc_tile``: token rows per encoder workgroup, None = auto, 32 or 64
+        (``oetr_set_encoder_tile``)."""
         self.lib = load_library()
         if precision not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {sorted(self.PRECISIONS)}')
@@ -301,6 +326,21 @@ class HotPathEngine:
         _check(self.lib, self.lib.oetr_set_encoder_tile(self._h, int(rows or 0)),
                'oetr_set_encoder_tile')
 
+    def query_flags(self, clear=True):
+        """Status word of the handle (``oetr_query_flags``): synchronises
+        torch's current stream on the engine's device.  Bit
+        ``FLAG_F16_RANGE`` = a GEMM operand of an earlier call reached the f16
+        range (f16-based precisions): that call's outputs are invalid."""
+        return _query_flags(self.lib, self.lib.oetr_query_flags, self._h, self.device, clear)
+
+    def check_range(self):
+        """Raise :class:`OetrRangeError` if any call since the last check
+        overflowed the f16 operand range (clears the flag)."""
+        if self.query_flags(clear=True) & FLAG_F16_RANGE:
+            raise OetrRangeError(
+                f"a GEMM operand reached |x| >= 65504 under precision "
+                f"'{self.precision}': results are invalid; use precision 'f32' or 'bf16'")
+
     # ------------------------------------------------------------ helpers
     def workspace(self, n, hf1, wf1, hf2, wf2):
         need = self.lib.oetr_workspace_bytes(self._h, n, hf1, wf1, hf2, wf2)
@@ -349,7 +389,7 @@ class HotPathEngine:
                 ws.data_ptr(), ws.numel(), box1.data_ptr(), box2.data_ptr()]
         with torch.cuda.device(dev):
             if not stages:
-                _check(self.lib, self.lib.oetr_forward(*args, _stream()),
+                _check(self.lib, self.lib.oetr_forward(*args, _stream(dev)),
                        'oetr_forward')
                 return box1, box2
             L1, L2 = hf1 * wf1, hf2 * wf2
@@ -370,7 +410,7 @@ class HotPathEngine:
             for k, t in out.items():
                 setattr(st, k, t.data_ptr())
             _check(self.lib, self.lib.oetr_forward_stages(
-                *args, C.byref(st), _stream()), 'oetr_forward_stages')
+                *args, C.byref(st), _stream(dev)), 'oetr_forward_stages')
             out['box1'], out['box2'] = box1, box2
             if enc_layers < N_ENC:
                 out = {k: out[k] for k in ('memory1', 'memory2')}
@@ -393,7 +433,7 @@ class HotPathEngine:
                 self._h, feat1.data_ptr(), feat2.data_ptr(), pos1.data_ptr(),
                 pos2.data_ptr(), n, hf1, wf1, hf2, wf2, ws.data_ptr(),
                 ws.numel(), hs1.data_ptr(), hs2.data_ptr(), m1.data_ptr(),
-                m2.data_ptr(), _stream()), 'oetr_feature_correlation')
+                m2.data_ptr(), _stream(dev)), 'oetr_feature_correlation')
         return hs1, hs2, m1, m2
 
     def center_estimation(self, hs1, hs2, memory1, memory2, hf1, wf1, hf2, wf2,
@@ -412,7 +452,7 @@ class HotPathEngine:
                 self._h, hs1.data_ptr(), hs2.data_ptr(), memory1.data_ptr(),
                 memory2.data_ptr(), n, hf1, wf1, hf2, wf2, int(img_h1),
                 int(img_h2), ws.data_ptr(), ws.numel(), c1.data_ptr(),
-                c2.data_ptr(), _stream()), 'oetr_center_estimation')
+                c2.data_ptr(), _stream(self.device)), 'oetr_center_estimation')
         return c1, c2
 
     def size_regression(self, hs1, hs2):
@@ -423,7 +463,7 @@ class HotPathEngine:
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.oetr_size_regression(
                 self._h, hs1.data_ptr(), hs2.data_ptr(), n, t1.data_ptr(),
-                t2.data_ptr(), _stream()), 'oetr_size_regression')
+                t2.data_ptr(), _stream(self.device)), 'oetr_size_regression')
         return t1, t2
 
 
@@ -499,10 +539,22 @@ class NeckEngine:
         if ws is None or ws.numel() < need:
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         feat = torch.empty(n, D_MODEL, hb // 2, wb // 2, device=self.device)
-        _check(self.lib, self.lib.oetr_neck_forward(
-            self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
-            feat.data_ptr(), _stream()), 'oetr_neck_forward')
+        # launch on the ENGINE's device and on torch's current stream of that device
+        # (the model may live on a GPU that is not torch's current device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.oetr_neck_forward(
+                self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
+                feat.data_ptr(), _stream(self.device)), 'oetr_neck_forward')
         return feat
+
+    def query_flags(self, clear=True):
+        """Status word of the neck handle (see ``HotPathEngine.query_flags``)."""
+        return _query_flags(self.lib, self.lib.oetr_neck_query_flags, self._h, self.device, clear)
+
+    def check_range(self):
+        if self.query_flags(clear=True) & FLAG_F16_RANGE:
+            raise OetrRangeError('a backbone feature / neck intermediate reached |x| >= 65504 '
+                                 '(the HIP neck uses f16-split GEMMs): results are invalid')
 
 
 class KernelTrace:
@@ -560,7 +612,7 @@ def box_tlbr_to_xyxy(cxy, tlbr, max_h, max_w):
     with torch.cuda.device(cxy.device):
         _check(lib, lib.oetr_box_tlbr_to_xyxy(
             cxy.data_ptr(), tlbr.data_ptr(), n, int(max_h), int(max_w),
-            box.data_ptr(), _stream()), 'oetr_box_tlbr_to_xyxy')
+            box.data_ptr(), _stream(cxy.device)), 'oetr_box_tlbr_to_xyxy')
     return box
 
 
@@ -576,7 +628,7 @@ def _attention(fn_name, q, k, v):
     with torch.cuda.device(q.device):
         _check(lib, getattr(lib, fn_name)(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), n, L, S, out.data_ptr(),
-            _stream()), fn_name)
+            _stream(q.device)), fn_name)
     return out
 
 

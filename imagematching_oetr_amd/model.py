@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from .backbone import PatchMerging, PositionEncodingSine, ResnetEncoder
-from .hip_engine import HotPathEngine, NeckEngine, hot_path_keys, neck_keys
+from .hip_engine import (FLAG_F16_RANGE, HotPathEngine, NeckEngine, OetrRangeError,
+                         hot_path_keys, neck_keys)
 
 
 class _EncoderLayerParams(nn.Module):
@@ -113,8 +114,17 @@ class OETR(nn.Module):
         self.max_shape = cfg.NECK.MAX_SHAPE
         self.cycle = cfg.LOSS.CYCLE_OVERLAP
         self.softmax_temperature = 1
-        #: GEMM arithmetic of the HIP hot path: 'f32_split_f16' (default) or 'f32'
+        #: GEMM arithmetic of the HIP hot path: 'f32_split_f16' (default, fp32-class),
+        #: 'f32' (exact), 'f16' / 'bf16' (operands rounded, reduced parity margin)
         self.hip_precision = 'f32_split_f16'
+        #: what forward_dummy does when an f16-based precision ('f32_split_f16', 'f16',
+        #: and the HIP neck) reports an operand beyond the f16 range (|x| >= 65504):
+        #: 'f32' = redo the batch with exact-fp32 MFMA (neck: the torch modules),
+        #: 'raise' = OetrRangeError, 'ignore' = do not query (no stream sync)
+        self.hip_on_overflow = 'f32'
+        #: True: the engines are bound to the weights once and only rebuilt by
+        #: invalidate_engine() (skips the per-call parameter identity check)
+        self.hip_freeze_weights = False
         #: token rows per encoder workgroup: None = auto, 32 or 64 (HotPathEngine.set_encoder_tile)
         self.hip_enc_tile = None
         #: run input_proj -> PatchMerging -> input_proj2 as HIP kernels when the
@@ -122,6 +132,7 @@ class OETR(nn.Module):
         self.hip_neck = True
         self._engine = None
         self._engine_key = None
+        self._engine_f32 = None
         self._neck_engine = None
         self._neck_key = None
 
@@ -131,14 +142,25 @@ class OETR(nn.Module):
         (reference ``src/model.py:113-118``): the HIP neck on a GPU, the torch
         modules otherwise (host code either way)."""
         if self.hip_neck and x.is_cuda:
-            return self.neck_engine().forward(x)
+            eng = self.neck_engine()
+            feat = eng.forward(x)
+            if self.hip_on_overflow != 'ignore' and eng.query_flags() & FLAG_F16_RANGE:
+                if self.hip_on_overflow == 'raise':
+                    raise OetrRangeError('backbone features exceed the f16 range of the HIP neck')
+                return self._neck_torch(x)      # exact fp32 route (torch/MIOpen)
+            return feat
+        return self._neck_torch(x)
+
+    def _neck_torch(self, x):
         return self.input_proj2(self.patchmerging(self.input_proj(x)))
 
     def feature_extraction(self, image1, image2, mask1=None, mask2=None):
         """Reference ``src/model.py:109-130``.  Same-sized image batches go through
         the trunk and the neck as ONE batch of 2N images (per-sample ops: same
         results, half the launches)."""
-        if image1.shape == image2.shape:
+        if image1.shape == image2.shape and not self.training:
+            # (eval only: in train() mode one batch of 2N would change the BatchNorm
+            #  statistics against the reference's two separate trunk calls)
             n = image1.shape[0]
             f = self.neck(self.backbone(torch.cat([image1, image2], dim=0)))
             feat1, feat2 = f[:n], f[n:]
@@ -155,13 +177,35 @@ class OETR(nn.Module):
         sd = self.state_dict()
         return {k: sd[k] for k in hot_path_keys()}
 
+    def invalidate_engine(self):
+        """Drop the HIP engines (repacked weight copies, folded decoder constants):
+        the next call rebuilds them from the module's current parameters.  Needed
+        after writes the identity check below cannot see - ``param.data.copy_()``,
+        ``param.data.mul_()``, an EMA swap through ``.data`` - which neither move the
+        storage nor bump ``param._version``."""
+        self._engine = self._engine_key = self._engine_f32 = None
+        self._neck_engine = self._neck_key = None
+
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .half(): storages move
+        self.invalidate_engine()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_engine()
+        return super().load_state_dict(*args, **kwargs)
+
     def engine(self):
         """HIP engine bound to the current hot-path weights; rebuilt when a
-        weight tensor was replaced or written in place."""
+        weight tensor was replaced or written in place through autograd-visible
+        ops (see :meth:`invalidate_engine` for the writes it cannot see)."""
+        if self.hip_freeze_weights and self._engine is not None and \
+                self._engine_key[:2] == (self.hip_precision, self.hip_enc_tile):
+            return self._engine
         params = [self.get_parameter(k) for k in hot_path_keys()]
         key = (self.hip_precision, self.hip_enc_tile) + tuple(
             (p.data_ptr(), p._version) for p in params)
         if self._engine is None or key != self._engine_key:
+            self._engine_f32 = None
             dev = params[0].device
             if dev.type != 'cuda':
                 raise RuntimeError(
@@ -173,8 +217,21 @@ class OETR(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def exact_engine(self):
+        """Exact-fp32 MFMA engine on the same weights: the route taken when an
+        f16-based precision reports an operand out of range."""
+        main = self.engine()
+        if self.hip_precision == 'f32':
+            return main
+        if self._engine_f32 is None:
+            self._engine_f32 = HotPathEngine(self.hot_path_state(), device=main.device,
+                                             precision='f32')
+        return self._engine_f32
+
     def neck_engine(self):
         """HIP neck bound to the current neck weights (rebuilt when they change)."""
+        if self.hip_freeze_weights and self._neck_engine is not None:
+            return self._neck_engine
         params = [self.get_parameter(k) for k in neck_keys()]
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._neck_engine is None or key != self._neck_key:
@@ -222,8 +279,21 @@ class OETR(nn.Module):
         self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
         feat1, feat2, pos1, pos2, _, _, _, _ = self.feature_extraction(
             image1, image2)
-        return self.engine().forward(feat1, feat2, pos1, pos2, (h1, w1),
-                                     (h2, w2))
+        return self.boxes_from_features(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2))
+
+    def boxes_from_features(self, feat1, feat2, pos1, pos2, hw1, hw2):
+        """Everything after ``feature_extraction`` (reference ``src/model.py:239-252``)
+        as one fused HIP call, with the f16 range guard of the chosen precision."""
+        eng = self.engine()
+        boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2)
+        if self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE \
+                and eng.query_flags() & FLAG_F16_RANGE:
+            if self.hip_on_overflow == 'raise':
+                raise OetrRangeError(
+                    f"a GEMM operand reached |x| >= 65504 under hip_precision="
+                    f"'{eng.precision}'; set hip_precision to 'f32' or 'bf16'")
+            boxes = self.exact_engine().forward(feat1, feat2, pos1, pos2, hw1, hw2)
+        return boxes
 
     def forward(self, data, validation=False):
         raise NotImplementedError(

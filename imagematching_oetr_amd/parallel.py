@@ -34,8 +34,10 @@ def bucket_by_shape(shapes):
 
 def gather_boxes(box1, box2, n_pairs, group=None):
     """All-gather this rank's ``[n_local,4]`` boxes into the full
-    ``([n_pairs,4], [n_pairs,4])`` in shard order.  Works on any backend
-    (RCCL on GPUs, gloo on CPU tensors in tests)."""
+    ``([n_pairs,4], [n_pairs,4])`` in shard order: ONE ``all_gather_into_tensor``
+    of the (padded) ``[cap,2,4]`` shard.  The same code runs on every backend - RCCL
+    on GPUs, gloo on CPU tensors in the tests - so the CPU tests execute exactly the
+    collective the GPUs will."""
     if not (dist.is_available() and dist.is_initialized()):
         return box1, box2
     world = dist.get_world_size(group)
@@ -44,26 +46,17 @@ def gather_boxes(box1, box2, n_pairs, group=None):
     if box1.shape[0] != hi - lo or box2.shape[0] != hi - lo:
         raise ValueError(f'rank {rank} holds {box1.shape[0]} pairs, expected '
                          f'{hi - lo} of {n_pairs}')
-    if n_pairs % world == 0 and dist.get_backend(group) != 'gloo':
-        # equal shards (the benchmarked case): one stack, one collective, views
-        mine = torch.stack((box1, box2))                         # [2, n_local, 4]
-        flat = torch.empty((world * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype,
-                           device=mine.device)                   # concatenation along dim 0
-        dist.all_gather_into_tensor(flat, mine, group=group)
-        everyone = flat.view((world, 2) + tuple(mine.shape[1:]))
-        return (everyone[:, 0].reshape(n_pairs, 4), everyone[:, 1].reshape(n_pairs, 4))
-    cap = -(-n_pairs // world)                       # ceil: padded shard size
-    mine = torch.zeros(cap, 2, 4, dtype=box1.dtype, device=box1.device)
-    mine[:hi - lo, 0] = box1
-    mine[:hi - lo, 1] = box2
-    everyone = torch.empty(world * cap, 2, 4, dtype=box1.dtype,
-                           device=box1.device)
-    if dist.get_backend(group) == 'gloo':
-        parts = list(everyone.view(world, cap, 2, 4).unbind(0))
-        dist.all_gather(parts, mine, group=group)
-        everyone = torch.stack(parts).view(world * cap, 2, 4)
+    cap = -(-n_pairs // world)                       # ceil: (padded) shard size
+    if n_pairs % world == 0:
+        mine = torch.stack((box1, box2), dim=1)      # [cap, 2, 4], no padding needed
     else:
-        dist.all_gather_into_tensor(everyone, mine, group=group)
+        mine = torch.zeros(cap, 2, 4, dtype=box1.dtype, device=box1.device)
+        mine[:hi - lo, 0] = box1
+        mine[:hi - lo, 1] = box2
+    everyone = torch.empty(world * cap, 2, 4, dtype=box1.dtype, device=box1.device)
+    dist.all_gather_into_tensor(everyone, mine.contiguous(), group=group)
+    if n_pairs % world == 0:
+        return everyone[:, 0].contiguous(), everyone[:, 1].contiguous()
     keep = torch.cat([
         torch.arange(r * cap, r * cap + (shard_bounds(n_pairs, r, world)[1]
                                          - shard_bounds(n_pairs, r, world)[0]))

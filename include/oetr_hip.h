@@ -14,8 +14,12 @@
  *    repacked copy of the weights (created by oetr_create);
  *  - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*): no
  *    allocation, no synchronisation, so a call sequence is hipGraph-capturable;
- *  - a handle is immutable after creation: concurrent calls with distinct
- *    workspaces are safe;
+ *  - forward calls never modify a handle (its only device-side state is the
+ *    sticky status word of oetr_query_flags, updated atomically): concurrent
+ *    calls with distinct workspaces on distinct streams are safe.  The explicit
+ *    setters (oetr_set_encoder_tile, oetr_set_trace) DO modify it and must not
+ *    race with forward calls on the same handle;
+ *  - no environment variable is read by the library;
  *  - every function returns an oetr_status; oetr_last_error() gives the text
  *    for the calling thread.  Nothing throws.
  *  - `N` is the number of image PAIRS; side 1 has token grid hf1 x wf1
@@ -48,12 +52,27 @@ typedef enum {
   OETR_ERR_NO_DEVICE = 6     /* no gfx950 device visible                   */
 } oetr_status;
 
-/* Arithmetic of the GEMM-shaped stages (everything else is fp32 in both):
+/* Arithmetic of the GEMM-shaped stages.  In every mode accumulation, LayerNorm,
+ * phi = elu+1, the attention normaliser, softmax, GroupNorm and the residual
+ * stream are fp32; the modes differ in how the GEMM OPERANDS are represented:
  *   OETR_DTYPE_F32           exact fp32 products on v_mfma_f32_32x32x2_f32
  *   OETR_DTYPE_F32_SPLIT_F16 fp32-class results from 3 f16 MFMAs per product
- *                            (a = ah + al/2^11 split of both operands, fp32
- *                            accumulation; needs |GEMM inputs| < 65504)      */
-typedef enum { OETR_DTYPE_F32 = 0, OETR_DTYPE_F32_SPLIT_F16 = 1 } oetr_dtype;
+ *                            (a = ah + al/2^11 split of both operands; needs
+ *                            |GEMM inputs| < 65504, see oetr_status_flags)
+ *   OETR_DTYPE_F16           operands rounded to f16 (RNE), one
+ *                            v_mfma_f32_32x32x16_f16 per product ("fp16 with fp32
+ *                            accumulate", BASELINE configs[4]); same range limit
+ *   OETR_DTYPE_BF16          operands rounded to bf16 (RNE), one
+ *                            v_mfma_f32_32x32x16_bf16 per product ("bf16 MFMA
+ *                            attention", BASELINE configs[2]); fp32 range
+ * The reference itself is fp32-only (no autocast anywhere); the two 16-bit modes
+ * trade parity margin (tests/test_gpu_parity.py records the drift) for MFMA rate. */
+typedef enum {
+  OETR_DTYPE_F32 = 0,
+  OETR_DTYPE_F32_SPLIT_F16 = 1,
+  OETR_DTYPE_F16 = 2,
+  OETR_DTYPE_BF16 = 3
+} oetr_dtype;
 
 /* Encoder layer i - reference src/models/transformer.py:83-102.
  * Linear weights are torch layout [out][in], row-major. */
@@ -124,8 +143,23 @@ oetr_status oetr_create(const oetr_weights *w, oetr_dtype dtype, int device,
                         oetr_handle *out);
 void oetr_destroy(oetr_handle h);
 
+/* Status word of a handle: bits set (atomically, sticky) by the kernels of any
+ * forward call since creation / the last clearing query.
+ *   OETR_FLAG_F16_RANGE  a GEMM operand (activation) reached |x| >= 65504 in an
+ *                        f16-based dtype (F32_SPLIT_F16, F16) and could not be
+ *                        represented: the outputs of that call are INVALID.  Re-run
+ *                        with a handle created as OETR_DTYPE_F32 or OETR_DTYPE_BF16.
+ * oetr_query_flags copies the word to *flags (host), optionally clears it, and
+ * SYNCHRONISES `stream` (the one call of this library that does): ordered after
+ * every forward call previously enqueued on that stream.  Weights are range-checked
+ * by oetr_create (OETR_ERR_UNSUPPORTED).  Nothing like this exists in the fp32
+ * reference; it guards the reduced-range operand formats. */
+#define OETR_FLAG_F16_RANGE 1u
+oetr_status oetr_query_flags(oetr_handle h, void *stream, uint32_t *flags,
+                             int clear);
+
 /* Token rows per encoder workgroup: 0 = auto (default), 32 or 64.  64 exists in
- * the OETR_DTYPE_F32_SPLIT_F16 mode only (ignored otherwise): fewer
+ * the 16-bit-operand dtypes only (ignored for OETR_DTYPE_F32): fewer
  * CU-microseconds per token, half as many workgroups - the better shape once the
  * grid exceeds the chip (auto), or when several batches are in flight on
  * different streams.  Results do not depend on it beyond fp32 summation order
@@ -245,6 +279,10 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float *backbone_feat,
                               int n_images, int hb, int wb, void *workspace,
                               size_t workspace_bytes, float *feat_out,
                               void *stream);
+/* Status word of the neck handle (see oetr_query_flags): OETR_FLAG_F16_RANGE when a
+ * backbone feature / intermediate reached the f16 range of its split GEMMs. */
+oetr_status oetr_neck_query_flags(oetr_neck_handle h, void *stream,
+                                  uint32_t *flags, int clear);
 
 /* ---- measurement hook (bench.py / profiling only) -------------------------
  * A trace owns a pool of HIP events.  While attached to a handle, every
