@@ -290,6 +290,7 @@ DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w) {
   d.att0_part = w.att0; d.z0_part = w.z0; d.dkv1 = w.dkv1; d.dks1 = w.dks1;
   d.hs = w.hs;
   d.tbuf = nullptr;
+  d.dbg = 0;
 #ifdef OETR_PHASE_TIMING
   d.tbuf = g_tbuf ? g_tbuf + 16 * 4096 : nullptr;
 #endif

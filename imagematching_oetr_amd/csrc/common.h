@@ -28,7 +28,12 @@ constexpr int MAX_TOKENS = 10000;  // NECK.MAX_SHAPE 100x100 (reference default.
 #endif
 // Phase timing (tools/phase_timing.py): wave 0 of every workgroup stamps
 // s_memtime at phase boundaries.  Compiled out of the shipped build.
-#ifdef OETR_PHASE_TIMING
+// Cumulative timing (tools/ablate_run.py): with OETR_ABLATE = (n+1) << 16 every workgroup
+// returns when it reaches phase boundary n, so kernel time vs n is the cost of the
+// phases up to n under real conditions (launch, loads and barriers included).
+#if defined(OETR_ABLATE)
+#define PHASE_STAMP(p, idx) do { if (((p).dbg >> 16) == (idx) + 1) return; } while (0)
+#elif defined(OETR_PHASE_TIMING)
 #define PHASE_STAMP(p, idx)                                                              \
   do {                                                                                   \
     if (threadIdx.x == 0 && (p).tbuf) (p).tbuf[blockIdx.x * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
@@ -36,7 +41,11 @@ constexpr int MAX_TOKENS = 10000;  // NECK.MAX_SHAPE 100x100 (reference default.
 #else
 #define PHASE_STAMP(p, idx) do {} while (0)
 #endif
-enum { ABL_KVREDUCE = 1, ABL_GELU = 2, ABL_ELU = 4, ABL_LN = 8, ABL_GEMM = 16, ABL_STORE = 32 };
+#if defined(OETR_ABLATE) && defined(OETR_PHASE_TIMING)
+#error "OETR_ABLATE and OETR_PHASE_TIMING are separate builds"
+#endif
+enum { ABL_KVREDUCE = 1, ABL_GELU = 2, ABL_ELU = 4, ABL_LN = 8, ABL_GEMM = 16, ABL_STORE = 32,
+       ABL_XLOAD = 64, ABL_WLOAD = 128, ABL_ATTN = 256, ABL_KVSTATE = 512 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -168,24 +177,46 @@ __device__ __forceinline__ float erf_f32(float x) {
   const float large_v = copysignf(1.0f - __builtin_amdgcn_exp2f(t * r), x);
   return ax <= 0.92f ? small_v : large_v;
 }
-// Exact-erf GELU (torch nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)).
+// Exact-erf GELU (torch nn.GELU default): 0.5 v (1 + erf(v / sqrt 2)).
+//
+// GELU needs erf only to ABSOLUTE accuracy (it is added to 1), so one formula serves
+// every v:  gelu(v) = max(v, 0) - 0.5 |v| erfc(|v| / sqrt 2),  erfc = 2^(w Q(w)),
+// w = min(|v|, 5.5), Q = degree-9 fit of log2(erfc(w / sqrt 2)) / w on [0, 5.5]
+// (tools/fit_erf.py: max abs error 2.4e-7 over |v| <= 12, 1.2e-7 for |v| < 2, every
+// operation rounded to fp32 - tighter than the two-branch erf_f32 form it replaces,
+// 6.8e-7, at half the instructions: no small-|x| branch, no select, no copysign).
+#ifndef OETR_GELU_TWO_BRANCH
+#define OETR_GELU_TWO_BRANCH 0
+#endif
+constexpr float GELU_T = 5.5f;
+constexpr float GELU_Q[10] = {-1.151104268e+00f, -4.592180034e-01f, -5.245695910e-02f,
+                              6.978375917e-03f,  -3.027199248e-05f, -2.638561890e-04f,
+                              7.173310719e-05f,  -1.016200793e-05f, 7.862152819e-07f,
+                              -2.615616390e-08f};
 __device__ __forceinline__ float gelu_erf(float x) {
 #ifdef OETR_OCML_ERF
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-#else
+#elif OETR_GELU_TWO_BRANCH
   return 0.5f * x * (1.0f + erf_f32(x * 0.70710678118654752440f));
+#else
+  const float ax = fabsf(x), w = fminf(ax, GELU_T);
+  float q = GELU_Q[9];
+#pragma unroll
+  for (int i = 8; i >= 0; --i) q = fmaf(q, w, GELU_Q[i]);
+  const float e = __builtin_amdgcn_exp2f(w * q);
+  return fmaf(-0.5f * ax, e, fmaxf(x, 0.f));
 #endif
 }
 
-// Two GELUs per instruction stream: the polynomial chains run as v_pk_fma_f32
+// Two GELUs per instruction stream: the polynomial chain runs as v_pk_fma_f32
 // (packed fp32, 2 lanes of work per VALU slot); same operations in the same order
 // as gelu_erf (results agree to the last rounding of the packed/scalar code paths).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
-#ifdef OETR_OCML_ERF
+#if defined(OETR_OCML_ERF)
   return f32x2{gelu_erf(v[0]), gelu_erf(v[1])};
-#else
+#elif OETR_GELU_TWO_BRANCH
   const f32x2 x = v * splat2(0.70710678118654752440f);
   const f32x2 ax = __builtin_elementwise_abs(x);
   const f32x2 t = __builtin_elementwise_min(ax, splat2(4.0f));
@@ -215,6 +246,18 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
     e[i] = ax[i] <= 0.92f ? small_v[i] : large_v;
   }
   return (splat2(0.5f) * v) * (splat2(1.0f) + e);
+#else
+  const f32x2 ax = __builtin_elementwise_abs(v);
+  const f32x2 w = f32x2{fminf(ax[0], GELU_T), fminf(ax[1], GELU_T)};
+  f32x2 q = splat2(GELU_Q[9]);
+#pragma unroll
+  for (int i = 8; i >= 0; --i) q = __builtin_elementwise_fma(q, w, splat2(GELU_Q[i]));
+  const f32x2 u = w * q;
+  f32x2 g;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    g[i] = fmaf(-0.5f * ax[i], __builtin_amdgcn_exp2f(u[i]), fmaxf(v[i], 0.f));
+  return g;
 #endif
 }
 
@@ -308,8 +351,9 @@ __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
                                                             (b - (float)hi[1]) * SPLIT_SCALE));
 }
 // Range guard of the f16-based modes (GM_SPLIT, GM_F16): every activation that is
-// converted into a GEMM operand updates a per-thread max |x| (one v_max3_f32 per two
-// values - noise next to the conversion itself); a kernel ends with range_report(),
+// converted into a GEMM operand is compared with the f16 maximum (two VALU + one SALU
+// instruction per two values - noise next to the conversion itself); a kernel ends with
+// range_report(),
 // which sets FLAG_F16_RANGE in the handle's device flag word (one atomicOr, only when
 // violated) if any operand was >= 65504 (or inf) and so could not be represented.
 // The host reads the word with oetr_query_flags().  Weights are checked at create.
@@ -317,15 +361,18 @@ constexpr uint32_t FLAG_F16_RANGE = 1u;   // == OETR_FLAG_F16_RANGE
 constexpr float F16_MAX = 65504.0f;
 constexpr bool gm_f16_range(int m) { return m == GM_SPLIT || m == GM_F16; }
 struct Range {
-  float amax = 0.f;
+  // Wave-uniform violation mask, kept in an SGPR pair (v_cmp + s_or_b64 per check): the
+  // encoder kernels sit at the 256-VGPR limit and a per-lane running maximum carried
+  // across the whole kernel tips them into scratch spills.
+  unsigned long long bad = 0;
   __device__ __forceinline__ void see(float a, float b) {
-    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+    bad |= __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a), fabsf(b)) >= F16_MAX);
   }
 };
 template <int M>
 __device__ __forceinline__ void range_report(const Range& rg, uint32_t* flags) {
   if constexpr (gm_f16_range(M)) {
-    if (rg.amax >= F16_MAX) atomicOr(flags, FLAG_F16_RANGE);
+    if (rg.bad != 0 && (threadIdx.x & 63) == 0) atomicOr(flags, FLAG_F16_RANGE);
   }
 }
 // Two floats -> the mode's operand representation: `hi` = the (only, or high) plane's two
@@ -357,6 +404,30 @@ __device__ __forceinline__ f32x16 mma16(const f32x4& a, const f32x4& b, const f3
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
                                                   __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// 8 floats -> one 16-byte MFMA fragment per plane of the fp32-class split
+// (a = hi + lo/2^11): the operands of the small attention blocks are formed in
+// registers, straight from accumulators / f32 LDS tiles.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8(const f32x4& a0, const f32x4& a1, f32x4& hi, f32x4& lo,
+                                       Range& rg) {
+  uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+  cvt_planes2<GM_SPLIT>(a0[0], a0[1], h0, l0, rg);
+  cvt_planes2<GM_SPLIT>(a0[2], a0[3], h1, l1, rg);
+  cvt_planes2<GM_SPLIT>(a1[0], a1[1], h2, l2, rg);
+  cvt_planes2<GM_SPLIT>(a1[2], a1[3], h3, l3, rg);
+  hi = __builtin_bit_cast(f32x4, u32x4{h0, h1, h2, h3});
+  lo = __builtin_bit_cast(f32x4, u32x4{l0, l1, l2, l3});
+}
+// main += ah.bh ; cross += ah.bl + al.bh   (one k16 step of a split product; ONE cross
+// accumulator: these blocks are 2-4 steps long and short of registers, the dependent
+// cross MFMAs cost a few stalled cycles)
+__device__ __forceinline__ void mma16_split3(const f32x4& ah, const f32x4& al, const f32x4& bh,
+                                             const f32x4& bl, f32x16& main, f32x16& cross) {
+  cross = mma16<GM_SPLIT>(ah, bl, cross);
+  main = mma16<GM_SPLIT>(ah, bh, main);
+  cross = mma16<GM_SPLIT>(al, bh, cross);
+}
+
 // Store 4 consecutive floats of a row as 4 16-bit values per plane (8-byte stores).
 // Planes are typed _Float16* for storage only (bf16 bit patterns in GM_BF16).
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -616,8 +687,18 @@ __device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4]
 #ifndef OETR_WSTREAM
 #define OETR_WSTREAM 1
 #endif
+// Ring geometry (tools/variants A/B on MI355X, k_encoder<B,A> at 8 pairs @640x640, split
+// mode): chunks of 2 k16-steps, ring of 3: 46.1 us; ring of 4: 50.7 (registers); chunks
+// of ONE step, ring of 6 (5 steps = 10 KB per wave in flight): 42.3; ring of 8: 48.4.
+// The single-plane modes stream at ~47 B/clk/CU whatever the depth (L1-rate bound).
 #ifndef OETR_RING
-#define OETR_RING 3
+#define OETR_RING 6     // ring depth (chunks) of the two-plane (split) weight stream
+#endif
+#ifndef OETR_RING1
+#define OETR_RING1 6    // ring depth of the single-plane (f16 / bf16) weight stream
+#endif
+#ifndef OETR_WS_U
+#define OETR_WS_U 1     // k16 steps per chunk
 #endif
 template <int M, int NT, bool STREAMED = (gm_half(M) && NT == 1)>
 struct WStream {
@@ -636,15 +717,17 @@ struct WStream {
 template <int M>
 struct WStream<M, 1, true> {
   static constexpr bool TWO = gm_planes(M) == 2;
-  static constexpr int U = 2, D = OETR_RING, PRE = D - 1;
+  static constexpr int U = OETR_WS_U, D = TWO ? OETR_RING : OETR_RING1, PRE = D - 1;
   struct BChunk { f32x4 bh[U], bl[TWO ? U : 1]; };
   struct AChunk { f32x4 ah[U], al[TWO ? U : 1]; };
   BChunk ring[D];
+  int dbg = 0;  // ablation flags (OETR_ABLATE builds only)
 
   static constexpr int adv(int P, int K) { return (P + K / 16 / U) % D; }
 
   template <int SLOT>
   __device__ __forceinline__ void fetch(const f32x4* wh, const f32x4* wl, int chunk) {
+    if (ABL(dbg, ABL_WLOAD)) return;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ring[SLOT].bh[u] = wh[(chunk * U + u) * 64];
@@ -707,6 +790,7 @@ struct WStream<M, 1, true> {
   __device__ __forceinline__ void gemm(const AT& A, const f32x4* W, const f32x4* Wl, int nt0,
                                        int lane, f32x16 (&acc)[1], const f32x4* nW,
                                        const f32x4* nWl, int nnt0, int) {
+    if (ABL(dbg, ABL_GEMM)) return;
     static_assert(PRE * U * 16 <= K && (NK == 0 || PRE * U * 16 <= NK), "ring deeper than a GEMM");
     const size_t off = (size_t)nt0 * (K / 16) * 64 + lane;
     const size_t noff = (size_t)nnt0 * ((NK ? NK : 16) / 16) * 64 + lane;
@@ -751,12 +835,15 @@ struct PlanesT {  // 16-bit planes [RT][LDAH] (hi, and lo*2^11 in GM_SPLIT) in o
 typedef PlanesT<GM_SPLIT> Planes2;
 
 #ifndef OETR_RING2
-#define OETR_RING2 4   // k16 steps of B fragments in the ring (one being consumed)
+#define OETR_RING2 4   // k16 steps of B fragments in the ring (one being consumed), split mode
+#endif
+#ifndef OETR_RING2_1P
+#define OETR_RING2_1P 4   // the same for the single-plane modes
 #endif
 template <int M>
 struct WStream2T {
   static constexpr bool TWO = gm_planes(M) == 2;
-  static constexpr int D = OETR_RING2, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
+  static constexpr int D = TWO ? OETR_RING2 : OETR_RING2_1P, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
   struct BStep { f32x4 bh, bl; };
   struct AStep { f32x4 ah[2], al[2]; };
   BStep ring[D];
@@ -920,6 +1007,7 @@ struct DecLaunch {
   const float* dks1;       // [ntiles][256]
   float* hs;               // [2N][256]
   long long* tbuf;         // OETR_PHASE_TIMING builds only
+  int dbg;                 // OETR_ABLATE builds only
 };
 struct DecConstLaunch {
   DecLayerDev layer[2];

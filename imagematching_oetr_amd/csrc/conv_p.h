@@ -63,7 +63,7 @@ __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restri
 template <int MODE>
 __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __restrict__ P, int tile,
                                               float* smem) {
-  static_assert(WStream2T<MODE>::D == 4, "tap loop below assumes a ring phase of 0 after every GEMM");
+  static_assert(16 % WStream2T<MODE>::D == 0, "tap loop below assumes a ring phase of 0 after every GEMM");
   constexpr int THREADS = 512, TPR = THREADS / RT, F4 = 64 / TPR;
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;

@@ -28,6 +28,16 @@
 
 #include "common.h"
 
+// fp32-class split f16 MFMAs (instead of f32 MFMAs at 1/16 of the rate) for the two small
+// attention blocks of the f16-based modes: the per-tile KV state phi(K)^T V and the
+// attention apply phi(Q).KV (A/B: tools/variants)
+#ifndef OETR_SPLIT_STATE
+#define OETR_SPLIT_STATE 1
+#endif
+#ifndef OETR_SPLIT_APPLY
+#define OETR_SPLIT_APPLY 1
+#endif
+
 namespace oetr {
 
 // ---------------------------------------------------------------------------
@@ -118,42 +128,73 @@ struct EncCfg {
 // == elu(x)+1 bit for bit) on scalars, four at a time between sched_barriers: as a select
 // hipcc branches per element (with whole-tuple copies when done in place), unfenced it
 // schedules all exps at once and spills.
+template <int MODE>
 __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& accV, bool skip_phi,
                                             int S_len, int nvalid, int half, f32x16& kv,
-                                            float& ksum) {
+                                            float& ksum, Range& rg) {
   const float inv_len = 1.0f / (float)S_len;
   kv = f32x16{0};
   ksum = 0.f;
+  if constexpr (gm_f16_range(MODE) && OETR_SPLIT_STATE) {
+    // f16-based modes: the 32-token contraction as 2 k16 steps of the fp32-class split
+    // (6 f16 MFMAs = 192 matrix-pipe cycles instead of 16 f32 MFMAs = 1024).  Lane (d, half)
+    // supplies, for k-slot 8*half + i of step s, the token in its accumulator register
+    // 8s + i - the same token in the phi(K) (A) and V (B) operand, which is all the
+    // contraction needs.
+    f32x16 c1 = {0};
 #pragma unroll
-  for (int r0 = 0; r0 < 16; r0 += 4) {
-    float k[4], v[4];
+    for (int s = 0; s < 2; ++s) {
+      f32x4 k0, k1, v0, v1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float m = crow(r0 + j, half) < nvalid ? 1.0f : 0.0f;
-      const float x = accK[r0 + j];
-      k[j] = (skip_phi ? x : fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
-      v[j] = accV[r0 + j] * (inv_len * m);
-      ksum += k[j];
+      for (int i = 0; i < 8; ++i) {
+        const int r = 8 * s + i;
+        const float m = crow(r, half) < nvalid ? 1.0f : 0.0f;
+        const float x = accK[r];
+        const float kk = (skip_phi ? x : fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+        const float vv = accV[r] * (inv_len * m);
+        ksum += kk;
+        if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
+      }
+      f32x4 ah, al, bh, bl;
+      split8(k0, k1, ah, al, rg);
+      split8(v0, v1, bh, bl, rg);
+      mma16_split3(ah, al, bh, bl, kv, c1);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
+  } else {
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+      float k[4], v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m = crow(r0 + j, half) < nvalid ? 1.0f : 0.0f;
+        const float x = accK[r0 + j];
+        k[j] = (skip_phi ? x : fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+        v[j] = accV[r0 + j] * (inv_len * m);
+        ksum += k[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
 // phi(K)^T (V/S) for this wave's heads straight from the K and V accumulators,
 // plus sum_s phi(K); stores the per-tile partial states.
-template <int NT>
+template <int MODE, int NT>
 __device__ __forceinline__ void kv_state_store(f32x16 (&accK)[NT], f32x16 (&accV)[NT],
                                                bool skip_phi, int S_len, int nvalid, int lane,
                                                int wave, float* __restrict__ kv_out,
-                                               float* __restrict__ ks_out, int slot) {
+                                               float* __restrict__ ks_out, int slot, Range& rg) {
   const int half = lane >> 5;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float ksum;
     f32x16 kv;
-    kv_state_32(accK[t], accV[t], skip_phi, S_len, nvalid, half, kv, ksum);
+    kv_state_32<MODE>(accK[t], accV[t], skip_phi, S_len, nvalid, half, kv, ksum, rg);
     const int h = NT * wave + t;
     f32x4* dst = reinterpret_cast<f32x4*>(kv_out) + ((size_t)slot * NH + h) * 4 * 64 + lane;
 #pragma unroll
@@ -197,6 +238,9 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   float* lnp_s = smem + LNP_OFF;
   using WS = WStream<MODE, NT>;
   WS ws;  // this wave's weight stream (runs ahead across the GEMMs below)
+#ifdef OETR_ABLATE
+  if constexpr (SPLIT && NT == 1) ws.dbg = p.dbg;
+#endif
   // ring slot of each GEMM's first chunk
   constexpr int P_MERGE = 0;
   constexpr int P_W1A = WS::adv(P_MERGE, C);
@@ -246,14 +290,14 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     const int nts = ABL(p.dbg, ABL_KVREDUCE) ? 1 : g.nt[ss];
     const int src_slot0 = g.tile0[ss] + n * g.nt[ss];
 
-    load_tile<THREADS>(S0, p.qp + row_base * C, nvalid, tid);  // phi(Q) tile
+    if (!ABL(p.dbg, ABL_XLOAD)) load_tile<THREADS>(S0, p.qp + row_base * C, nvalid, tid);  // phi(Q) tile
     // residual x in accumulator layout
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(crow(r, half), nvalid - 1);
-        xacc[t][r] = p.x[(row_base + row) * C + wcol + 32 * t + col];
+        xacc[t][r] = ABL(p.dbg, ABL_XLOAD) ? 0.5f : p.x[(row_base + row) * C + wcol + 32 * t + col];
       }
     // reduce the source image's partial KV states (fixed order -> deterministic);
     // the result is already in B-operand register order.  Several tiles are in
@@ -294,7 +338,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     PHASE_STAMP(p, 1);
 
     // Z[row][h] = 1 / (phi(Q)[row,h,:] . Ksum[h,:] + eps)
-    if (THREADS == TM * NH || tid < TM * NH) {
+    if (!ABL(p.dbg, ABL_ATTN) && (THREADS == TM * NH || tid < TM * NH)) {
       const int r = tid >> 3, h = tid & 7;
       const f32x4* qrow = reinterpret_cast<const f32x4*>(S0 + r * LDA + h * HD);
       const f32x4* kk = reinterpret_cast<const f32x4*>(ksum_s + h * HD);
@@ -309,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     __syncthreads();
 
     // message = (phi(Q) . KV) * Z * S  for this wave's heads -> S1
-    {
+    if (!ABL(p.dbg, ABL_ATTN)) {
       float zr[NT][16];  // read before any S1 store: LDS stores would otherwise
 #pragma unroll           // serialise these reads one by one (may-alias)
       for (int t = 0; t < NT; ++t)
@@ -318,16 +362,37 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       f32x16 macc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) macc[t] = f32x16{0};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
+        // phi(Q).KV as 2 k16 steps of the fp32-class split per head (same reads of the
+        // phi(Q) tile; k-slot 8*half + i of step s <-> d = 16s + 8*(i>>2) + 4*half + (i&3)
+        // in BOTH operands)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(S0 + col * LDA + (NT * wave + t) * HD +
-                                                          4 * half + ks * 8);
+          f32x16 c1 = {0};
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[t][ks][j], macc[t], 0, 0, 0);
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const float* qrow = S0 + col * LDA + (NT * wave + t) * HD + 4 * half + 16 * s2;
+            f32x4 ah, al, bh, bl;
+            split8(*reinterpret_cast<const f32x4*>(qrow), *reinterpret_cast<const f32x4*>(qrow + 8),
+                   ah, al, rg);
+            split8(kvB[t][2 * s2], kvB[t][2 * s2 + 1], bh, bl, rg);
+            mma16_split3(ah, al, bh, bl, macc[t], c1);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) macc[t][r] = fmaf(c1[r], SPLIT_INV, macc[t][r]);
         }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(S0 + col * LDA + (NT * wave + t) * HD +
+                                                            4 * half + ks * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[t][ks][j], macc[t], 0, 0, 0);
+          }
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -401,7 +466,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = crow(r, half);
-        if (row < nvalid) p.x[(row_base + row) * C + wcol + 32 * t + col] = xacc[t][r];
+        if (row < nvalid && !ABL(p.dbg, ABL_STORE)) p.x[(row_base + row) * C + wcol + 32 * t + col] = xacc[t][r];
       }
     if (TAIL != 2) acc_to_lds<NT>(S0, LDA, wcol, lane, xacc);
     __syncthreads();  // also: every wave is done reading Hh before S2 (alias) is written
@@ -446,7 +511,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
-          if (row < nvalid)
+          if (row < nvalid && !ABL(p.dbg, ABL_STORE))
             p.qp[(row_base + row) * C + wcol + 32 * t + col] = ABL(p.dbg, ABL_ELU) ? acc[t][r] : elu1(acc[t][r]);
         }
     }
@@ -459,7 +524,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     ws.template gemm<C, P_T2, 0>(S2, p.a.wv, p.a.wv_l, NT * wave, lane, accV, nullptr, nullptr, 0,
                                  p.dbg);
     PHASE_STAMP(p, 9);
-    kv_state_store<NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.kv_out, p.ks_out, slot);
+    if (!ABL(p.dbg, ABL_KVSTATE))
+    kv_state_store<MODE, NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.kv_out, p.ks_out, slot, rg);
     PHASE_STAMP(p, 10);
   } else if (TAIL == 1) {
     // ============ decoder preparation (transformer.py:240-246) ============
@@ -498,8 +564,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       ws.template gemm<C, PV, (dl == 0 ? C : 0)>(Vin, p.d.wv[dl], p.d.wv_l[dl], NT * wave, lane,
                                                  accV, p.d.wk[1], p.d.wk_l[1], NT * wave, p.dbg);
       if constexpr (dl == 1) {
-        kv_state_store<NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.dkv1_out,
-                           p.dks1_out, slot);
+        kv_state_store<MODE, NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.dkv1_out,
+                                 p.dks1_out, slot, rg);
       } else {
         // Decoder layer 0's query is a create-time constant q0 (decoder.hip), and
         // its cross-attention is linear in the state, so this tile contributes
@@ -510,7 +576,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
           const int h = NT * wave + t;
           float ksum;
           f32x16 kv;
-          kv_state_32(accK[t], accV[t], false, L, nvalid, half, kv, ksum);
+          kv_state_32<MODE>(accK[t], accV[t], false, L, nvalid, half, kv, ksum, rg);
           const float* q0 = p.dec_q0 + side * C + h * HD;
           float a = 0.f;
 #pragma unroll
@@ -560,11 +626,12 @@ constexpr int E2_LNP = E2_Z + RT * NH;
 constexpr int E2_SMEM = E2_LNP + 6 * C;                  // 36096 floats = 141 KB
 
 // phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
+template <int MODE>
 __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x16 (&accV)[2],
                                             int S_len, int nvalid, int half, bool two, f32x16& kv,
-                                            float& ksum) {
+                                            float& ksum, Range& rg) {
   // Branch-free phi (max(x,0) + exp(min(x,0)) == elu(x)+1 bit for bit: exp_neg(0) == 1) on
-  // scalars, four at a time: as a select hipcc branches per element (and, on the
+  // scalars, a few at a time: as a select hipcc branches per element (and, on the
   // accumulator tuples, copies whole 16-register tuples around the branch); unfenced,
   // it schedules all 32 exps at once and spills.
   const float inv_len = 1.0f / (float)S_len;
@@ -574,23 +641,53 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
   //  clamps at the top of the kernel and 32 values live - spilled - until here)
   int nv2 = nvalid - 4 * half;
   asm volatile("" : "+v"(nv2));
+  if constexpr (gm_f16_range(MODE) && OETR_SPLIT_STATE) {
+    // 64-token contraction as 4 k16 steps of the fp32-class split (see kv_state_32)
+    f32x16 c1 = {0};
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    if (mt == 1 && !two) break;  // no valid row in the second row tile
+    for (int mt = 0; mt < 2; ++mt) {
+      if (mt == 1 && !two) break;  // no valid row in the second row tile
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 4) {
-      float k[4], v[4];
+      for (int s = 0; s < 2; ++s) {
+        f32x4 k0, k1, v0, v1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float m = 32 * mt + crow(r0 + j, 0) < nv2 ? 1.0f : 0.0f;
-        const float x = accK[mt][r0 + j];
-        k[j] = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
-        v[j] = accV[mt][r0 + j] * (inv_len * m);
-        ksum += k[j];
+        for (int i = 0; i < 8; ++i) {
+          const int r = 8 * s + i;
+          const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
+          const float x = accK[mt][r];
+          const float kk = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+          const float vv = accV[mt][r] * (inv_len * m);
+          ksum += kk;
+          if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
+        }
+        f32x4 ah, al, bh, bl;
+        split8(k0, k1, ah, al, rg);
+        split8(v0, v1, bh, bl, rg);
+        mma16_split3(ah, al, bh, bl, kv, c1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (mt == 1 && !two) break;  // no valid row in the second row tile
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 4) {
+        float k[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float m = 32 * mt + crow(r0 + j, 0) < nv2 ? 1.0f : 0.0f;
+          const float x = accK[mt][r0 + j];
+          k[j] = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+          v[j] = accV[mt][r0 + j] * (inv_len * m);
+          ksum += k[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   ksum += __shfl_xor(ksum, 32, 64);
@@ -728,6 +825,11 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     __syncthreads();
 
     // message = (phi(Q) . KV) * Z * S for head = wave -> R1 planes
+    f32x4 kvBh[2], kvBl[2];  // f16-based modes: the reduced state as split B fragments
+    if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) split8(kvB[2 * s2], kvB[2 * s2 + 1], kvBh[s2], kvBl[s2], rg);
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       if (mt == 1 && !ws.two) break;  // ragged tile: rows 32.. are never stored
@@ -735,13 +837,27 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) zr[r] = z_s[(32 * mt + crow(r, half)) * NH + wave];
       f32x16 macc = {0};
+      if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
+        f32x16 c1 = {0};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(R2f + (32 * mt + col) * LDA + wave * HD +
-                                                        4 * half + ks * 8);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const float* qrow = R2f + (32 * mt + col) * LDA + wave * HD + 4 * half + 16 * s2;
+          f32x4 ah, al;
+          split8(*reinterpret_cast<const f32x4*>(qrow), *reinterpret_cast<const f32x4*>(qrow + 8),
+                 ah, al, rg);
+          mma16_split3(ah, al, kvBh[s2], kvBl[s2], macc, c1);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[ks][j], macc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) macc[r] = fmaf(c1[r], SPLIT_INV, macc[r]);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(R2f + (32 * mt + col) * LDA + wave * HD +
+                                                          4 * half + ks * 8);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[ks][j], macc, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) macc[r] = macc[r] * zr[r] * (float)S_len;
@@ -905,7 +1021,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     PHASE_STAMP(p, 11);
     f32x16 kv;
     float ksum;
-    kv_state_64(accK, accV, L, nvalid, half, ws.two, kv, ksum);
+    kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two, kv, ksum, rg);
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
   } else if (TAIL == 1) {
@@ -945,7 +1061,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
                                         nullptr, 0, 0);
       f32x16 kv;
       float ksum;
-      kv_state_64(accK, accV, L, nvalid, half, ws.two, kv, ksum);
+      kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two, kv, ksum, rg);
       if constexpr (dl == 1) {
         kv_state_write(kv, ksum, lane, wave, p.dkv1_out, p.dks1_out, slot);
       } else {

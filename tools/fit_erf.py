@@ -78,3 +78,30 @@ g_got = (f32(0.5) * xs * (f32(1.0) + erf32((xs * f32(0.70710678118654752440)).as
 print('gelu max abs err %.3e' % np.abs(g_got - g_ref).max())
 print('P =', ', '.join('%.9ef' % c for c in P))
 print('R =', ', '.join('%.9ef' % c for c in R))
+
+
+# ---------------------------------------------------------------------------
+# Single-formula GELU (csrc/common.h: gelu_erf, round 2).  GELU adds erf to 1, so only
+# ABSOLUTE erf accuracy matters and the small-|x| branch above is unnecessary:
+#   gelu(v) = max(v, 0) - 0.5 |v| erfc(|v| / sqrt 2),   erfc(w / sqrt 2) = 2^(w Q(w)),
+#   w = min(|v|, T),  Q = degree-9 fit of log2(erfc(w / sqrt 2)) / w on [0, T], T = 5.5
+T = 5.5
+S2 = np.sqrt(2.0)
+
+
+def qfun(w):
+    with np.errstate(divide='ignore', invalid='ignore'):
+        r = np.log2(special.erfc(w / S2)) / w
+    return np.where(w < 1e-9, -2 / np.sqrt(np.pi) / np.log(2) / S2, r)
+
+
+Q = fit(qfun, 0.0, T, 9, n=6000)
+v = np.concatenate([np.linspace(-12, 12, 4000001), np.linspace(-1e-2, 1e-2, 200001)]).astype(f32)
+w = np.minimum(np.abs(v), f32(T)).astype(f32)
+e = np.exp2((w * horner32(Q, w)).astype(f32)).astype(f32)
+g = (np.maximum(v, f32(0)) - (f32(0.5) * np.abs(v) * e).astype(f32)).astype(f32)
+g_ref = 0.5 * v.astype(np.float64) * (1 + special.erf(v.astype(np.float64) / S2))
+err = np.abs(g.astype(np.float64) - g_ref)
+print('single-formula gelu: max abs err %.3e at v=%.3f; |v|<2: %.3e' % (err.max(), v[err.argmax()],
+                                                                      err[np.abs(v) < 2].max()))
+print('Q =', ', '.join('%.9ef' % c for c in Q))

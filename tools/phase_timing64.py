@@ -14,8 +14,10 @@ f1 = (torch.rand(n, 256, 20, 20) - 0.5).to(dev); f2 = (torch.rand(n, 256, 20, 20
 pos = model.pos_encoding(f1.cpu()).contiguous().to(dev)
 NAMES = ['loads+kvreduce', 'Z+attn-apply', 'merge GEMM', 'stage+LN2', 'MLP1a+GELU', 'MLP2a', 'MLP1b+GELU', 'MLP2b+store+stage',
          'LN-A', 'Q GEMM+phi+store', 'K,V GEMMs', 'KV state']
-eng = pkg.HotPathEngine(model.hot_path_state(), device=dev)
+prec = sys.argv[1] if len(sys.argv) > 1 else 'f32_split_f16'
+eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision=prec, enc_tile=64)
 lib = eng.lib
+print('precision', prec)
 for _ in range(3):
     eng.forward(f1, f2, pos, pos, (640, 640), (640, 640), stages=True, enc_layers=3)
 # stop after the encoder with 3 layers: last launch is <B> only; the one before is <B,A>

@@ -22,7 +22,8 @@ names = sys.argv[1:] or sorted(Path(p).parent.name for p in glob.glob(str(REPO /
 engines = {}
 for name in names:
     hip_engine._lib = hip_engine.load_library(str(REPO / 'tools' / 'variants' / name / 'liboetr_hip.so'))
-    engines[name] = pkg.HotPathEngine(w, device=dev)
+    engines[name] = pkg.HotPathEngine(w, device=dev, precision=os.environ.get('PREC', 'f32_split_f16'),
+                                      enc_tile=int(os.environ.get('TILE', 0)) or None)
 hw = (hf * 32, hf * 32)
 ref = None
 acc = {k: {} for k in names}
