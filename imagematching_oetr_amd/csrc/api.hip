@@ -113,6 +113,10 @@ struct Packer {
 
 }  // namespace
 
+namespace oetr {
+int set_last_error(int status, const char* msg) { return fail((oetr_status)status, msg); }
+}  // namespace oetr
+
 enum KernelId { K_PREP, K_ENC_A, K_ENC_BA, K_ENC_BDEC, K_ENC_B, K_DECODER, K_HEAT_CONV,
                 K_HEAT_FINAL, K_SIZE_REG, K_BOXES, K_DEC_CONVP, K_HEAT_COMBINE, K_NECK_PROJ,
                 K_NECK_CONV, K_NECK_OUT, K_COUNT };

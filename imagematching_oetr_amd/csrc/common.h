@@ -939,6 +939,8 @@ typedef WStream2T<GM_SPLIT> WStream2;
 #endif  // __HIPCC__
 
 // ------------------------------------------------------------------ host
+// sets the calling thread's oetr_last_error() text; returns `status` (api.hip)
+int set_last_error(int status, const char* msg);
 // Repacked weights of one encoder layer (device pointers).
 struct EncLayerDev {
   const f32x4 *wq, *wk, *wv, *wmerge, *w1, *w2;  // fragment-packed (f32 mode: values;

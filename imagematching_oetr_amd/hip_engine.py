@@ -59,6 +59,14 @@ class _NeckWeights(C.Structure):
         ('input_proj2_w', _f32p), ('input_proj2_b', _f32p)]
 
 
+class _CropInfo(C.Structure):
+    _fields_ = [('valid', C.c_int32), ('box', (C.c_int32 * 4) * 2),
+                ('crop_w', C.c_int32 * 2), ('crop_h', C.c_int32 * 2),
+                ('new_w', C.c_int32 * 2), ('new_h', C.c_int32 * 2),
+                ('out_w', C.c_int32 * 2), ('out_h', C.c_int32 * 2),
+                ('ratio', (C.c_double * 2) * 2), ('sbox', (C.c_float * 4) * 2)]
+
+
 ABI_VERSION = 1
 EXPORTS = (
     'oetr_last_error', 'oetr_abi_version', 'oetr_create', 'oetr_destroy',
@@ -69,7 +77,7 @@ EXPORTS = (
     'oetr_set_trace', 'oetr_trace_summary', 'oetr_neck_create',
     'oetr_neck_destroy', 'oetr_neck_workspace_bytes', 'oetr_neck_forward',
     'oetr_neck_set_trace', 'oetr_set_encoder_tile', 'oetr_query_flags',
-    'oetr_neck_query_flags')
+    'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -185,6 +193,11 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.restype = i
         fn.argtypes = [vp, vp, C.POINTER(C.c_uint32), i]
+    lib.oetr_overlap_crop_capacity.restype = sz
+    lib.oetr_overlap_crop_capacity.argtypes = [i, i, i, i, i, i, C.POINTER(i), C.POINTER(i)]
+    lib.oetr_overlap_crop.restype = i
+    lib.oetr_overlap_crop.argtypes = [vp, vp, i, i, i, i, i, vp, vp, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), i, i, i, vp, vp, vp, sz, vp, vp]
     if lib.oetr_abi_version() != ABI_VERSION:
         raise RuntimeError(f'{p}: ABI version {lib.oetr_abi_version()} != '
                            f'{ABI_VERSION}')
@@ -642,3 +655,78 @@ def full_attention(q, k, v):
     """HIP version of reference ``FullAttention.forward``
     (``src/models/linear_attention.py:53-87``)."""
     return _attention('oetr_full_attention', q, k, v)
+
+
+class OverlapCrops:
+    """Result of :func:`overlap_crop`: device buffers + the device-side geometry.
+    Nothing here has touched the host yet; :meth:`geometry` (or any of the properties
+    built on it) copies the 120-byte ``oetr_crop_info`` back, which synchronises the
+    stream - do it when the crops are about to be consumed."""
+
+    def __init__(self, out0, out1, info, channels):
+        self._out, self._info, self._channels, self._geo = (out0, out1), info, channels, None
+
+    def geometry(self):
+        if self._geo is None:
+            raw = bytes(self._info.cpu().numpy().tobytes()[:C.sizeof(_CropInfo)])
+            self._geo = _CropInfo.from_buffer_copy(raw)
+        return self._geo
+
+    @property
+    def valid(self):
+        return bool(self.geometry().valid)
+
+    def crop(self, i):
+        """[1, C, out_h, out_w] view of image ``i``'s crop (the reference's ``left[None]``)."""
+        g = self.geometry()
+        h, w = int(g.out_h[i]), int(g.out_w[i])
+        return self._out[i][:self._channels * h * w].view(1, self._channels, h, w)
+
+    def bbox(self, i):
+        """The reference's ``pred['bbox0'/'bbox1']``: the scaled float box, [1, 4]."""
+        return torch.tensor([list(self.geometry().sbox[i])], dtype=torch.float32)
+
+    def ratio(self, i):
+        """The reference's ``ratio0/ratio1`` = [[rx, ry]] (Python floats)."""
+        g = self.geometry()
+        return [[float(g.ratio[i][0]), float(g.ratio[i][1])]]
+
+
+def overlap_crop(image0, image1, box0, box1, scales0, scales1, keep_aspect=True,
+                 size_divisor=1, pragueparks=False):
+    """HIP version of the reference's box -> crop step (``evaluation.py:82-170`` +
+    ``tensor_overlap_crop``, ``dloc/core/utils/utils.py:509-564``) for one pair, enqueued
+    on torch's current stream with the boxes staying on the GPU.
+
+    ``image0/1``: [1,C,H,W] float32 GPU tensors in [0,1]; ``box0/1``: the OETR boxes
+    ([N,4] or [4]; entry 0 is used, as the reference does); ``scales0/1``: (sx, sy)
+    ``overlap_scales`` of ``read_overlap_image``; ``keep_aspect`` = extractor is not
+    'disk'; ``size_divisor`` 8 for LoFTR; ``pragueparks`` selects that dataset's gate.
+    Returns an :class:`OverlapCrops`."""
+    lib = load_library()
+    image0, image1 = _dev(image0, 'image0'), _dev(image1, 'image1')
+    if image0.dim() != 4 or image1.dim() != 4 or image0.shape[0] != 1 or image1.shape[0] != 1 \
+            or image0.shape[1] != image1.shape[1]:
+        raise ValueError('images must be [1,C,H,W] with equal C')
+    dev = image0.device
+    b0 = _dev(box0.reshape(-1, 4)[0], 'box0')
+    b1 = _dev(box1.reshape(-1, 4)[0], 'box1')
+    ch, h0, w0 = (int(v) for v in image0.shape[1:])
+    h1, w1 = int(image1.shape[2]), int(image1.shape[3])
+    cap = lib.oetr_overlap_crop_capacity(ch, h0, w0, h1, w1, int(size_divisor), None, None)
+    if cap == 0:
+        raise ValueError('invalid crop arguments')
+    tmp = torch.empty(2 * cap, device=dev)
+    out0, out1 = torch.empty(cap, device=dev), torch.empty(cap, device=dev)
+    info = torch.zeros((C.sizeof(_CropInfo) + 7) // 8, dtype=torch.float64, device=dev)
+    s0 = (C.c_float * 2)(float(scales0[0]), float(scales0[1]))
+    s1 = (C.c_float * 2)(float(scales1[0]), float(scales1[1]))
+    with torch.cuda.device(dev):
+        _check(lib, lib.oetr_overlap_crop(
+            image0.data_ptr(), image1.data_ptr(), ch, h0, w0, h1, w1, b0.data_ptr(), b1.data_ptr(),
+            s0, s1, int(bool(keep_aspect)), int(size_divisor), int(bool(pragueparks)),
+            tmp.data_ptr(), out0.data_ptr(), out1.data_ptr(), cap, info.data_ptr(),
+            _stream(dev)), 'oetr_overlap_crop')
+    res = OverlapCrops(out0, out1, info, ch)
+    res._keep = (image0, image1, b0, b1, tmp)      # inputs stay alive until the work has run
+    return res

@@ -284,6 +284,53 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float *backbone_feat,
 oetr_status oetr_neck_query_flags(oetr_neck_handle h, void *stream,
                                   uint32_t *flags, int clear);
 
+/* ---- box -> crop step on the device ---------------------------
+ * Replaces, for one image pair, the overlap branch of Matching.forward (reference
+ * evaluation.py:82-170: boxes x overlap_scales, int truncation, the size gate) and
+ * tensor_overlap_crop / patch_resize (dloc/core/utils/utils.py:476-564: integer crop
+ * rectangle, target size from the larger-area image, cv2.resize INTER_CUBIC of the
+ * crop x255, optional second resize to a multiple of size_divisor, /255).  The
+ * reference reads the boxes back to the host and resizes with OpenCV on the CPU;
+ * here the boxes stay on the GPU and the step is enqueue-only (no D2H copy, no
+ * synchronisation): sizes are data dependent, so the caller provides buffers of
+ * oetr_overlap_crop_capacity() floats and reads the geometry from `info` (device
+ * memory) whenever it needs it.
+ * Integer / ratio outputs are pinned to the reference (tests/golden/crop.npz); the
+ * resize follows OpenCV's published float32 bicubic (a = -0.75) but is
+ * parity-UNPINNED: cv2 is not installed where the fixtures were generated. */
+typedef struct {
+  int32_t valid;        /* 1: crops made; 0: gate failed, full images passed through
+                           (evaluation.py:142-170) or a size exceeded the capacity   */
+  int32_t box[2][4];    /* scaled boxes truncated to int, xyxy (utils.py:515-516)      */
+  int32_t crop_w[2], crop_h[2]; /* slice sizes (Python slicing clamps at the border) */
+  int32_t new_w[2], new_h[2];   /* patch_resize output (utils.py:476-493)            */
+  int32_t out_w[2], out_h[2];   /* after rounding up to size_divisor (:547-556)      */
+  double ratio[2][2];   /* ratio1 / ratio2 = [[rx, ry]] as Python floats             */
+  float sbox[2][4];     /* bbox * overlap_scales: the 'bbox0' / 'bbox1' the reference
+                           returns (full-image box when valid == 0)                  */
+} oetr_crop_info;
+
+/* Floats per output buffer ([channels][cap_h][cap_w], cap = the larger image's size
+ * rounded up to size_divisor).  0 on invalid arguments. */
+size_t oetr_overlap_crop_capacity(int channels, int h1, int w1, int h2, int w2,
+                                  int size_divisor, int *cap_h, int *cap_w);
+
+/*   image1/image2 [channels][h][w]   the matcher's images (data['image0'/'image1'][0])
+ *   box1/box2     device [4]         entry 0 of the OETR boxes, OETR input frame
+ *   scale1/scale2 host (sx, sy)      overlap_scales0/1 (read_overlap_image, utils.py:313-318)
+ *   keep_aspect   extractor_name != 'disk';  size_divisor  8 for LoFTR, else 1
+ *   gate_mode     0: crops whenever every box side > 1 px; 1: 'pragueparks-val' rule
+ *                 (additionally an integer size ratio > 2 between the two boxes)
+ *   tmp           2 x capacity floats (device scratch between the two resize passes)
+ *   out1/out2     capacity floats each; hold [channels][out_h][out_w] densely packed
+ *   info          device, written by the first launch                                */
+oetr_status oetr_overlap_crop(const float *image1, const float *image2, int channels,
+                              int h1, int w1, int h2, int w2, const float *box1,
+                              const float *box2, const float scale1[2],
+                              const float scale2[2], int keep_aspect, int size_divisor,
+                              int gate_mode, float *tmp, float *out1, float *out2,
+                              size_t capacity_floats, oetr_crop_info *info, void *stream);
+
 /* ---- measurement hook (bench.py / profiling only) -------------------------
  * A trace owns a pool of HIP events.  While attached to a handle, every
  * kernel launched by the forward entry points is bracketed by two events

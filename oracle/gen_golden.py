@@ -276,15 +276,114 @@ def gen_misc(out_dir):
     print('misc.npz')
 
 
+# (image0 hw, image1 hw, channels, box0, box1 in the OETR input frame, overlap_scales0,
+#  overlap_scales1, extractor name, matcher name, dataset name)
+CROP_CASES = [
+    ((480, 640), (480, 640), 1, (100.3, 50.7, 300.9, 250.2), (20.0, 30.0, 320.5, 400.0),
+     (1.0, 0.75), (1.0, 0.75), 'superpoint', 'superglue', 'megadepth'),
+    ((480, 640), (640, 480), 3, (0.0, 0.0, 640.0, 640.0), (33.3, 44.4, 555.5, 600.1),
+     (1.0, 0.75), (0.75, 1.0), 'disk', 'superglue', 'megadepth'),
+    ((96, 128), (160, 96), 3, (10.2, 8.8, 90.9, 70.1), (5.5, 5.5, 60.6, 120.9),
+     (0.2, 0.15), (0.15, 0.25), 'superpoint', 'loftr', 'imc'),           # size_divisor 8
+    ((96, 128), (96, 128), 1, (10.0, 10.0, 11.5, 90.0), (5.0, 5.0, 60.0, 80.0),
+     (1.0, 1.0), (1.0, 1.0), 'superpoint', 'superglue', 'megadepth'),    # 1-px-wide box: gated out
+    ((120, 160), (120, 160), 1, (10.0, 10.0, 150.0, 110.0), (30.0, 30.0, 70.0, 60.0),
+     (1.0, 1.0), (1.0, 1.0), 'superpoint', 'superglue', 'pragueparks-val'),   # ratio 3 > 2: crops
+    ((120, 160), (120, 160), 1, (10.0, 10.0, 150.0, 110.0), (30.0, 30.0, 130.0, 100.0),
+     (1.0, 1.0), (1.0, 1.0), 'superpoint', 'superglue', 'pragueparks-val'),   # ratio 1: no crops
+    ((200, 300), (100, 150), 3, (250.0, 150.0, 420.0, 280.0), (10.0, 10.0, 140.0, 95.0),
+     (0.75, 0.75), (1.0, 1.0), 'd2net', 'loftr', 'megadepth'),           # box past the border
+    ((64, 64), (64, 64), 1, (3.9, 3.9, 60.1, 60.1), (0.0, 0.0, 64.0, 64.0),
+     (1.0, 1.0), (1.0, 1.0), 'disk', 'loftr', 'megadepth'),
+]
+
+
+def gen_crop(out_dir):
+    """Box -> crop step from the reference's own code: the overlap
+    branch of ``Matching.forward`` (evaluation.py:66-170; its function body is compiled
+    straight from /root/reference/evaluation.py - importing that module would drag in
+    h5py, the extractors and the matchers) with ``tensor_overlap_crop`` /
+    ``patch_resize`` imported from dloc/core/utils/utils.py.  cv2 is not installed:
+    ``cv2.resize`` is the oracle's restatement of OpenCV's bicubic, so the PIXELS of the
+    crops pin only the crop / x255 / second-resize plumbing, never cv2's numerics; the
+    integer geometry, the ratios and the gate are the reference's own arithmetic."""
+    import ast
+    from oracle import crop_oracle as cro
+    cv2 = sys.modules['cv2']
+    cv2.INTER_CUBIC = 2
+    cv2.resize = lambda img, size, interpolation=None: cro.bicubic_resize(img, size[0], size[1])
+    import importlib
+    utils = importlib.import_module('dloc.core.utils.utils')
+    tree = ast.parse((REF / 'evaluation.py').read_text())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'Matching')
+    fwd = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'forward')
+    ns = {'torch': torch, 'tensor_overlap_crop': utils.tensor_overlap_crop}
+    exec(compile(ast.Module(body=[fwd], type_ignores=[]), str(REF / 'evaluation.py'), 'exec'), ns)
+    forward = ns['forward']
+
+    data = {'n_cases': np.int64(len(CROP_CASES))}
+    for ci, (hw0, hw1, ch, box0, box1, sc0, sc1, extractor_nm, matcher_nm, dataset) in enumerate(CROP_CASES):
+        g = torch.Generator().manual_seed(500 + ci)
+        im0 = torch.rand(1, ch, *hw0, generator=g)
+        im1 = torch.rand(1, ch, *hw1, generator=g)
+        seen = {}
+
+        class Self:        # the attributes Matching.forward touches on its overlap branch
+            config = {'direct': True}
+            matcher_name, extractor_name, size_divisor = matcher_nm, extractor_nm, 1
+
+            @staticmethod
+            def overlap(d):
+                return torch.tensor([box0]), torch.tensor([box1])
+
+            @staticmethod
+            def matcher(d):
+                seen['cropped'] = 'overlap_image0' not in d
+                seen['image0'], seen['image1'] = d['image0'], d['image1']
+                return {}
+
+        pred = forward(Self, {'image0': im0, 'image1': im1, 'overlap_image0': im0, 'overlap_image1': im1,
+                              'overlap_scales0': sc0, 'overlap_scales1': sc1, 'dataset_name': dataset},
+                       with_overlap=True)
+        tag = f'c{ci}_'
+        data[tag + 'hw0'], data[tag + 'hw1'] = np.asarray(hw0), np.asarray(hw1)
+        data[tag + 'channels'] = np.int64(ch)
+        data[tag + 'seed'] = np.int64(500 + ci)
+        data[tag + 'box0'], data[tag + 'box1'] = np.float32(box0), np.float32(box1)
+        data[tag + 'scales0'], data[tag + 'scales1'] = np.float64(sc0), np.float64(sc1)
+        data[tag + 'keep_aspect'] = np.int64(extractor_nm != 'disk')
+        data[tag + 'size_divisor'] = np.int64(8 if matcher_nm == 'loftr' else 1)
+        data[tag + 'pragueparks'] = np.int64(dataset == 'pragueparks-val')
+        data[tag + 'valid'] = np.int64(seen['cropped'])
+        data[tag + 'bbox0'] = pred['bbox0'].reshape(-1).numpy().astype(np.float32)
+        data[tag + 'bbox1'] = pred['bbox1'].reshape(-1).numpy().astype(np.float32)
+        data[tag + 'ratio0'] = np.asarray(pred['ratio0'], dtype=np.float64).reshape(-1)
+        data[tag + 'ratio1'] = np.asarray(pred['ratio1'], dtype=np.float64).reshape(-1)
+        data[tag + 'out_shape0'] = np.asarray(seen['image0'].shape)
+        data[tag + 'out_shape1'] = np.asarray(seen['image1'].shape)
+        data[tag + 'in_fp'] = np.stack([fp(im0), fp(im1)])
+        data[tag + 'out_fp'] = np.stack([fp(seen['image0']), fp(seen['image1'])])
+        if im0.numel() <= 40000:     # small cases: the crops themselves
+            data[tag + 'crop0'], data[tag + 'crop1'] = seen['image0'].numpy(), seen['image1'].numpy()
+        print(f'crop case {ci}: cropped={seen["cropped"]} out {tuple(seen["image0"].shape)} '
+              f'{tuple(seen["image1"].shape)} ratio0 {data[tag + "ratio0"]}')
+    np.savez_compressed(out_dir / 'crop.npz', **data)
+    print('crop.npz', len(CROP_CASES), 'cases')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=str(REPO / 'tests' / 'golden'))
+    ap.add_argument('--only', default=None, help='generate one family only (e.g. crop)')
     args = ap.parse_args()
     out_dir = Path(args.out)
     out_dir.mkdir(parents=True, exist_ok=True)
     torch.set_grad_enabled(False)
     install_stubs()
+    if args.only == 'crop':
+        return gen_crop(out_dir)
     gen_misc(out_dir)
+    gen_crop(out_dir)
     gen_attention(out_dir)
     model = build_reference_model()
     gen_hot(out_dir, model)

@@ -1,0 +1,149 @@
+"""GPU tests of the two "next" rows either side of the hot path:
+
+* the device-side box -> crop step (``oetr_overlap_crop``) against the goldens the
+  reference's own functions produced (gate, scaled boxes, ratios, shapes: exact) and
+  against the oracle's restatement of OpenCV's bicubic (pixels; OpenCV itself is
+  parity-unpinned - cv2 is not installed);
+* the batched pair front-end (``forward_pairs``) on the real model: a mixed list of
+  640x640 / 640x1280 / 480x640 pairs must give, in input order, the boxes of the
+  reference's per-pair loop.
+"""
+import numpy as np
+import pytest
+import torch
+
+import imagematching_oetr_amd as pkg
+from oracle import crop_oracle as cro
+from oracle import oetr_oracle as orc
+from tests.test_crop_cpu import load_cases
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+PIX_TOL = 2e-6      # crops live in [0,1]; same algorithm, fp32, different FMA contraction
+
+
+def test_crop_step_matches_reference_goldens(gpu, golden_dir):
+    n = 0
+    for ci, c, im0, im1 in load_cases(golden_dir):
+        res = pkg.overlap_crop(im0.to(gpu), im1.to(gpu), torch.from_numpy(c['box0']).to(gpu),
+                               torch.from_numpy(c['box1']).to(gpu), tuple(c['scales0']),
+                               tuple(c['scales1']), keep_aspect=bool(c['keep_aspect']),
+                               size_divisor=int(c['size_divisor']), pragueparks=bool(c['pragueparks']))
+        assert res.valid == bool(c['valid']), ci
+        for i, s in ((0, '0'), (1, '1')):
+            assert np.array_equal(res.bbox(i).numpy().reshape(-1), c['bbox' + s]), (ci, i)
+            assert np.array_equal(np.float32(res.ratio(i)).astype(np.float64).reshape(-1), c['ratio' + s]), (ci, i)
+            crop = res.crop(i)
+            assert tuple(crop.shape) == tuple(c['out_shape' + s]), (ci, i)
+            if 'crop' + s in c:
+                err = float((crop.cpu() - torch.from_numpy(c['crop' + s])).abs().max())
+                assert err <= PIX_TOL, (ci, i, err)
+        # all cases: pixels vs the oracle
+        ref = cro.overlap_crop(im0, im1, torch.from_numpy(c['box0']), torch.from_numpy(c['box1']),
+                               tuple(c['scales0']), tuple(c['scales1']), bool(c['keep_aspect']),
+                               int(c['size_divisor']), bool(c['pragueparks']))
+        assert float((res.crop(0).cpu() - ref['crop0']).abs().max()) <= PIX_TOL
+        assert float((res.crop(1).cpu() - ref['crop1']).abs().max()) <= PIX_TOL
+        n += 1
+    assert n == 8
+
+
+def test_crop_geometry_fuzz_is_bit_exact_vs_oracle(gpu):
+    """Random boxes / scales / sizes / modes: every integer, ratio and the gate equal to
+    the oracle's (which is pinned to the reference by tests/golden/crop.npz)."""
+    import random
+    rng = random.Random(11)
+    im_cache = {}
+    for case in range(60):
+        hw0 = (rng.randrange(40, 200), rng.randrange(40, 200))
+        hw1 = (rng.randrange(40, 200), rng.randrange(40, 200))
+        for hw in (hw0, hw1):
+            if hw not in im_cache:
+                im_cache[hw] = torch.rand(1, 1, *hw, generator=torch.Generator().manual_seed(hw[0] * 1000 + hw[1]))
+        sc0 = (rng.choice([1.0, 0.75, 0.3, 1.6]), rng.choice([1.0, 0.6, 0.25, 1.3]))
+        sc1 = (rng.choice([1.0, 0.75, 0.3, 1.6]), rng.choice([1.0, 0.6, 0.25, 1.3]))
+
+        def box(hw, sc):
+            w, h = hw[1] / sc[0], hw[0] / sc[1]          # OETR-frame size that maps onto the image
+            x1, y1 = rng.uniform(0, w * 0.7), rng.uniform(0, h * 0.7)
+            return torch.tensor([x1, y1, x1 + rng.uniform(0.5, w * 0.6), y1 + rng.uniform(0.5, h * 0.6)])
+        b0, b1 = box(hw0, sc0), box(hw1, sc1)
+        keep, div, pp = rng.random() < 0.7, rng.choice([1, 1, 8]), rng.random() < 0.3
+        ref = cro.overlap_crop(im_cache[hw0], im_cache[hw1], b0, b1, sc0, sc1, keep, div, pp)
+        res = pkg.overlap_crop(im_cache[hw0].to(gpu), im_cache[hw1].to(gpu), b0.to(gpu), b1.to(gpu),
+                               sc0, sc1, keep, div, pp)
+        assert res.valid == ref['valid'], case
+        for i, s in ((0, '0'), (1, '1')):
+            assert torch.equal(res.bbox(i).reshape(-1), ref['bbox' + s].float().reshape(-1)), (case, i)
+            assert res.ratio(i)[0] == list(ref['ratio' + s]), (case, i)
+            assert tuple(res.crop(i).shape) == tuple(ref['crop' + s].shape), (case, i)
+            assert float((res.crop(i).cpu() - ref['crop' + s]).abs().max()) <= PIX_TOL, (case, i)
+
+
+def test_crop_step_is_enqueue_only(gpu):
+    """No device-to-host copy or synchronisation inside the call: it can be captured in a
+    HIP graph together with the hot path that produced the boxes, and replayed."""
+    g0 = torch.Generator().manual_seed(3)
+    im0, im1 = torch.rand(1, 3, 96, 128, generator=g0).to(gpu), torch.rand(1, 3, 80, 112, generator=g0).to(gpu)
+    b0 = torch.tensor([[10.0, 12.0, 100.0, 80.0]], device=gpu)
+    b1 = torch.tensor([[5.0, 6.0, 90.0, 70.0]], device=gpu)
+    eager = pkg.overlap_crop(im0, im1, b0, b1, (1, 1), (1, 1), True, 8)
+    want0 = eager.crop(0).clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = pkg.overlap_crop(im0, im1, b0, b1, (1, 1), (1, 1), True, 8)
+    b0.copy_(torch.tensor([[20.0, 12.0, 100.0, 80.0]]))       # new boxes, same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    fresh = pkg.overlap_crop(im0, im1, b0, b1, (1, 1), (1, 1), True, 8)
+    assert torch.equal(captured.crop(0), fresh.crop(0)) and not torch.equal(fresh.crop(0), want0)
+
+
+def test_crop_argument_errors(gpu):
+    im = torch.rand(1, 1, 32, 32, device=gpu)
+    b = torch.tensor([[1.0, 1.0, 20.0, 20.0]], device=gpu)
+    with pytest.raises(ValueError):
+        pkg.overlap_crop(im, torch.rand(1, 3, 32, 32, device=gpu), b, b, (1, 1), (1, 1))
+    with pytest.raises(pkg.OetrError):
+        pkg.overlap_crop(im.cpu(), im, b, b, (1, 1), (1, 1))
+    with pytest.raises(ValueError):
+        pkg.overlap_crop(im, im, b, b, (1, 1), (1, 1), size_divisor=0)
+
+
+def test_forward_pairs_equals_the_per_pair_loop_on_the_real_model(gpu):
+    """Mixed 640x640 / 640x1280 / 480x640 pairs through trunk + HIP neck + HIP hot path
+    in shape buckets: entry i must be what forward_dummy returns for pair i alone
+    (reference evaluation.py:77-80).  The HIP stages are batch-invariant bit for bit; the
+    torch/MIOpen trunk may pick another convolution algorithm for another batch size, so
+    the end-to-end comparison allows 0.05 px (the box tolerance of the parity tests)
+    while the HIP part is checked bit-exactly on identical features."""
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    sd = model.state_dict()
+    sd.update(orc.make_hot_weights(5, sharpen=True))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    g = torch.Generator().manual_seed(9)
+    sizes = [((640, 640), (640, 640)), ((640, 1280), (640, 640)), ((480, 640), (480, 640)),
+             ((640, 640), (640, 640)), ((640, 1280), (640, 640)), ((640, 640), (640, 640)),
+             ((480, 640), (480, 640)), ((640, 640), (640, 640))]
+    pairs = [(torch.rand(1, *a, 3, generator=g), torch.rand(*b, 3, generator=g)) for a, b in sizes]
+    b0, b1 = pkg.forward_pairs(model, pairs, max_batch=8)
+    assert b0.shape == (len(pairs), 4) and b0.device.type == 'cuda'
+    exact = True
+    for i, (a, b) in enumerate(pairs):
+        e0, e1 = model.forward_dummy(a.to(gpu), b[None].to(gpu))
+        assert float((b0[i] - e0[0]).abs().max()) <= 5e-2 and float((b1[i] - e1[0]).abs().max()) <= 5e-2, i
+        exact &= torch.equal(b0[i], e0[0]) and torch.equal(b1[i], e1[0])
+    print('forward_pairs bit-equal to the per-pair loop end to end:', exact)
+    # the HIP part on identical features: batched == one by one, bit for bit
+    idx = [i for i, s in enumerate(sizes) if s == sizes[0]]
+    im0 = torch.cat([pairs[i][0] for i in idx]).to(gpu)
+    im1 = torch.cat([pairs[i][1][None] for i in idx]).to(gpu)
+    f0, f1, p0, p1, *_ = model.feature_extraction(im0, im1)
+    full = model.boxes_from_features(f0, f1, p0, p1, (640, 640), (640, 640))
+    for j in range(len(idx)):
+        one = model.boxes_from_features(f0[j:j + 1].contiguous(), f1[j:j + 1].contiguous(), p0, p1,
+                                        (640, 640), (640, 640))
+        assert torch.equal(one[0][0], full[0][j]) and torch.equal(one[1][0], full[1][j])
