@@ -778,6 +778,14 @@ oetr_status oetr_full_attention(const float* q, const float* k, const float* v, 
   return OETR_OK;
 }
 
+oetr_status oetr_full_attention_split(const float* q, const float* k, const float* v, int n, int L,
+                                      int S, float* out, uint32_t* flags, void* stream) {
+  if (!q || !k || !v || !out || n <= 0 || L <= 0 || S <= 0)
+    return fail(OETR_ERR_BAD_ARG, "oetr_full_attention_split: bad argument");
+  HIP_TRY(launch_full_attention_split(q, k, v, n, L, S, out, flags, static_cast<hipStream_t>(stream)));
+  return OETR_OK;
+}
+
 // ---------------------------------------------------------------- neck ----
 namespace {
 

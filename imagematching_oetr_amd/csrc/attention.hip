@@ -172,4 +172,144 @@ hipError_t launch_full_attention(const float* q, const float* k, const float* v,
   return hipGetLastError();
 }
 
+// -------------------------------------------------------------- full, split f16
+// The same math on the f16 matrix pipe with the fp32-class operand split of common.h
+// (a = hi + lo/2^11, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation): 12
+// MFMAs of 32 cycles per 32x32 score tile instead of 32 f32 MFMAs of 64 cycles.
+//
+// One block = (image, head, 128 queries), 4 waves x 32 queries.  Per 32-key tile the
+// block converts K and V once into split planes in LDS (K row-major, V transposed with
+// the key order the MFMA k-slots want), then every wave computes, with NO lane
+// exchange at all:
+//   S^T = K . Q^T      A = K fragments (LDS),  B = Q (registers, split once)
+//   P   = exp(S^T/sqrt(D) - m)  in the lane that owns the query column
+//   O^T += V^T . P^T   A = V^T fragments (LDS), B = P straight from the S^T accumulator
+//                      registers (k-slot 8*half + i of step s <-> key crow(8s+i, half))
+// O^T keeps the query in the lane, so the online-softmax rescale and the final 1/l are
+// per-lane scalars.  The L x S score volume exists only in accumulators.
+constexpr int FA_PITCH = 40;   // halves per LDS row (32 + 8): conflict-free ds_read_b128
+
+__global__ __launch_bounds__(256) void k_full_attention_split(const float* __restrict__ q,
+                                                              const float* __restrict__ k,
+                                                              const float* __restrict__ v,
+                                                              int L, int S, float* __restrict__ out,
+                                                              uint32_t* flags) {
+  __shared__ __attribute__((aligned(16))) _Float16 Kh[32 * FA_PITCH], Kl[32 * FA_PITCH];
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * FA_PITCH], Vl[32 * FA_PITCH];  // [d][slot]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int qchunks = (L + 127) / 128;
+  const int qc = blockIdx.x % qchunks, nh = blockIdx.x / qchunks, n = nh / NH, h = nh % NH;
+  const int q0 = qc * 128 + wave * 32;
+  const float temp = 1.0f / sqrtf((float)HD);
+  Range rg;
+
+  // Q as the B operand of S^T = K Q^T: lane (query = col) holds d = 16s + 8*half + 0..7
+  f32x4 qh[2], ql[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (q0 + col < L) {
+      const float* qp = q + (((size_t)n * L + q0 + col) * NH + h) * HD + 16 * s + 8 * half;
+      a0 = *reinterpret_cast<const f32x4*>(qp);
+      a1 = *reinterpret_cast<const f32x4*>(qp + 4);
+    }
+    split8(a0, a1, qh[s], ql[s], rg);
+  }
+  f32x16 o = {0};   // O^T: rows = d (crow(r, half)), col = query
+  // (masked scores and the initial maximum are a large FINITE negative: exp_neg - the
+  //  6-instruction exp of common.h, arguments <= 0 - would turn -inf into NaN)
+  constexpr float NEG = -1.0e30f;
+  float m_run = NEG, l_run = 0.f;
+
+  // staging role: thread -> (key row = tid >> 3, 4 consecutive d = 4 * (tid & 7))
+  const int srow = tid >> 3, sd = 4 * (tid & 7);
+  // position of key `srow` in the k-slot order of the P.V contraction: swap bits 2 and 3
+  const int spos = (srow & ~12) | ((srow & 4) << 1) | ((srow & 8) >> 1);
+  auto load_kv = [&](int k0, f32x4& kk, f32x4& vv) {
+    kk = f32x4{0.f, 0.f, 0.f, 0.f};
+    vv = kk;
+    if (k0 + srow < S) {
+      const size_t off = (((size_t)n * S + k0 + srow) * NH + h) * HD + sd;
+      kk = *reinterpret_cast<const f32x4*>(k + off);
+      vv = *reinterpret_cast<const f32x4*>(v + off);
+    }
+  };
+  f32x4 kreg, vreg;
+  load_kv(0, kreg, vreg);
+  for (int k0 = 0; k0 < S; k0 += 32) {
+    __syncthreads();   // every wave is done with the previous tile's planes
+    store_planes4<GM_SPLIT>(Kh + srow * FA_PITCH, Kl + srow * FA_PITCH, sd, kreg, rg);
+    {
+      uint32_t h0, l0, h1, l1;
+      cvt_planes2<GM_SPLIT>(vreg[0], vreg[1], h0, l0, rg);
+      cvt_planes2<GM_SPLIT>(vreg[2], vreg[3], h1, l1, rg);
+      uint16_t* vh = reinterpret_cast<uint16_t*>(Vh);
+      uint16_t* vl = reinterpret_cast<uint16_t*>(Vl);
+      vh[(sd + 0) * FA_PITCH + spos] = (uint16_t)h0; vh[(sd + 1) * FA_PITCH + spos] = (uint16_t)(h0 >> 16);
+      vh[(sd + 2) * FA_PITCH + spos] = (uint16_t)h1; vh[(sd + 3) * FA_PITCH + spos] = (uint16_t)(h1 >> 16);
+      vl[(sd + 0) * FA_PITCH + spos] = (uint16_t)l0; vl[(sd + 1) * FA_PITCH + spos] = (uint16_t)(l0 >> 16);
+      vl[(sd + 2) * FA_PITCH + spos] = (uint16_t)l1; vl[(sd + 3) * FA_PITCH + spos] = (uint16_t)(l1 >> 16);
+    }
+    if (k0 + 32 < S) load_kv(k0 + 32, kreg, vreg);   // next tile's rows under this tile's math
+    __syncthreads();
+
+    // S^T tile: rows = keys, cols = queries
+    f32x16 st = {0}, cr = {0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const f32x4 ah = *reinterpret_cast<const f32x4*>(Kh + col * FA_PITCH + 16 * s + 8 * half);
+      const f32x4 al = *reinterpret_cast<const f32x4*>(Kl + col * FA_PITCH + 16 * s + 8 * half);
+      mma16_split3(ah, al, qh[s], ql[s], st, cr);
+    }
+    float mt = NEG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sv = fmaf(cr[r], SPLIT_INV, st[r]);
+      st[r] = (k0 + crow(r, half) < S) ? sv * temp : NEG;
+      mt = fmaxf(mt, st[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = exp_neg(fminf(m_run - m_new, 0.f));  // 0 on the first tile
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = exp_neg(fminf(st[r] - m_new, 0.f)); ps += st[r]; }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;   // this lane's query, all of its d rows
+    // O^T += V^T P^T
+    f32x16 oc = {0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 ph, pl;
+      split8(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]},
+             f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]}, ph, pl, rg);
+      const f32x4 ah = *reinterpret_cast<const f32x4*>(Vh + col * FA_PITCH + 16 * s + 8 * half);
+      const f32x4 al = *reinterpret_cast<const f32x4*>(Vl + col * FA_PITCH + 16 * s + 8 * half);
+      mma16_split3(ah, al, ph, pl, o, oc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = fmaf(oc[r], SPLIT_INV, o[r]);
+  }
+  if (q0 + col < L) {
+    const float inv = 1.0f / l_run;
+    float* dst = out + (((size_t)n * L + q0 + col) * NH + h) * HD + 4 * half;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)   // registers 4*g4 .. 4*g4+3 = d rows 8*g4 + 4*half + 0..3
+      *reinterpret_cast<f32x4*>(dst + 8 * g4) =
+          f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+  }
+  if (flags) range_report<GM_SPLIT>(rg, flags);
+}
+
+hipError_t launch_full_attention_split(const float* q, const float* k, const float* v, int n, int L,
+                                       int S, float* out, uint32_t* flags, hipStream_t s) {
+  const int qchunks = (L + 127) / 128;
+  hipLaunchKernelGGL(k_full_attention_split, dim3((unsigned)(n * NH * qchunks)), dim3(256), 0, s, q,
+                     k, v, L, S, out, flags);
+  return hipGetLastError();
+}
+
 }  // namespace oetr

@@ -1104,5 +1104,7 @@ hipError_t launch_linear_attention(const float* q, const float* k, const float* 
                                    int L, int S, float* out, hipStream_t s);
 hipError_t launch_full_attention(const float* q, const float* k, const float* v, int n,
                                  int L, int S, float* out, hipStream_t s);
+hipError_t launch_full_attention_split(const float* q, const float* k, const float* v, int n,
+                                       int L, int S, float* out, uint32_t* flags, hipStream_t s);
 
 }  // namespace oetr

@@ -77,7 +77,8 @@ EXPORTS = (
     'oetr_set_trace', 'oetr_trace_summary', 'oetr_neck_create',
     'oetr_neck_destroy', 'oetr_neck_workspace_bytes', 'oetr_neck_forward',
     'oetr_neck_set_trace', 'oetr_set_encoder_tile', 'oetr_query_flags',
-    'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity')
+    'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity',
+    'oetr_full_attention_split')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -168,6 +169,8 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.restype = i
         fn.argtypes = [vp, vp, vp, i, i, i, vp, vp]
+    lib.oetr_full_attention_split.restype = i
+    lib.oetr_full_attention_split.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
     lib.oetr_trace_create.restype = i
     lib.oetr_trace_create.argtypes = [i, C.POINTER(vp)]
     lib.oetr_trace_destroy.restype = None
@@ -651,10 +654,34 @@ def linear_attention(q, k, v):
     return _attention('oetr_linear_attention', q, k, v)
 
 
-def full_attention(q, k, v):
+FULL_ATTENTION_VARIANTS = ('f32', 'f32_split_f16')
+
+
+def full_attention(q, k, v, variant='f32', check_range=False):
     """HIP version of reference ``FullAttention.forward``
-    (``src/models/linear_attention.py:53-87``)."""
-    return _attention('oetr_full_attention', q, k, v)
+    (``src/models/linear_attention.py:53-87``).  ``variant``: 'f32' = exact fp32 MFMA
+    products; 'f32_split_f16' = fp32-class products on the f16 matrix pipe (3 MFMAs per
+    product; inputs must stay below 65504 - ``check_range=True`` verifies that, at the
+    price of a stream synchronisation)."""
+    if variant == 'f32':
+        return _attention('oetr_full_attention', q, k, v)
+    if variant != 'f32_split_f16':
+        raise ValueError(f'variant must be one of {FULL_ATTENTION_VARIANTS}')
+    lib = load_library()
+    q, k, v = _dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v')
+    n, L, h, d = q.shape
+    S = int(k.shape[1])
+    if (h, d) != (N_HEAD, D_MODEL // N_HEAD) or k.shape != (n, S, h, d) or v.shape != k.shape:
+        raise ValueError('attention expects q [N,L,8,32], k,v [N,S,8,32]')
+    out = torch.empty_like(q)
+    flags = torch.zeros(1, dtype=torch.int32, device=q.device) if check_range else None
+    with torch.cuda.device(q.device):
+        _check(lib, lib.oetr_full_attention_split(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), n, L, S, out.data_ptr(),
+            flags.data_ptr() if check_range else None, _stream(q.device)), 'oetr_full_attention_split')
+    if check_range and int(flags.item()) & FLAG_F16_RANGE:
+        raise OetrRangeError('full_attention: an input reached |x| >= 65504 under the f16 split')
+    return out
 
 
 class OverlapCrops:

@@ -246,6 +246,13 @@ oetr_status oetr_linear_attention(const float *q, const float *k,
  * "all-pairs QK^T volume" variant, never materialised in HBM.  Same shapes. */
 oetr_status oetr_full_attention(const float *q, const float *k, const float *v,
                                 int n, int L, int S, float *out, void *stream);
+/* The same on the f16 matrix pipe with the fp32-class operand split of
+ * OETR_DTYPE_F32_SPLIT_F16 (12 f16 MFMAs per 32x32 score tile instead of 32 f32 MFMAs;
+ * inputs must be < 65504: `flags`, an optional DEVICE uint32 word, receives
+ * OETR_FLAG_F16_RANGE otherwise - pass NULL to skip the check). */
+oetr_status oetr_full_attention_split(const float *q, const float *k,
+                                      const float *v, int n, int L, int S,
+                                      float *out, uint32_t *flags, void *stream);
 
 /* ---- neck: input_proj -> PatchMerging -> input_proj2 ------
  * The part of OETR.feature_extraction between the ResNet trunk and the hot

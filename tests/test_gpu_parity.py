@@ -176,6 +176,28 @@ def test_attention_cores_vs_reference_golden(gpu, golden_dir):
         full = full_attention(q.to(gpu), k.to(gpu), v.to(gpu)).reshape(2, L, 256)
         assert maxerr(lin[:, ::step], g[tag + '_lin']) <= 2e-6, tag
         assert maxerr(full[:, ::step], g[tag + '_full']) <= 5e-6, tag
+        # the f16-matrix-pipe variant (fp32-class operand split) of the same kernel
+        fs = full_attention(q.to(gpu), k.to(gpu), v.to(gpu), variant='f32_split_f16',
+                            check_range=True).reshape(2, L, 256)
+        assert maxerr(fs[:, ::step], g[tag + '_full']) <= 5e-6, tag
+
+
+def test_full_attention_split_edge_shapes_and_range(gpu):
+    """Ragged query / key counts (not multiples of 32 / 128), a single key, and the f16
+    range check of the split variant."""
+    from imagematching_oetr_amd import OetrRangeError, full_attention
+    for (n, L, S) in [(1, 1, 1), (3, 33, 95), (2, 129, 31), (1, 300, 1000)]:
+        gen = torch.Generator().manual_seed(L * 1000 + S)
+        q = (torch.rand(n, L, 8, 32, generator=gen) - 0.5) * 4
+        k = (torch.rand(n, S, 8, 32, generator=gen) - 0.5) * 4
+        v = (torch.rand(n, S, 8, 32, generator=gen) - 0.5) * 2
+        ref = orc.full_attention(q.double(), k.double(), v.double())
+        for variant in ('f32', 'f32_split_f16'):
+            out = full_attention(q.to(gpu), k.to(gpu), v.to(gpu), variant=variant)
+            assert maxerr(out, ref) <= 5e-6, (n, L, S, variant)
+    big = torch.full((1, 4, 8, 32), 7.0e4, device=gpu)
+    with pytest.raises(OetrRangeError):
+        full_attention(big, big, big, variant='f32_split_f16', check_range=True)
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)
