@@ -129,6 +129,9 @@ constexpr int NC_STAGES = NECK_PIX * 4;        // 16 pixels x 4 channel quarters
 static_assert(NC_ROWB % 16 == 0 && (NC_ROWB / 4) % 64 == 4, "conflict-free b128 row stride");
 
 struct ConvB { f32x4 h, l; };                  // one k16-step of B fragments (hi, lo)
+#ifndef NECK_SLICE_MAJOR
+#define NECK_SLICE_MAJOR 0   // work-item order: 0 = tile-major (X rows of a tile share an L2), 1 = slice-major
+#endif
 #ifndef NECK_ABL
 #define NECK_ABL 0   // timing experiments only: 1 no A gathers, 2 no B loads, 4 no MFMA, 8 no LDS writes
 #endif
@@ -145,7 +148,14 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   // 256-position tile are adjacent) and each XCD takes a contiguous run of them:
   // the gathered X rows of a tile (~1.6 MB) are then shared through ONE L2.
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
+#if NECK_SLICE_MAJOR
+  // slice-major: the 25 position tiles of one weight slice (2.2 MB) are adjacent, so an
+  // XCD keeps the slice in its L2 while it streams the tiles' X rows
+  const int mtiles = p.nblocks / p.items_per_mt;
+  const int it = logical / mtiles, mt = logical - it * mtiles;
+#else
   const int mt = logical / p.items_per_mt, it = logical - mt * p.items_per_mt;
+#endif
   const int ci = it >= p.conv[2].item0 ? 2 : (it >= p.conv[1].item0 ? 1 : 0);
   const NeckConvDesc& cd = p.conv[ci];
   const int rem = it - cd.item0;

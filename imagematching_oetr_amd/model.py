@@ -19,6 +19,9 @@ Their ``forward`` is never called.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from . import losses
 
 from .backbone import PatchMerging, PositionEncodingSine, ResnetEncoder
 from .hip_engine import (FLAG_F16_RANGE, HotPathEngine, NeckEngine, OetrRangeError,
@@ -113,6 +116,7 @@ class OETR(nn.Module):
         self.pos_encoding = PositionEncodingSine(d, max_shape=cfg.NECK.MAX_SHAPE)
         self.max_shape = cfg.NECK.MAX_SHAPE
         self.cycle = cfg.LOSS.CYCLE_OVERLAP
+        self.oiou = cfg.LOSS.OIOU          # IouOverlapLoss(oiou=cfg.LOSS.OIOU), reference model.py:89
         self.softmax_temperature = 1
         #: GEMM arithmetic of the HIP hot path: 'f32_split_f16' (default, fp32-class),
         #: 'f32' (exact), 'f16' / 'bf16' (operands rounded, reduced parity margin)
@@ -296,9 +300,67 @@ class OETR(nn.Module):
         return boxes
 
     def forward(self, data, validation=False):
-        raise NotImplementedError(
-            'training forward (losses/autograd, reference src/model.py:255-376)'
-            ' is out of scope for the HIP path; use forward_dummy')
+        """Training-side pipeline of reference ``src/model.py:255-376`` as a FORWARD
+        pass: the pairs selected by ``data['overlap_valid']`` go through the HIP hot
+        path, the UNCLAMPED boxes (``obtain_overlap_bbox``, ``:193-226``) are compared
+        with ``data['overlap_box1/2']`` and the reference's result dict is returned
+        (``pred_bbox1/2``, ``iouloss``, ``wh_loss``, ``loc_loss``, ``iou1/2``,
+        ``oiou1/2`` and, with ``LOSS.CYCLE_OVERLAP``, ``cycle_loss``).
+
+        The HIP kernels have no backward: the losses are VALUES (validation, loss
+        curves, checkpoint selection).  Called with autograd enabled on parameters that
+        require grad this raises instead of silently returning graph-less losses."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                'OETR.forward(data): the HIP hot path has no backward kernels - wrap the call '
+                'in torch.no_grad() (loss values / metrics), or train with the reference '
+                'PyTorch model and load the checkpoint here (same state-dict keys)')
+        if 'resize_mask1' in data:
+            self._no_masks(data['resize_mask1'], data['resize_mask2'])
+        valid = data['overlap_valid']
+        image1, image2 = data['image1'][valid], data['image2'][valid]
+        h1, w1 = image1.shape[1:3]
+        h2, w2 = image2.shape[1:3]
+        self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
+        with torch.no_grad():
+            feat1, feat2, pos1, pos2, hf1, wf1, hf2, wf2 = self.feature_extraction(image1, image2)
+            eng = self.engine()
+            st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True)
+            if self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE \
+                    and eng.query_flags() & FLAG_F16_RANGE:
+                if self.hip_on_overflow == 'raise':
+                    raise OetrRangeError('a GEMM operand reached |x| >= 65504; use hip_precision "f32"')
+                eng = self.exact_engine()
+                st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True)
+            xyxy1, xyxy2, cxywh1, cxywh2 = losses.obtain_overlap_bbox(
+                st['cxy1'], st['tlbr1'], st['cxy2'], st['tlbr2'], (h1, w1), (h2, w2))
+            gt1 = data['overlap_box1'][valid].to(xyxy1.device)
+            gt2 = data['overlap_box2'][valid].to(xyxy1.device)
+            gtc1 = losses.box_xyxy_to_cxywh(gt1, max_h=h1, max_w=w1)
+            gtc2 = losses.box_xyxy_to_cxywh(gt2, max_h=h2, max_w=w2)
+            s1 = torch.tensor([w1, h1], device=xyxy1.device)
+            s2 = torch.tensor([w2, h2], device=xyxy1.device)
+            loc = F.l1_loss(cxywh1[:, :2] / s1, gtc1[:, :2] / s1) + F.l1_loss(cxywh2[:, :2] / s2, gtc2[:, :2] / s2)
+            wh = (F.l1_loss(cxywh1[:, 2:] / s1, gtc1[:, 2:] / s1) + F.l1_loss(cxywh2[:, 2:] / s2, gtc2[:, 2:] / s2)) / 2
+            box_loss = losses.oiou_loss if self.oiou else losses.giou_loss
+            iouloss = (box_loss(xyxy1, gt1) + box_loss(xyxy2, gt2)) / 2.0
+            results = {
+                'pred_bbox1': xyxy1, 'pred_bbox2': xyxy2,
+                'iouloss': iouloss.mean(), 'wh_loss': wh.mean(), 'loc_loss': loc.mean(),
+                'iou1': losses.bbox_iou_aligned(xyxy1, gt1).mean(),
+                'iou2': losses.bbox_iou_aligned(xyxy2, gt2).mean(),
+                'oiou1': losses.bbox_oiou(gt1, xyxy1).mean(),
+                'oiou2': losses.bbox_oiou(gt2, xyxy2).mean(),
+            }
+            if self.cycle:
+                # centres with the two decoder queries swapped (reference model.py:354-356)
+                c1f2, c2f1 = eng.center_estimation(st['hs2'], st['hs1'], st['memory1'], st['memory2'],
+                                                   hf1, wf1, hf2, wf2, h1, h2)
+                _, _, cyc1, cyc2 = losses.obtain_overlap_bbox(c1f2, st['tlbr1'], c2f1, st['tlbr2'],
+                                                              (h1, w1), (h2, w2))
+                cycle = F.l1_loss(cyc1[:, :2] / s1, gtc1[:, :2] / s1) + F.l1_loss(cyc2[:, :2] / s2, gtc2[:, :2] / s2)
+                results['cycle_loss'] = cycle.mean()
+        return results
 
 
 def build_detectors(cfg):

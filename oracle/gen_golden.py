@@ -371,6 +371,36 @@ def gen_crop(out_dir):
     print('crop.npz', len(CROP_CASES), 'cases')
 
 
+@torch.no_grad()
+def gen_train_forward(out_dir, model):
+    """Training-side ``OETR.forward(data)`` (src/model.py:255-376) of the REFERENCE model on
+    CPU: unclamped boxes (obtain_overlap_bbox), L1 / GIoU (or oIoU) / cycle losses and the
+    IoU metrics, for a small seeded batch with a partially valid ``overlap_valid`` mask."""
+    sd = model.state_dict()
+    sd.update(orc.make_hot_weights(5, sharpen=True))
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(77)
+    data = {
+        'image1': torch.rand(3, 128, 160, 3, generator=g),
+        'image2': torch.rand(3, 160, 128, 3, generator=g),
+        'overlap_valid': torch.tensor([True, False, True]),
+        'overlap_box1': torch.tensor([[20.0, 10.0, 120.0, 100.0], [0.0, 0.0, 1.0, 1.0], [5.0, 30.0, 150.0, 126.0]]),
+        'overlap_box2': torch.tensor([[10.0, 25.0, 100.0, 140.0], [0.0, 0.0, 1.0, 1.0], [-4.0, 8.0, 70.0, 170.0]]),
+    }
+    out = {'seed': np.int64(77), 'hot_seed': np.int64(5), 'in_fp': np.stack([fp(data['image1']), fp(data['image2'])])}
+    for k in ('overlap_valid', 'overlap_box1', 'overlap_box2'):
+        out[k] = data[k].numpy()
+    for tag, cycle, oiou in (('giou', False, False), ('giou_cycle', True, False), ('oiou_cycle', True, True)):
+        model.cycle = cycle
+        model.iouloss.oiou = oiou
+        res = model(dict(data))
+        for k, v in res.items():
+            out[f'{tag}_{k}'] = np.asarray(v.detach().numpy(), dtype=np.float32)
+        print(f'train_forward[{tag}]', {k: (float(v) if v.dim() == 0 else tuple(v.shape)) for k, v in res.items()})
+    model.cycle, model.iouloss.oiou = False, False
+    np.savez_compressed(out_dir / 'train_forward.npz', **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=str(REPO / 'tests' / 'golden'))
@@ -382,6 +412,8 @@ def main():
     install_stubs()
     if args.only == 'crop':
         return gen_crop(out_dir)
+    if args.only == 'train':
+        return gen_train_forward(out_dir, build_reference_model())
     gen_misc(out_dir)
     gen_crop(out_dir)
     gen_attention(out_dir)
@@ -389,6 +421,7 @@ def main():
     gen_hot(out_dir, model)
     gen_full(out_dir, model)
     gen_neck(out_dir, model)
+    gen_train_forward(out_dir, model)
 
 
 if __name__ == '__main__':

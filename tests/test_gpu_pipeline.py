@@ -147,3 +147,36 @@ def test_forward_pairs_equals_the_per_pair_loop_on_the_real_model(gpu):
         one = model.boxes_from_features(f0[j:j + 1].contiguous(), f1[j:j + 1].contiguous(), p0, p1,
                                         (640, 640), (640, 640))
         assert torch.equal(one[0][0], full[0][j]) and torch.equal(one[1][0], full[1][j])
+
+
+def test_training_forward_matches_the_reference_results(gpu, golden_dir):
+    """``OETR.forward(data)`` on the HIP stages vs the result dict the
+    REFERENCE model's forward produced on CPU for the same seeded weights and batch
+    (``tests/golden/train_forward.npz``): unclamped boxes, L1 / GIoU / oIoU / cycle losses,
+    IoU metrics.  Tolerances cover the torch-CPU vs MIOpen trunk (features differ ~1e-5)."""
+    g = np.load(golden_dir / 'train_forward.npz')
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    sd = model.state_dict()
+    sd.update(orc.make_hot_weights(int(g['hot_seed']), sharpen=True))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    gen = torch.Generator().manual_seed(int(g['seed']))
+    data = {'image1': torch.rand(3, 128, 160, 3, generator=gen), 'image2': torch.rand(3, 160, 128, 3, generator=gen)}
+    assert orc.checksum(data['image1']) == list(g['in_fp'][0])
+    data = {k: v.to(gpu) for k, v in data.items()}
+    data['overlap_valid'] = torch.from_numpy(g['overlap_valid']).to(gpu)
+    data['overlap_box1'] = torch.from_numpy(g['overlap_box1']).to(gpu)
+    data['overlap_box2'] = torch.from_numpy(g['overlap_box2']).to(gpu)
+    for tag, cycle, oiou in (('giou', False, False), ('giou_cycle', True, False), ('oiou_cycle', True, True)):
+        model.cycle, model.oiou = cycle, oiou
+        res = model(data)
+        keys = ['pred_bbox1', 'pred_bbox2', 'iouloss', 'wh_loss', 'loc_loss', 'iou1', 'iou2', 'oiou1',
+                'oiou2'] + (['cycle_loss'] if cycle else [])
+        assert set(res) == set(keys), sorted(res)
+        for k in res:
+            ref = torch.from_numpy(g[f'{tag}_{k}'])
+            err = float((res[k].cpu() - ref).abs().max())
+            tol = 0.1 if k.startswith('pred_bbox') else 2e-3
+            assert err <= tol, (tag, k, err)
+    model.cycle, model.oiou = False, False
