@@ -50,8 +50,9 @@ def test_forward_contract_without_a_gpu():
             'overlap_valid': torch.tensor([True]),
             'overlap_box1': torch.tensor([[1.0, 1.0, 30.0, 30.0]]),
             'overlap_box2': torch.tensor([[1.0, 1.0, 30.0, 30.0]])}
-    with pytest.raises(NotImplementedError, match='no backward'):
-        model(data)                       # autograd on: no graph-less losses by accident
+    with torch.enable_grad():
+        with pytest.raises(NotImplementedError, match='no backward'):
+            model(data)                   # autograd on: no graph-less losses by accident
     with torch.no_grad():
         with pytest.raises(NotImplementedError, match='masks'):
             model(dict(data, resize_mask1=torch.ones(1, 2, 2), resize_mask2=torch.ones(1, 2, 2)))
