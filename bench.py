@@ -100,6 +100,9 @@ def parse_args(argv=None):
                     help='token rows per encoder workgroup (0: 64 while batches overlap on several '
                          'streams - fewest CU-microseconds per token - and the library default, '
                          '32 at this size, for the serial pass)')
+    ap.add_argument('--attention', default='linear', choices=['linear', 'full'],
+                    help="encoder attention core: 'linear' (the reference's default model) or 'full' "
+                         "(EncoderLayer(attention='full'): all-pairs softmax attention, flash style)")
     ap.add_argument('--kernel', default=None, choices=[None, 'full_attention'],
                     help='micro-benchmark of one stand-alone kernel instead of the hot path')
     ap.add_argument('--L', type=int, default=1024, help='--kernel full_attention: tokens per image')
@@ -218,12 +221,12 @@ def mangled_encoder(tile, mode_id):
     return f'k_encoderILb1ELi0ELi{mode_id}ELi{4 if mode_id == 0 else 8}EE'
 
 
-def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload):
+def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload, extra_flop=0):
     if not kern or DOMINANT not in kern:
         return None
     launches, total_ms = kern[DOMINANT]
     avg_ms = total_ms / launches
-    flop = ENC_FLOP_PER_TOKEN * tokens            # algorithmic, both sides
+    flop = ENC_FLOP_PER_TOKEN * tokens + extra_flop   # algorithmic, both sides
     cost, pipe_peak, basis = MFMA_COST[precision]
     # `achieved` is ALGORITHMIC FLOP/s; the MFMA roof for a scheme that spends `cost`
     # MFMA products per algorithmic product is the pipe's dense peak / cost.
@@ -337,7 +340,7 @@ def main():
     hw, hw2 = (args.size, args.size), (size2, size2)
     n_total = n * world
     tokens = n * (hf * hf + hf2 * hf2)
-    standard = (n, args.size, size2) == (8, 640, 640)
+    standard = (n, args.size, size2) == (8, 640, 640) and args.attention == 'linear'
 
     gatherer = BoxGatherer() if world > 1 else None
     n_streams = max(1, args.streams)
@@ -388,9 +391,10 @@ def main():
         return trace.summary(), dt
 
     def measure(precision, with_serial_trace):
-        eng = pkg.HotPathEngine(weights, device=device, precision=precision)
+        eng = pkg.HotPathEngine(weights, device=device, precision=precision,
+                                attention=args.attention if precision == args.precision else 'linear')
         half = precision != 'f32'
-        tile_overlap = args.enc_tile or (64 if (n_streams > 1 and half) else 0)
+        tile_overlap = args.enc_tile or (64 if (n_streams > 1 and half and eng.attention == 'linear') else 0)
         res = {'tile_overlap': tile_overlap, 'engine': eng}
         eng.set_encoder_tile(args.enc_tile)
         warm(eng, 1)
@@ -411,7 +415,7 @@ def main():
     main_res = measure(args.precision, with_serial_trace=True)
     eng = main_res['engine']
     exact_res = None
-    if args.precision == 'f32_split_f16' and not args.no_exact_f32:
+    if args.precision == 'f32_split_f16' and not args.no_exact_f32 and args.attention == 'linear':
         exact_res = measure('f32', with_serial_trace=False)
 
     if rank != 0:
@@ -448,7 +452,8 @@ def main():
         'config': {'workload': tag + f'batch={n} pairs/GPU, {args.size}x{args.size}'
                                + (f' vs {size2}x{size2}' if size2 != args.size else '')
                                + f' -> {hf}x{hf}' + (f' / {hf2}x{hf2}' if hf2 != hf else '')
-                               + f' tokens/image, C=256, 8 enc + 2 dec layers, {args.precision}',
+                               + f' tokens/image, C=256, 8 enc + 2 dec layers, {args.precision}'
+                               + (', attention=full' if args.attention == 'full' else ''),
                    'pairs_per_gpu': n, 'global_pairs': n_total,
                    'streams': n_streams,
                    'encoder_tile_rows': tile_overlap or 'auto',

@@ -137,6 +137,7 @@ struct oetr_ctx {
   int device = 0;
   int mode = GM_SPLIT;  // oetr_dtype == GM_* (common.h)
   int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
+  int attn_full = 0;   // OETR_ATTENTION_FULL (oetr_set_attention)
   int num_cus = 256;
   float* dev = nullptr;  // all repacked weights
   size_t dev_floats = 0;
@@ -170,7 +171,7 @@ long long* g_tbuf = nullptr;
 
 struct Workspace {
   float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
-      *logits, *cxy, *tlbr, *convp;
+      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2];
   size_t bytes;
 };
 
@@ -197,7 +198,7 @@ bool make_geom(int n, int hf1, int wf1, int hf2, int wf2, Geom* g) {
 // auto: 64 once the 32-token grid no longer fits the chip in one wave of
 // workgroups; oetr_set_encoder_tile overrides.  The heads keep TM.
 int encoder_tile_rows(const oetr_ctx* h, const Geom& g) {
-  if (!gm_half(h->mode)) return TM;
+  if (!gm_half(h->mode) || h->attn_full) return TM;
   const int want = h->enc_tile;
   if (want == TM || want == 64) return want;
   return g.ntiles > h->num_cus ? 64 : TM;
@@ -210,7 +211,7 @@ Geom encoder_geom(const Geom& g, int rows) {
   return e;
 }
 
-Workspace carve(const Geom& g, void* base) {
+Workspace carve(const Geom& g, void* base, bool attn_full = false) {
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -232,15 +233,19 @@ Workspace carve(const Geom& g, void* base) {
   w.cxy = take((size_t)2 * g.N * 2);
   w.tlbr = take((size_t)2 * g.N * 4);
   w.convp = take((size_t)9 * rows * C);  // P_tap = W_tap . memory (forward path)
+  for (int i = 0; i < 2; ++i) {           // attention == full: K rows and V^T, per layer parity
+    w.kbuf[i] = attn_full ? take(rows * C) : nullptr;
+    w.vt[i] = attn_full ? take((size_t)g.N * C * TM * (g.nt[0] + g.nt[1])) : nullptr;
+  }
   w.bytes = off;
   return w;
 }
 
-oetr_status check_ws(const Geom& g, void* ws, size_t ws_bytes, Workspace* out) {
+oetr_status check_ws(const Geom& g, void* ws, size_t ws_bytes, Workspace* out, bool attn_full = false) {
   if (!ws) return fail(OETR_ERR_WORKSPACE, "workspace is NULL");
   if (reinterpret_cast<uintptr_t>(ws) & 255)
     return fail(OETR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
-  *out = carve(g, ws);
+  *out = carve(g, ws, attn_full);
   if (out->bytes > ws_bytes)
     return fail(OETR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(out->bytes) +
                                         " bytes, got " + std::to_string(ws_bytes));
@@ -322,6 +327,10 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
 #endif
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
   p.flags = h->flags;
+  p.attn_full = h->attn_full;
+  for (int i = 0; i < 2; ++i) p.lpad[i] = g.nt[i] * TM;
+  p.vt_off[0] = 0; p.vt_off[1] = (size_t)g.N * C * p.lpad[0];
+  p.kbuf_out = w.kbuf[0]; p.vt_out = w.vt[0];
   p.a = h->enc[0];
   p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];
   TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, h->mode, s));
@@ -329,6 +338,7 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
     p.b = h->enc[l];
     p.b_cross = l & 1;
     p.kv_in = w.kvp[l & 1]; p.ks_in = w.ksp[l & 1];
+    p.kbuf_in = w.kbuf[l & 1]; p.vt_in = w.vt[l & 1];
     int tail;
     if (l + 1 == OETR_N_ENC) {
       tail = 1;
@@ -339,6 +349,7 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
       tail = 0;
       p.a = h->enc[l + 1];
       p.kv_out = w.kvp[(l + 1) & 1]; p.ks_out = w.ksp[(l + 1) & 1];
+      p.kbuf_out = w.kbuf[(l + 1) & 1]; p.vt_out = w.vt[(l + 1) & 1];
     } else {
       tail = 2;
     }
@@ -619,13 +630,12 @@ void oetr_destroy(oetr_handle h) {
 }
 
 size_t oetr_workspace_bytes(oetr_handle h, int n_pairs, int hf1, int wf1, int hf2, int wf2) {
-  (void)h;
   Geom g;
   if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g)) {
     g_err = "invalid shape: need N>0 and 1 <= hf*wf <= " + std::to_string(OETR_MAX_TOKENS);
     return 0;
   }
-  return carve(g, nullptr).bytes;
+  return carve(g, nullptr, h && h->attn_full).bytes;   // (h may be NULL: shape-only query, linear attention)
 }
 
 oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* feat2,
@@ -653,7 +663,7 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
   if (full && (img_h1 < hf1 || img_h2 < hf2 || img_w1 <= 0 || img_w2 <= 0))
     return fail(OETR_ERR_BAD_SHAPE, "image size smaller than the token grid");
   Workspace w;
-  oetr_status rc = check_ws(g, workspace, workspace_bytes, &w);
+  oetr_status rc = check_ws(g, workspace, workspace_bytes, &w, h->attn_full);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, enc_layers, s, /*with_decoder=*/false);
@@ -712,7 +722,7 @@ oetr_status oetr_feature_correlation(oetr_handle h, const float* feat1, const fl
   if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g))
     return fail(OETR_ERR_BAD_SHAPE, "invalid shape");
   Workspace w;
-  oetr_status rc = check_ws(g, workspace, workspace_bytes, &w);
+  oetr_status rc = check_ws(g, workspace, workspace_bytes, &w, h->attn_full);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if ((rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, OETR_N_ENC, s))) return rc;
@@ -1057,6 +1067,16 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows) {
   if (rows != 0 && rows != TM && rows != 64)
     return fail(OETR_ERR_BAD_ARG, "oetr_set_encoder_tile: rows must be 0 (auto), 32 or 64");
   h->enc_tile = rows;
+  return OETR_OK;
+}
+
+oetr_status oetr_set_attention(oetr_handle h, oetr_attention mode) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_attention: NULL handle");
+  if (mode != OETR_ATTENTION_LINEAR && mode != OETR_ATTENTION_FULL)
+    return fail(OETR_ERR_BAD_ARG, "oetr_set_attention: unknown mode");
+  if (mode == OETR_ATTENTION_FULL && !gm_f16_range(h->mode))
+    return fail(OETR_ERR_UNSUPPORTED, "attention 'full' is built for OETR_DTYPE_F32_SPLIT_F16 and OETR_DTYPE_F16");
+  h->attn_full = mode == OETR_ATTENTION_FULL;
   return OETR_OK;
 }
 

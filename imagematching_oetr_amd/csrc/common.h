@@ -973,6 +973,18 @@ struct EncLaunch {
   EncLayerDev b;         // layer being finished (phase B), if any
   EncLayerDev a;         // next layer (phase A), TAIL==0
   DecKVDev d;            // TAIL==1
+  // attention == full (reference EncoderLayer(attention='full'), transformer.py:86-89):
+  // phase A stores raw Q (in qp), K row-major and V transposed instead of phi(Q) and the
+  // per-tile KV states; phase B runs flash attention over the source image's tokens
+  int attn_full;
+  // (ping-pong by layer parity like the partial states: a fast tile already writes layer
+  //  l+1's K/V while a slow one still reads layer l's)
+  const float* kbuf_in;  // [rows][256] K projections (no phi) of the layer being finished
+  const float* vt_in;    // per image [256][lpad] V projections, token index minor
+  float* kbuf_out;       // ... of the next layer (phase A)
+  float* vt_out;
+  int lpad[2];           // tokens per image rounded up to TM, per side
+  size_t vt_off[2];      // first float of the side's images in vt
   int tile_rows;         // token rows per workgroup: 32 (TM) or 64 (split mode, k_encoder64);
                          // g.nt / g.tile0 / g.ntiles are in units of this tile
   int b_cross;           // phase-B layer is a cross layer

@@ -222,9 +222,100 @@ __device__ __forceinline__ void load_tile(float* S, const float* __restrict__ sr
   }
 }
 
-template <bool HAS_B, int TAIL, int MODE, int NW>
+// ---------------------------------------------------------------------------
+// attention == 'full' (reference FullAttention, src/models/linear_attention.py:53-87,
+// selected by EncoderLayer(attention='full'), transformer.py:86-89): softmax(Q K^T /
+// sqrt(D)) V over ALL tokens of the source image, for this tile's 32 queries and the
+// wave's head.  Flash style with the fp32-class f16 split (attention.hip has the
+// stand-alone version): S^T = K Q^T with Q as the B operand held in registers, the
+// online softmax lane-local (a lane owns one query column), O^T += V^T P^T with P taken
+// straight from the S^T accumulator registers.  K rows and V^T rows come from the
+// buffers phase A wrote; nothing L x S ever exists in memory.  Result -> message tile S1.
+template <int MODE>
+__device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, int ss, size_t row_base,
+                                                    int nvalid, int lane, int head,
+                                                    const ATile<MODE>& S1, Range& rg) {
+  const Geom& g = p.g;
+  const int half = lane >> 5, col = lane & 31;
+  const int S = g.L[ss];
+  const float* kb = p.kbuf_in + ((size_t)g.row0[ss] + (size_t)n * S) * C + head * HD + 8 * half;
+  const float* vr = p.vt_in + p.vt_off[ss] + ((size_t)n * C + head * HD + col) * p.lpad[ss] + 4 * half;
+  constexpr float NEG = -1.0e30f;   // finite "minus infinity": exp_neg(NEG - m) == 0, no NaN
+  const float temp = 0.17677669529663687f;   // 1 / sqrt(32)
+  f32x4 qh[2], ql[2];
+  {
+    const float* qp = p.qp + (row_base + min(col, nvalid - 1)) * C + head * HD + 8 * half;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      split8(*reinterpret_cast<const f32x4*>(qp + 16 * s), *reinterpret_cast<const f32x4*>(qp + 16 * s + 4),
+             qh[s], ql[s], rg);
+  }
+  auto load = [&](int k0, f32x4 (&kk)[4], f32x4 (&vv)[4]) {
+    const float* kr = kb + (size_t)min(k0 + col, S - 1) * C;   // rows past S: clamped, masked below
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      kk[2 * s] = *reinterpret_cast<const f32x4*>(kr + 16 * s);
+      kk[2 * s + 1] = *reinterpret_cast<const f32x4*>(kr + 16 * s + 4);
+      // k-slot 8*half + i of step s <-> key k0 + 16s + 8(i>>2) + 4*half + (i&3)
+      vv[2 * s] = *reinterpret_cast<const f32x4*>(vr + k0 + 16 * s);
+      vv[2 * s + 1] = *reinterpret_cast<const f32x4*>(vr + k0 + 16 * s + 8);
+    }
+  };
+  f32x16 o = {0};   // O^T: rows = d (crow(r, half)), col = query
+  float m_run = NEG, l_run = 0.f;
+  f32x4 kk[4], vv[4];
+  load(0, kk, vv);
+  for (int k0 = 0; k0 < S; k0 += 32) {
+    f32x4 kh[2], kl[2], vh[2], vl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      split8(kk[2 * s], kk[2 * s + 1], kh[s], kl[s], rg);
+      split8(vv[2 * s], vv[2 * s + 1], vh[s], vl[s], rg);
+    }
+    if (k0 + 32 < S) load(k0 + 32, kk, vv);   // next tile's rows under this tile's math
+    f32x16 st = {0}, cr = {0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) mma16_split3(kh[s], kl[s], qh[s], ql[s], st, cr);
+    float mt = NEG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sv = fmaf(cr[r], SPLIT_INV, st[r]);
+      st[r] = (k0 + crow(r, half) < S) ? sv * temp : NEG;
+      mt = fmaxf(mt, st[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = exp_neg(fminf(m_run - m_new, 0.f));
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = exp_neg(fminf(st[r] - m_new, 0.f)); ps += st[r]; }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    f32x16 oc = {0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 ph, pl;
+      split8(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]},
+             f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]}, ph, pl, rg);
+      mma16_split3(vh[s], vl[s], ph, pl, o, oc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = fmaf(oc[r], SPLIT_INV, o[r]);
+  }
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)   // registers 4*g4.. = d rows 8*g4 + 4*half + 0..3 of query `col`
+    S1.put4(col, head * HD + 8 * g4 + 4 * half,
+            f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv});
+}
+
+template <bool HAS_B, int TAIL, int MODE, int NW, bool FULL = false>
 __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   constexpr bool SPLIT = gm_half(MODE);  // GEMM operands live in 16-bit LDS planes
+  static_assert(!FULL || (gm_f16_range(MODE) && NW == 8), "full attention: f16-based modes, one head per wave");
   using Cfg = EncCfg<NW>;
   constexpr int NT = Cfg::NT, THREADS = Cfg::THREADS, WC = Cfg::WC, TPR = Cfg::TPR, F4 = Cfg::F4;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
@@ -290,7 +381,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     const int nts = ABL(p.dbg, ABL_KVREDUCE) ? 1 : g.nt[ss];
     const int src_slot0 = g.tile0[ss] + n * g.nt[ss];
 
-    if (!ABL(p.dbg, ABL_XLOAD)) load_tile<THREADS>(S0, p.qp + row_base * C, nvalid, tid);  // phi(Q) tile
+    if (!FULL && !ABL(p.dbg, ABL_XLOAD)) load_tile<THREADS>(S0, p.qp + row_base * C, nvalid, tid);  // phi(Q) tile
     // residual x in accumulator layout
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -299,6 +390,11 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
         const int row = min(crow(r, half), nvalid - 1);
         xacc[t][r] = ABL(p.dbg, ABL_XLOAD) ? 0.5f : p.x[(row_base + row) * C + wcol + 32 * t + col];
       }
+    if constexpr (FULL) {
+      full_attention_tile<MODE>(p, n, ss, row_base, nvalid, lane, wave, S1, rg);
+      ws.template prime<C, P_MERGE>(p.b.wmerge, p.b.wmerge_l, NT * wave, lane);
+      PHASE_STAMP(p, 1);
+    } else {
     // reduce the source image's partial KV states (fixed order -> deterministic);
     // the result is already in B-operand register order.  Several tiles are in
     // flight per round trip (32 float4 loads per lane).
@@ -399,6 +495,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
         for (int r = 0; r < 16; ++r) macc[t][r] = macc[t][r] * zr[t][r] * (float)S_len;
       S1.template put_acc<NT>(wcol, lane, macc);
     }
+    }  // !FULL
     __syncthreads();
     PHASE_STAMP(p, 2);
 
@@ -512,7 +609,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
           if (row < nvalid && !ABL(p.dbg, ABL_STORE))
-            p.qp[(row_base + row) * C + wcol + 32 * t + col] = ABL(p.dbg, ABL_ELU) ? acc[t][r] : elu1(acc[t][r]);
+            p.qp[(row_base + row) * C + wcol + 32 * t + col] = (FULL || ABL(p.dbg, ABL_ELU)) ? acc[t][r] : elu1(acc[t][r]);
         }
     }
     PHASE_STAMP(p, 8);
@@ -524,7 +621,20 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     ws.template gemm<C, P_T2, 0>(S2, p.a.wv, p.a.wv_l, NT * wave, lane, accV, nullptr, nullptr, 0,
                                  p.dbg);
     PHASE_STAMP(p, 9);
-    if (!ABL(p.dbg, ABL_KVSTATE))
+    if constexpr (FULL) {
+      // K row-major, V transposed ([channel][token], padded to whole tiles: every row of
+      // the tile is written - rows past the image end hold the duplicated last row, finite)
+      float* vt = p.vt_out + p.vt_off[side] + ((size_t)n * C + wcol + col) * p.lpad[side] + l0 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = crow(r, half);
+        if (row < nvalid) p.kbuf_out[(row_base + row) * C + wcol + col] = accK[0][r];
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<f32x4*>(vt + 8 * g4) =
+            f32x4{accV[0][4 * g4], accV[0][4 * g4 + 1], accV[0][4 * g4 + 2], accV[0][4 * g4 + 3]};
+    } else if (!ABL(p.dbg, ABL_KVSTATE))
     kv_state_store<MODE, NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.kv_out, p.ks_out, slot, rg);
     PHASE_STAMP(p, 10);
   } else if (TAIL == 1) {
@@ -1115,6 +1225,23 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
     }
   }
   constexpr int NW = gm_half(MODE) ? OETR_SPLIT_WAVES : OETR_F32_WAVES;
+  if (p.attn_full) {
+    if constexpr (gm_f16_range(MODE) && NW == 8) {
+#define OETR_LAUNCHF(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, NW, true>), grid, dim3(64 * NW), 0, s, p)
+      if (has_b) {
+        if (tail == 0) OETR_LAUNCHF(true, 0);
+        else if (tail == 1) OETR_LAUNCHF(true, 1);
+        else OETR_LAUNCHF(true, 2);
+      } else {
+        if (tail == 0) OETR_LAUNCHF(false, 0);
+        else return hipErrorInvalidValue;
+      }
+#undef OETR_LAUNCHF
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
 #define OETR_LAUNCH(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, NW>), grid, dim3(64 * NW), 0, s, p)
   if (has_b) {
     if (tail == 0) OETR_LAUNCH(true, 0);

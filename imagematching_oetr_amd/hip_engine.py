@@ -78,7 +78,7 @@ EXPORTS = (
     'oetr_neck_destroy', 'oetr_neck_workspace_bytes', 'oetr_neck_forward',
     'oetr_neck_set_trace', 'oetr_set_encoder_tile', 'oetr_query_flags',
     'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity',
-    'oetr_full_attention_split')
+    'oetr_full_attention_split', 'oetr_set_attention')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -182,6 +182,8 @@ def load_library(path=None):
                                        C.POINTER(i), C.POINTER(C.c_float)]
     lib.oetr_set_encoder_tile.restype = i
     lib.oetr_set_encoder_tile.argtypes = [vp, i]
+    lib.oetr_set_attention.restype = i
+    lib.oetr_set_attention.argtypes = [vp, i]
     lib.oetr_neck_create.restype = i
     lib.oetr_neck_create.argtypes = [C.POINTER(_NeckWeights), i, C.POINTER(vp)]
     lib.oetr_neck_destroy.restype = None
@@ -257,14 +259,21 @@ class HotPathEngine:
     #: precisions whose GEMM operands are f16 values (|x| < 65504, see query_flags)
     F16_RANGE = ('f32_split_f16', 'f16')
 
-    def __init__(self, weights, device=None, precision='f32_split_f16', enc_tile=None):
+    #: encoder attention cores (oetr_attention in the header)
+    ATTENTIONS = {'linear': 0, 'full': 1}
+
+    def __init__(self, weights, device=None, precision='f32_split_f16', enc_tile=None,
+                 attention='linear'):
         """``precision``: 'f32' = exact fp32 MFMA products; 'f32_split_f16' =
         fp32-class results from 3 f16 MFMAs per product (default; same parity
         tolerances, ~2x faster); 'f16' / 'bf16' = GEMM operands rounded to
         f16 / bf16, one MFMA per product, fp32 accumulate and fp32 everything
         else (BASELINE configs[4] / configs[2]; reduced parity margin).
         ``enc_tile``: token rows per encoder workgroup, None = auto, 32 or 64
-        (``oetr_set_encoder_tile``)."""
+        (``oetr_set_encoder_tile``).  ``attention``: 'linear' (what the reference
+        builds, ``src/model.py:82-84``) or 'full' = ``EncoderLayer(attention='full')``
+        (``transformer.py:86-89``): all-pairs softmax attention, f16-based precisions
+        only."""
         self.lib = load_library()
         if precision not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {sorted(self.PRECISIONS)}')
@@ -328,6 +337,12 @@ class HotPathEngine:
         self._ws = {}
         if enc_tile is not None:
             self.set_encoder_tile(enc_tile)
+        if attention not in self.ATTENTIONS:
+            raise ValueError(f'attention must be one of {sorted(self.ATTENTIONS)}')
+        self.attention = attention
+        if attention != 'linear':
+            _check(self.lib, self.lib.oetr_set_attention(self._h, self.ATTENTIONS[attention]),
+                   'oetr_set_attention')
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None

@@ -121,6 +121,9 @@ class OETR(nn.Module):
         #: GEMM arithmetic of the HIP hot path: 'f32_split_f16' (default, fp32-class),
         #: 'f32' (exact), 'f16' / 'bf16' (operands rounded, reduced parity margin)
         self.hip_precision = 'f32_split_f16'
+        #: encoder attention core: 'linear' (the reference's QueryTransformer default) or
+        #: 'full' (EncoderLayer(attention='full'), reference transformer.py:86-89)
+        self.hip_attention = 'linear'
         #: what forward_dummy does when an f16-based precision ('f32_split_f16', 'f16',
         #: and the HIP neck) reports an operand beyond the f16 range (|x| >= 65504):
         #: 'f32' = redo the batch with exact-fp32 MFMA (neck: the torch modules),
@@ -203,10 +206,10 @@ class OETR(nn.Module):
         weight tensor was replaced or written in place through autograd-visible
         ops (see :meth:`invalidate_engine` for the writes it cannot see)."""
         if self.hip_freeze_weights and self._engine is not None and \
-                self._engine_key[:2] == (self.hip_precision, self.hip_enc_tile):
+                self._engine_key[:3] == (self.hip_precision, self.hip_enc_tile, self.hip_attention):
             return self._engine
         params = [self.get_parameter(k) for k in hot_path_keys()]
-        key = (self.hip_precision, self.hip_enc_tile) + tuple(
+        key = (self.hip_precision, self.hip_enc_tile, self.hip_attention) + tuple(
             (p.data_ptr(), p._version) for p in params)
         if self._engine is None or key != self._engine_key:
             self._engine_f32 = None
@@ -217,7 +220,8 @@ class OETR(nn.Module):
                     f'weights are on {dev}. There is no CPU implementation.')
             self._engine = HotPathEngine(self.hot_path_state(), device=dev,
                                          precision=self.hip_precision,
-                                         enc_tile=self.hip_enc_tile)
+                                         enc_tile=self.hip_enc_tile,
+                                         attention=self.hip_attention)
             self._engine_key = key
         return self._engine
 
@@ -227,6 +231,9 @@ class OETR(nn.Module):
         main = self.engine()
         if self.hip_precision == 'f32':
             return main
+        if self.hip_attention != 'linear':
+            raise OetrRangeError("a GEMM operand reached |x| >= 65504 and attention='full' has no "
+                                 'exact-fp32 build to fall back to')
         if self._engine_f32 is None:
             self._engine_f32 = HotPathEngine(self.hot_path_state(), device=main.device,
                                              precision='f32')

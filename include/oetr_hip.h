@@ -167,6 +167,19 @@ oetr_status oetr_query_flags(oetr_handle h, void *stream, uint32_t *flags,
  * concurrent forward calls. */
 oetr_status oetr_set_encoder_tile(oetr_handle h, int rows);
 
+/* Attention core of the eight encoder layers.  The reference builds
+ * QueryTransformer(attention_mode='linear') (src/model.py:82-84; the config knob
+ * OETR.NECK.ATTENTION is never read), LINEAR is therefore the default; FULL is
+ * EncoderLayer(attention='full') (src/models/transformer.py:86-89): softmax(Q K^T /
+ * sqrt(D)) V over all tokens of the source image (FullAttention,
+ * src/models/linear_attention.py:53-87) - the all-pairs HW x HW correlation, computed
+ * flash style on the f16 matrix pipe (fp32-class operand split), never materialised.
+ * Same weights, same state dict.  FULL exists for the f16-based dtypes
+ * (F32_SPLIT_F16, F16), uses 32-token workgroups and a larger workspace (query
+ * oetr_workspace_bytes after the call).  Mutates the handle like the other setters. */
+typedef enum { OETR_ATTENTION_LINEAR = 0, OETR_ATTENTION_FULL = 1 } oetr_attention;
+oetr_status oetr_set_attention(oetr_handle h, oetr_attention mode);
+
 /* Bytes of workspace a forward call needs for this shape (256-B aligned
  * device buffer).  Returns 0 on invalid shape. */
 size_t oetr_workspace_bytes(oetr_handle h, int n_pairs, int hf1, int wf1,

@@ -126,10 +126,25 @@ HOT_CASES = [
 ]
 
 
+# attention='full' (EncoderLayer(attention='full'), transformer.py:86-89): same weights,
+# FullAttention instead of LinearAttention in all eight encoder layers
+FULL_ATTN_CASES = [
+    ('s1_20x20_sharp', 1, True, 11, 2, (20, 20), (20, 20), (640, 640), (640, 640)),
+    ('s4_15x20_25x10', 4, True, 14, 3, (15, 20), (25, 10), (480, 640), (800, 320)),
+    ('s6_9x7_33x40', 6, False, 16, 2, (9, 7), (33, 40), (288, 224), (1056, 1280)),
+]
+
+
 @torch.no_grad()
-def gen_hot(out_dir, model):
+def gen_hot(out_dir, model, cases=None, prefix='hot_', full_attention=False):
     from src.models.utils import box_tlbr_to_xyxy
-    for (tag, wseed, sharp, fseed, n, g1, g2, im1, im2) in HOT_CASES:
+    saved = None
+    if full_attention:
+        from src.models.linear_attention import FullAttention
+        saved = [layer.attention for layer in model.transformer.encoder]
+        for layer in model.transformer.encoder:
+            layer.attention = FullAttention()
+    for (tag, wseed, sharp, fseed, n, g1, g2, im1, im2) in (cases or HOT_CASES):
         w = orc.make_hot_weights(wseed, sharpen=sharp)
         missing, unexpected = model.load_state_dict(w, strict=False)
         assert not unexpected, unexpected
@@ -182,8 +197,11 @@ def gen_hot(out_dir, model):
                 data[f'enc{li}_x{side + 1}'] = arr
                 data[f'enc{li}_x{side + 1}_step'] = np.int64(st)
                 data[f'enc{li}_x{side + 1}_fp'] = fp(enc_out[li][side])
-        np.savez_compressed(out_dir / f'hot_{tag}.npz', **data)
-        print(f'hot_{tag}.npz  box1[0]={b1[0].tolist()}')
+        np.savez_compressed(out_dir / f'{prefix}{tag}.npz', **data)
+        print(f'{prefix}{tag}.npz  box1[0]={b1[0].tolist()}')
+    if saved is not None:
+        for layer, att in zip(model.transformer.encoder, saved):
+            layer.attention = att
 
 
 @torch.no_grad()
@@ -412,6 +430,8 @@ def main():
     install_stubs()
     if args.only == 'crop':
         return gen_crop(out_dir)
+    if args.only == 'fullattn':
+        return gen_hot(out_dir, build_reference_model(), FULL_ATTN_CASES, 'fullattn_', True)
     if args.only == 'train':
         return gen_train_forward(out_dir, build_reference_model())
     gen_misc(out_dir)
@@ -419,6 +439,7 @@ def main():
     gen_attention(out_dir)
     model = build_reference_model()
     gen_hot(out_dir, model)
+    gen_hot(out_dir, model, FULL_ATTN_CASES, 'fullattn_', True)
     gen_full(out_dir, model)
     gen_neck(out_dir, model)
     gen_train_forward(out_dir, model)

@@ -440,7 +440,7 @@ def cast_weights(w, dtype):
 
 @torch.no_grad()
 def hot_path(feat1, feat2, w, img_hw1, img_hw2, pos1=None, pos2=None,
-             return_stages=False):
+             return_stages=False, attention=None):
     """feat [N,256,hf,wf] -> (box1, box2) [N,4] xyxy pixels, following
     OETR.forward_dummy after feature_extraction (model.py:239-252)."""
     dtype = feat1.dtype
@@ -450,7 +450,8 @@ def hot_path(feat1, feat2, w, img_hw1, img_hw2, pos1=None, pos2=None,
         pos1 = position_table(hf1, wf1, dtype=dtype)
     if pos2 is None:
         pos2 = position_table(hf2, wf2, dtype=dtype)
-    hs1, hs2, m1, m2 = feature_correlation(feat1, feat2, pos1, pos2, w)
+    hs1, hs2, m1, m2 = feature_correlation(feat1, feat2, pos1, pos2, w,
+                                           attention=attention or linear_attention)
     lg1 = heatmap_logits(hs1, m1, hf1, wf1, w)
     lg2 = heatmap_logits(hs2, m2, hf2, wf2, w)
     c1 = soft_argmax(lg1, hf1, wf1, img_hw1[0])

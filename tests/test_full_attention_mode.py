@@ -1,0 +1,97 @@
+"""attention='full' as an encoder mode (reference
+``EncoderLayer(attention='full')``, ``src/models/transformer.py:86-89`` with
+``FullAttention``, ``src/models/linear_attention.py:53-87``): goldens
+``tests/golden/fullattn_*.npz`` come from the reference model with the attention module of
+all eight encoder layers swapped (``oracle/gen_golden.py``); the CPU test pins the oracle,
+the GPU test the HIP path (flash-style f16-split kernel fused into the encoder)."""
+import glob
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oetr_oracle as orc
+from tests.test_oracle_golden import load_hot_case
+
+torch.set_grad_enabled(False)
+CASES = sorted(glob.glob(str(Path(__file__).parent / 'golden' / 'fullattn_*.npz')))
+TOL = dict(memory=2e-4, hs=1e-4, logits=1e-3, cxy=5e-2, tlbr=1e-5, box=5e-2)
+
+
+def maxerr(a, b):
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    return float((a.reshape(b.shape) - b).abs().max())
+
+
+@pytest.mark.parametrize('path', CASES, ids=lambda p: p.split('fullattn_')[-1][:-4])
+def test_oracle_full_attention_matches_reference(path):
+    g, w, f1, f2 = load_hot_case(path)
+    im1, im2 = tuple(int(v) for v in g['img1']), tuple(int(v) for v in g['img2'])
+    ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True, attention=orc.full_attention)
+    for s in ('1', '2'):
+        step = int(g[f'memory{s}_step'])
+        assert maxerr(ref['memory' + s][:, ::step], g['memory' + s]) <= 5e-5
+        assert maxerr(ref['hs' + s], g['hs' + s]) <= 5e-5
+        assert maxerr(ref['cxy' + s], g['cxy' + s]) <= 1e-2
+        assert maxerr(ref['box' + s], g['box' + s]) <= 1e-2
+    # ... and it is a different function from the default linear attention
+    lin = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
+    assert maxerr(lin['memory1'], ref['memory1']) > 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['f32_split_f16', 'f16'])
+@pytest.mark.parametrize('path', CASES, ids=lambda p: p.split('fullattn_')[-1][:-4])
+def test_hip_full_attention_mode_vs_reference_golden(path, precision, gpu):
+    from imagematching_oetr_amd import HotPathEngine
+    g, w, f1, f2 = load_hot_case(path)
+    im1, im2 = tuple(int(v) for v in g['img1']), tuple(int(v) for v in g['img2'])
+    p1, p2 = orc.position_table(*g['grid1']), orc.position_table(*g['grid2'])
+    eng = HotPathEngine(w, device=gpu, precision=precision, attention='full')
+    dev = [t.to(gpu) for t in (f1, f2, p1, p2)]
+    out = eng.forward(*dev, im1, im2, stages=True)
+    assert eng.query_flags() == 0
+    if precision == 'f32_split_f16':          # fp32-class: the fp32 tolerances of the parity suite
+        for s in ('1', '2'):
+            step = int(g[f'memory{s}_step'])
+            assert maxerr(out['memory' + s][:, ::step], g['memory' + s]) <= TOL['memory']
+            for key in ('hs', 'logits', 'cxy', 'tlbr', 'box'):
+                assert maxerr(out[key + s], g[key + s]) <= TOL[key], (key, s)
+        for li in (0, 1):                     # encoder prefixes: self layer, cross layer
+            pre = eng.forward(*dev, im1, im2, stages=True, enc_layers=li + 1)
+            for s in ('1', '2'):
+                step = int(g[f'enc{li}_x{s}_step'])
+                assert maxerr(pre['memory' + s][:, ::step], g[f'enc{li}_x{s}']) <= TOL['memory'], (li, s)
+    else:                                     # single-pass f16 GEMMs: its own drift bounds
+        for s in ('1', '2'):
+            step = int(g[f'memory{s}_step'])
+            assert maxerr(out['memory' + s][:, ::step], g['memory' + s]) <= 2.5e-2
+    b1, b2 = eng.forward(*dev, im1, im2)
+    assert torch.equal(b1, out['box1']) and torch.equal(b2, out['box2'])      # repeatable, staged == plain
+    # batch slicing stays bit-exact (pairs independent)
+    c1, _ = eng.forward(dev[0][:1].contiguous(), dev[1][:1].contiguous(), dev[2], dev[3], im1, im2)
+    assert torch.equal(c1[0], b1[0])
+
+
+@pytest.mark.gpu
+def test_full_attention_mode_contract(gpu):
+    from imagematching_oetr_amd import HotPathEngine, OetrError
+    w = orc.make_hot_weights(0)
+    for prec in ('f32', 'bf16'):
+        with pytest.raises(OetrError, match='full'):
+            HotPathEngine(w, device=gpu, precision=prec, attention='full')
+    with pytest.raises(ValueError):
+        HotPathEngine(w, device=gpu, attention='sparse')
+    # single token per image, ragged tiles, 1600 keys
+    eng = HotPathEngine(w, device=gpu, attention='full')
+    for g1, g2 in (((1, 1), (1, 1)), ((1, 7), (33, 1)), ((5, 5), (40, 40))):
+        f1, f2 = orc.make_features(31, 2, *g1), orc.make_features(32, 2, *g2)
+        p1, p2 = orc.position_table(*g1), orc.position_table(*g2)
+        im1, im2 = (g1[0] * 32, g1[1] * 32), (g2[0] * 32, g2[1] * 32)
+        out = eng.forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p2.to(gpu), im1, im2, stages=True)
+        ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True, attention=orc.full_attention)
+        assert maxerr(out['memory1'], ref['memory1']) <= TOL['memory'], (g1, g2)
+        assert maxerr(out['memory2'], ref['memory2']) <= TOL['memory'], (g1, g2)
+        assert maxerr(out['box1'], ref['box1']) <= TOL['box']
