@@ -341,6 +341,9 @@ def main():
     n_total = n * world
     tokens = n * (hf * hf + hf2 * hf2)
     standard = (n, args.size, size2) == (8, 640, 640) and args.attention == 'linear'
+    L1, L2 = hf * hf, hf2 * hf2
+    # attention='full' adds QK^T and PV: 4*L*S*C per encoder call and image (self / cross average)
+    extra_flop = 0 if args.attention == 'linear' else 4 * 256 * n * (L1 * L1 + L2 * L2 + 2 * L1 * L2) // 2
 
     gatherer = BoxGatherer() if world > 1 else None
     n_streams = max(1, args.streams)
@@ -472,14 +475,14 @@ def main():
                      'ms_per_step_max': round(s_max / args.steps * 1e3, 4)}
     if 'trace_overlap_shape' in main_res:
         kern, t_s = main_res['trace_overlap_shape']
-        rb = roofline_block(kern, args.precision, tokens, tile_overlap or 32, args.steps, t_s, standard)
+        rb = roofline_block(kern, args.precision, tokens, tile_overlap or 32, args.steps, t_s, standard, extra_flop)
         if rb:
             out['roofline'] = rb
             out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
                                  for k, v in kern.items()}
     if 'trace_serial_shape' in main_res:
         kern, t_s = main_res['trace_serial_shape']
-        rb = roofline_block(kern, args.precision, tokens, args.enc_tile or 32, args.steps, t_s, standard)
+        rb = roofline_block(kern, args.precision, tokens, args.enc_tile or 32, args.steps, t_s, standard, extra_flop)
         if rb:
             out['serial']['roofline'] = rb
             out['serial']['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
