@@ -153,6 +153,8 @@ struct oetr_ctx {
 struct oetr_neck_ctx {
   oetr_trace* trace = nullptr;
   int device = 0;
+  int num_cus = 256;
+  int conv_rows = 0;     // 0 = auto (neck_conv_rows), else forced 256 / 192 / 128 (A/B timing)
   float* dev = nullptr;  // all repacked weights
   uint32_t* flags = nullptr;  // device status word (OETR_FLAG_*)
   const f32x4 *proj_wh[2], *proj_wl[2];
@@ -912,6 +914,7 @@ oetr_status oetr_neck_create(const oetr_neck_weights* w, int device, oetr_neck_h
 
   oetr_neck_ctx* h = new oetr_neck_ctx();
   h->device = device;
+  h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   int prev = 0;
   (void)hipGetDevice(&prev);
   hipError_t e = hipSetDevice(device);
@@ -984,7 +987,6 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
 
   NeckConvLaunch cp;
   cp.g = g; cp.xh = w.xh; cp.xl = w.xl;
-  const int mtiles = (g.M + NECK_MT - 1) / NECK_MT;
   int items = 0;
   const int order[3] = {2, 1, 0};  // k = 16 (16 slices), k = 8 (4), k = 4 (2 column halves)
   for (int oi = 0; oi < 3; ++oi) {
@@ -999,7 +1001,8 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
     items += cs.nsplit * cs.nhalf;
   }
   cp.items_per_mt = items;
-  cp.nblocks = items * mtiles;
+  cp.mt_rows = h->conv_rows > 0 ? h->conv_rows : neck_conv_rows(g.M, items, h->num_cus);
+  cp.nblocks = items * ((g.M + cp.mt_rows - 1) / cp.mt_rows);
   TRACED(h, s, K_NECK_CONV, launch_neck_conv(cp, s));
 
   NeckOutLaunch op;
@@ -1035,6 +1038,14 @@ oetr_status oetr_query_flags(oetr_handle h, void* stream, uint32_t* flags, int c
 oetr_status oetr_neck_query_flags(oetr_neck_handle h, void* stream, uint32_t* flags, int clear) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_query_flags: NULL handle");
   return query_flags(h->device, h->flags, stream, flags, clear);
+}
+
+oetr_status oetr_neck_set_conv_rows(oetr_neck_handle h, int rows) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_set_conv_rows: NULL handle");
+  if (rows != 0 && rows != 256 && rows != 192 && rows != 128)
+    return fail(OETR_ERR_BAD_ARG, "oetr_neck_set_conv_rows: rows must be 0 (auto), 256, 192 or 128");
+  h->conv_rows = rows;
+  return OETR_OK;
 }
 
 oetr_status oetr_neck_set_trace(oetr_neck_handle h, oetr_trace_handle t) {

@@ -1069,7 +1069,7 @@ hipError_t launch_boxes(const float* cxy, const float* tlbr, int n, int max_h, i
                         float* box, hipStream_t s);
 // ---- neck (input_proj -> PatchMerging -> input_proj2), neck.hip ----
 constexpr int BBC = 1024;        // backbone (ResNet layer3) channels
-constexpr int NECK_MT = 256;     // output positions per conv workgroup
+constexpr int NECK_MT = 256;     // output positions per conv workgroup (largest shape; 192 / 128 too)
 constexpr int NECK_PIX = 16;     // kernel pixels per conv workgroup (its K slice = 16 * 256)
 struct NeckGeom {
   int n_img, hb, wb, ho, wo;
@@ -1096,7 +1096,8 @@ struct NeckConvLaunch {
   const _Float16 *xh, *xl;
   NeckConvDesc conv[3];
   int items_per_mt;       // K slices x column halves of all three convs (22)
-  int nblocks;            // items_per_mt * number of 256-position tiles
+  int mt_rows;            // output positions per workgroup: 256, 192 or 128 (neck_conv_rows)
+  int nblocks;            // items_per_mt * number of mt_rows-position tiles
 };
 struct NeckOutLaunch {
   NeckGeom g;
@@ -1110,6 +1111,7 @@ struct NeckOutLaunch {
 };
 hipError_t launch_neck_proj(const NeckProjLaunch& p, hipStream_t s);
 hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s);
+int neck_conv_rows(int M, int items_per_mt, int num_cus);
 hipError_t launch_neck_out(const NeckOutLaunch& p, hipStream_t s);
 
 hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n,

@@ -124,7 +124,6 @@ hipError_t launch_neck_proj(const NeckProjLaunch& p, hipStream_t s) {
 // k_neck_conv
 // ---------------------------------------------------------------------------
 constexpr int NC_ROWB = 272;                   // staged row: hi 128 B | lo 128 B | pad 16 B
-constexpr int NC_BUF = NECK_MT * NC_ROWB;      // 69632 B per stage buffer
 constexpr int NC_STAGES = NECK_PIX * 4;        // 16 pixels x 4 channel quarters
 static_assert(NC_ROWB % 16 == 0 && (NC_ROWB / 4) % 64 == 4, "conflict-free b128 row stride");
 
@@ -136,21 +135,30 @@ struct ConvB { f32x4 h, l; };                  // one k16-step of B fragments (h
 #define NECK_ABL 0   // timing experiments only: 1 no A gathers, 2 no B loads, 4 no MFMA, 8 no LDS writes
 #endif
 
+// RTW = 32-row MFMA tiles per wave: a workgroup covers MT = 64 * RTW output positions
+// (two row halves of RTW tiles each) - 256, 192 or 128.  Fewer rows per workgroup mean
+// more, smaller work items (better balance over the 256 CUs when the item count is a
+// little over a multiple of it) at the price of re-streaming each weight slab more often;
+// launch_neck_conv picks the cheapest for the problem size.
+// (Capping the 128-row shape at 128 VGPRs so that two workgroups share a CU spills 72 B per
+//  lane and runs 1.5x slower: 781 vs 514 us - tools/neck_rows.py.)
+template <int RTW>
 __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * NC_BUF];
-  __shared__ int2 rowinfo[NECK_MT];
+  constexpr int MT = 64 * RTW, HALF_ROWS = 32 * RTW, BUF = MT * NC_ROWB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  __shared__ int2 rowinfo[MT];
   const NeckGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
-  const int nt = wave & 3, rh = wave >> 2;  // this wave: n-tile nt, rows [128*rh, 128*rh+128)
+  const int nt = wave & 3, rh = wave >> 2;  // this wave: n-tile nt, rows [HALF_ROWS*rh, +HALF_ROWS)
 
   // ---- which output tile / conv / K slice ----
   // Work items are ordered tile-major (all 22 slices of the three convs of one
-  // 256-position tile are adjacent) and each XCD takes a contiguous run of them:
+  // position tile are adjacent) and each XCD takes a contiguous run of them:
   // the gathered X rows of a tile (~1.6 MB) are then shared through ONE L2.
+  // (Slice-major - a weight slice stays in L2, the tiles' X rows stream - measured equal:
+  //  518.8 vs 525.6 us at 16 maps of 40x40; the kernel is not fabric-bound.)
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
 #if NECK_SLICE_MAJOR
-  // slice-major: the 25 position tiles of one weight slice (2.2 MB) are adjacent, so an
-  // XCD keeps the slice in its L2 while it streams the tiles' X rows
   const int mtiles = p.nblocks / p.items_per_mt;
   const int it = logical / mtiles, mt = logical - it * mtiles;
 #else
@@ -170,9 +178,9 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   const f32x4* xplane = reinterpret_cast<const f32x4*>(slot < 8 ? p.xh : p.xl) + (slot & 7);
   // per output row: {index of its window origin in X (may be negative), (iy0+64)<<16 | ix0+64}
   // kept in LDS - eight rows' worth of loop-invariant registers would not fit
-  if (tid < NECK_MT) {
+  if (tid < MT) {
     const int hw_o = g.ho * g.wo;
-    const int r = mt * NECK_MT + tid;
+    const int r = mt * MT + tid;
     const int rc = min(r, g.M - 1);
     const int img = rc / hw_o, q = rc - img * hw_o;
     const int oy = q / g.wo, ox = q - oy * g.wo;
@@ -187,27 +195,27 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
     const int row = ((info.x + ky * g.wb + kx) & m) | (g.rows_in & ~m);
     return (size_t)row * 32 + cq * 8;  // 16-byte units: 256 halves per row, 64 per quarter
   };
-  f32x4 sreg[4] = {};
-  auto stage_load = [&](int s, int jh) {  // rows j = 4*jh .. 4*jh+3 of stage s -> registers
+  f32x4 sreg[RTW] = {};
+  auto stage_load = [&](int s, int jh) {  // rows (tid>>4) + 32*(RTW*jh + j), j < RTW, of stage s -> registers
     const int pix = NECK_PIX * split + (s >> 2), cq = s & 3;
     const int ky = pix >> cd.log2ks, kx = pix & ksmask;
-    int2 info[4];
+    int2 info[RTW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) info[j] = rowinfo[(tid >> 4) + 128 * jh + 32 * j];
+    for (int j = 0; j < RTW; ++j) info[j] = rowinfo[(tid >> 4) + HALF_ROWS * jh + 32 * j];
     if (NECK_ABL & 1) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sreg[j] = xplane[src_unit(info[j], ky, kx, cq)];
+    for (int j = 0; j < RTW; ++j) sreg[j] = xplane[src_unit(info[j], ky, kx, cq)];
   };
   auto stage_write = [&](int buf, int jh) {
-    char* dst = smem + buf * NC_BUF + ((tid >> 4) + 128 * jh) * NC_ROWB + slot * 16;
+    char* dst = smem + buf * BUF + ((tid >> 4) + HALF_ROWS * jh) * NC_ROWB + slot * 16;
     if (NECK_ABL & 8) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + 32 * j * NC_ROWB) = sreg[j];
+    for (int j = 0; j < RTW; ++j) *reinterpret_cast<f32x4*>(dst + 32 * j * NC_ROWB) = sreg[j];
   };
 
-  f32x16 acc[4], cross[4];
+  f32x16 acc[RTW], cross[RTW];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { acc[t] = f32x16{0}; cross[t] = f32x16{0}; }
+  for (int t = 0; t < RTW; ++t) { acc[t] = f32x16{0}; cross[t] = f32x16{0}; }
   ConvB bf[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) { bf[kk].h = wh[kk * 64]; bf[kk].l = wl[kk * 64]; }
@@ -218,17 +226,17 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
 
   // Issue order inside a stage is pinned (sched_barrier): the compiler otherwise sinks
   // the run-ahead loads to their first use and the MFMAs wait a full L2 round trip.
-  //   G0 (rows 0-127 of stage s+1) | k16 step 0, B(s+1, 0) | step 1, B(s+1, 1) |
-  //   W0, G1 (rows 128-255) | step 2, B(s+1, 2) | step 3, B(s+1, 3) | W1 | barrier
-  const int a_lane_off = (128 * rh + col) * NC_ROWB + 16 * half;
+  //   G0 (first row half of stage s+1) | k16 step 0, B(s+1, 0) | step 1, B(s+1, 1) |
+  //   W0, G1 (second half) | step 2, B(s+1, 2) | step 3, B(s+1, 3) | W1 | barrier
+  const int a_lane_off = (HALF_ROWS * rh + col) * NC_ROWB + 16 * half;
   for (int s = 0; s < NC_STAGES; ++s) {
     const int cur = s & 1;
     const bool more = s + 1 < NC_STAGES;
-    const char* abase = smem + cur * NC_BUF + a_lane_off;
+    const char* abase = smem + cur * BUF + a_lane_off;
     if (more) stage_load(s + 1, 0);
-    f32x4 ah[4], al[4];
+    f32x4 ah[RTW], al[RTW];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < RTW; ++t) {
       ah[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB);
       al[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB + 128);
     }
@@ -237,23 +245,27 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
     for (int kk = 0; kk < 4; ++kk) {
       const f16x8 bh = __builtin_bit_cast(f16x8, bf[kk].h), bl = __builtin_bit_cast(f16x8, bf[kk].l);
 #pragma unroll
-      for (int tp = 0; tp < 4; tp += 2) {
+      for (int tp = 0; tp < RTW; tp += 2) {
+        constexpr bool dummy = false; (void)dummy;
+        const bool pair = tp + 1 < RTW;   // compile-time after unrolling
+        const int t1 = pair ? tp + 1 : tp;
         const f16x8 a0h = __builtin_bit_cast(f16x8, ah[tp]), a0l = __builtin_bit_cast(f16x8, al[tp]);
-        const f16x8 a1h = __builtin_bit_cast(f16x8, ah[tp + 1]), a1l = __builtin_bit_cast(f16x8, al[tp + 1]);
+        const f16x8 a1h = __builtin_bit_cast(f16x8, ah[t1]), a1l = __builtin_bit_cast(f16x8, al[t1]);
         if (NECK_ABL & 4) {
           acc[tp][0] += (float)a0h[0] + (float)a0l[0] + (float)bh[0] + (float)bl[0];
-          acc[tp + 1][0] += (float)a1h[0] + (float)a1l[0];
+          if (pair) acc[t1][0] += (float)a1h[0] + (float)a1l[0];
         } else {
-        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[tp], 0, 0, 0);
-        acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[tp + 1], 0, 0, 0);
-        cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[tp], 0, 0, 0);
-        cross[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[tp + 1], 0, 0, 0);
-        cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[tp], 0, 0, 0);
-        cross[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[tp + 1], 0, 0, 0);
+          // (dependent MFMAs on one accumulator are kept two apart where a pair exists)
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[tp], 0, 0, 0);
+          if (pair) acc[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[t1], 0, 0, 0);
+          cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[tp], 0, 0, 0);
+          if (pair) cross[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[t1], 0, 0, 0);
+          cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[tp], 0, 0, 0);
+          if (pair) cross[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[t1], 0, 0, 0);
         }
-        if (kk < 3) {  // this pair's fragments for the next k16 step
+        if (kk < 3) {  // these tiles' fragments for the next k16 step
 #pragma unroll
-          for (int t = tp; t < tp + 2; ++t) {
+          for (int t = tp; t <= t1; ++t) {
             ah[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB + (kk + 1) * 32);
             al[t] = *reinterpret_cast<const f32x4*>(abase + t * 32 * NC_ROWB + (kk + 1) * 32 + 128);
           }
@@ -278,16 +290,38 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   // ---- partial sums -> HBM ----
   float* out = cd.part + ((size_t)split * g.M) * cd.ncols + nh * 128 + nt * 32 + col;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < RTW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = mt * NECK_MT + 128 * rh + 32 * t + crow(r, half);
+      const int row = mt * MT + HALF_ROWS * rh + 32 * t + crow(r, half);
       if (row < g.M) out[(size_t)row * cd.ncols] = fmaf(cross[t][r], SPLIT_INV, acc[t][r]);
     }
 }
 
+// Rows per workgroup: minimise (rounds over the CUs) x (per-item cost ~ rows + a fixed
+// part for the 2 MB weight slab every item streams).  16 maps of 40x40 (6400 positions,
+// 22 items per tile): 256 rows -> 550 items = 3 rounds; 192 rows -> 748 items = 3 rounds
+// of 3/4 the work each.
+int neck_conv_rows(int M, int items_per_mt, int num_cus) {
+  int best = NECK_MT;
+  long best_cost = -1;
+  for (int rows : {256, 192, 128}) {
+    const long items = (long)items_per_mt * ((M + rows - 1) / rows);
+    const long rounds = (items + num_cus - 1) / num_cus;
+    const long cost = rounds * (rows + 32);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rows; }
+  }
+  return best;
+}
+
 hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_neck_conv, dim3(p.nblocks), dim3(512), 0, s, p);
+  const dim3 grid(p.nblocks), block(512);
+  switch (p.mt_rows) {
+    case 256: hipLaunchKernelGGL((k_neck_conv<4>), grid, block, 0, s, p); break;
+    case 192: hipLaunchKernelGGL((k_neck_conv<3>), grid, block, 0, s, p); break;
+    case 128: hipLaunchKernelGGL((k_neck_conv<2>), grid, block, 0, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -78,7 +78,7 @@ EXPORTS = (
     'oetr_neck_destroy', 'oetr_neck_workspace_bytes', 'oetr_neck_forward',
     'oetr_neck_set_trace', 'oetr_set_encoder_tile', 'oetr_query_flags',
     'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity',
-    'oetr_full_attention_split', 'oetr_set_attention')
+    'oetr_full_attention_split', 'oetr_set_attention', 'oetr_neck_set_conv_rows')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -194,6 +194,8 @@ def load_library(path=None):
     lib.oetr_neck_forward.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp]
     lib.oetr_neck_set_trace.restype = i
     lib.oetr_neck_set_trace.argtypes = [vp, vp]
+    lib.oetr_neck_set_conv_rows.restype = i
+    lib.oetr_neck_set_conv_rows.argtypes = [vp, i]
     for name in ('oetr_query_flags', 'oetr_neck_query_flags'):
         fn = getattr(lib, name)
         fn.restype = i
@@ -577,6 +579,11 @@ class NeckEngine:
                 self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
                 feat.data_ptr(), _stream(self.device)), 'oetr_neck_forward')
         return feat
+
+    def set_conv_rows(self, rows):
+        """Output positions per workgroup of the conv kernel: 0/None = auto, 256, 192, 128."""
+        _check(self.lib, self.lib.oetr_neck_set_conv_rows(self._h, int(rows or 0)),
+               'oetr_neck_set_conv_rows')
 
     def query_flags(self, clear=True):
         """Status word of the neck handle (see ``HotPathEngine.query_flags``)."""

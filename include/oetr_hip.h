@@ -299,6 +299,11 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float *backbone_feat,
                               int n_images, int hb, int wb, void *workspace,
                               size_t workspace_bytes, float *feat_out,
                               void *stream);
+/* Output positions per workgroup of the fused PatchMerging conv kernel: 0 = auto
+ * (default: the shape with the fewest workgroup rounds over the CUs for this problem
+ * size), or 256 / 192 / 128.  Results are identical in every shape (same summation
+ * order per output).  Mutates the handle. */
+oetr_status oetr_neck_set_conv_rows(oetr_neck_handle h, int rows);
 /* Status word of the neck handle (see oetr_query_flags): OETR_FLAG_F16_RANGE when a
  * backbone feature / intermediate reached the f16 range of its split GEMMs. */
 oetr_status oetr_neck_query_flags(oetr_neck_handle h, void *stream,

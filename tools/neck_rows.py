@@ -1,0 +1,30 @@
+"""k_neck_conv rows-per-workgroup A/B (256 / 192 / 128 / auto) on the bench shape."""
+import sys
+from pathlib import Path
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(REPO))
+import torch
+import imagematching_oetr_amd as pkg
+torch.set_grad_enabled(False)
+dev = torch.device('cuda', 0)
+torch.manual_seed(0)
+model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+for n, hb in ((16, 40), (64, 40), (16, 64), (2, 80)):
+    bb = torch.relu(torch.randn(n, 1024, hb, hb, device=dev))
+    eng = pkg.NeckEngine({k: v for k, v in model.state_dict().items() if k in pkg.neck_keys()}, device=dev)
+    ref = None
+    line = f'n={n} {hb}x{hb}:'
+    for rows in (256, 192, 128, 0, 256, 192, 128, 0):     # two passes: the first also warms clocks / caches
+        eng.set_conv_rows(rows)
+        for _ in range(3):
+            out = eng.forward(bb)
+        with pkg.KernelTrace(eng) as tr:
+            for _ in range(10):
+                eng.forward(bb)
+            torch.cuda.synchronize()
+        ks = {k: v[1] / v[0] * 1e3 for k, v in tr.summary().items()}
+        if ref is None:
+            ref = out.clone()
+        assert torch.equal(out, ref), 'rows-per-workgroup changed the result'
+        line += f'  rows={rows or "auto"}: conv {ks["k_neck_conv"]:.1f} us'
+    print(line, flush=True)

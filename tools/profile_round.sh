@@ -1,37 +1,56 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): bench line + rocprofv3 kernel stats + PMC passes.
-# usage: tools/profile_round.sh <tag>     outputs under gpurun_out/<tag>/
-TAG=${1:-r1}
+# Run on the GPU box (via gpurun): bench lines + rocprofv3 kernel stats + PMC passes.
+# usage: tools/profile_round.sh <tag>     outputs under gpurun_out/<tag>/ ; copy the
+# summaries you want judged into profiles/<tag>_*.
+TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
-timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-e2e --no-trace --streams 1 --steps 50 --warmup 5"
+# ---- bench lines (driver-style invocations) --------------------------------
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --precision bf16 --no-e2e > $OUT/bench_bf16.json 2>> $OUT/bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --precision f16 --size2 1280 --no-e2e > $OUT/bench_f16_mixed.json 2>> $OUT/bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --attention full --no-e2e --no-cpu-baseline > $OUT/bench_attention_full.json 2>> $OUT/bench.err
+OETR_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-e2e --no-exact-f32 2>> $OUT/bench.err | grep '^{' > $OUT/bench_gloo2.json
+for L in 1024 4096; do
+  timeout 200 python bench.py --kernel full_attention --L $L --steps 20 --warmup 3 --repeats 5 > $OUT/full_attention_L$L.json 2>> $OUT/bench.err
+done
+bash tools/extra_configs.sh $TAG > $OUT/extra_configs.log 2>&1
+mv $ROOT/gpurun_out/${TAG}_extra_configs.jsonl $OUT/extra_configs.jsonl 2>/dev/null
+# ---- rocprofv3: one process runs BOTH encoder shapes (3-stream pass with 64-token
+#      workgroups, then the serial pass with 32-token ones) --------------------------
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-e2e --no-trace --no-exact-f32 --steps 50 --warmup 5 --repeats 1"
+SERIAL32="$BENCH --streams 1"
+SERIAL64="$BENCH --streams 1 --enc-tile 64"
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-# PMC in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $SERIAL32 > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace64 -o trace -- $SERIAL64 > $OUT/trace64.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/overlap_trace -o trace -- $BENCH > $OUT/overlap_trace.log 2>&1
+# PMC in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass); default bench = both shapes
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o pmc -- $BENCH > $OUT/pmc_lds.log 2>&1
-# the default (value) mode of bench.py: batches overlapped on 3 streams, 64-row encoder tiles
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/overlap_trace -o trace -- python $ROOT/bench.py --no-cpu-baseline --no-e2e --no-trace --steps 50 --warmup 5 > $OUT/overlap_trace.log 2>&1
 # neck: 16 backbone maps of 40x40 through the HIP neck
 NECK="python $ROOT/tools/neck_bench.py 16 40"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/neck_trace -o trace -- $NECK > $OUT/neck_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/neck_pmc_fetch -o pmc -- $NECK > $OUT/neck_pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/neck_pmc_write -o pmc -- $NECK > $OUT/neck_pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/neck_pmc_lds -o pmc -- $NECK > $OUT/neck_pmc_lds.log 2>&1
+# stand-alone FullAttention kernels
+FA="python $ROOT/bench.py --kernel full_attention --L 1024 --steps 20 --warmup 3 --repeats 2"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/fa_trace -o trace -- $FA > $OUT/fa_trace.log 2>&1
 cd $ROOT
 # summarise on the box; the raw rocpd databases are too big to carry back
-for d in trace overlap_trace neck_trace; do
+for d in trace trace64 overlap_trace neck_trace fa_trace; do
   db=$(find $OUT/$d -name "*.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_summary.py $db $OUT/${d}_kernel_stats.csv > /dev/null
 done
 for d in pmc_fetch pmc_write pmc_sq pmc_lds neck_pmc_fetch neck_pmc_write neck_pmc_lds; do
   db=$(find $OUT/$d -name "*.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_pmc.py $db $OUT/$d.csv > /dev/null
 done
 find $OUT -name "*.db" -delete
-cat $OUT/bench.json
+find $OUT -type d -empty -delete
+head -c 600 $OUT/bench.json; echo
 ls $OUT
