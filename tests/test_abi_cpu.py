@@ -95,7 +95,7 @@ def test_product_path_has_no_cpu_fallback():
         model.forward_dummy(img, img)
     with pytest.raises(NotImplementedError):
         model.forward_dummy(img, img, mask1=torch.ones(1, 2, 2))
-    with pytest.raises(KeyError):          # training forward: needs the reference's data keys
+    with torch.no_grad(), pytest.raises(KeyError):   # training forward: needs the reference's data keys
         model({'image1': img})
     with pytest.raises(ValueError):
         cfg = pkg.get_cfg_defaults().OETR
