@@ -528,6 +528,16 @@ def main():
                 model.forward_dummy(im1, im2)
             torch.cuda.synchronize()
             out['end_to_end_pairs_per_s'] = round(n * reps / (time.perf_counter() - t1), 1)
+            # the same through the batched pair front-end: a stream of single
+            # pairs, bucketed by shape into batches of n
+            pair_list = [(im1[i:i + 1], im2[i:i + 1]) for i in range(n)] * 2
+            pkg.forward_pairs(model, pair_list, max_batch=n)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(5):
+                pkg.forward_pairs(model, pair_list, max_batch=n)
+            torch.cuda.synchronize()
+            out['end_to_end_forward_pairs_per_s'] = round(len(pair_list) * 5 / (time.perf_counter() - t2), 1)
             # front end of that forward: neck (HIP) per batch of 2N backbone maps
             bbf = model.backbone(torch.cat([im1, im2])) if args.size == size2 else model.backbone(im1)
             with pkg.KernelTrace(model.neck_engine()) as ntr:

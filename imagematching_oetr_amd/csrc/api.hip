@@ -774,11 +774,20 @@ oetr_status oetr_box_tlbr_to_xyxy(const float* cxy, const float* tlbr, int n, in
   return OETR_OK;
 }
 
+size_t oetr_linear_attention_workspace_bytes(int n) {
+  return n > 0 ? (size_t)n * NH * (HD * HD + HD) * sizeof(float) : 0;
+}
+
 oetr_status oetr_linear_attention(const float* q, const float* k, const float* v, int n, int L,
-                                  int S, float* out, void* stream) {
+                                  int S, float* out, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
   if (!q || !k || !v || !out || n <= 0 || L <= 0 || S <= 0)
     return fail(OETR_ERR_BAD_ARG, "oetr_linear_attention: bad argument");
-  HIP_TRY(launch_linear_attention(q, k, v, n, L, S, out, static_cast<hipStream_t>(stream)));
+  if (!workspace || workspace_bytes < oetr_linear_attention_workspace_bytes(n))
+    return fail(OETR_ERR_WORKSPACE, "oetr_linear_attention: workspace smaller than "
+                                    "oetr_linear_attention_workspace_bytes(n)");
+  HIP_TRY(launch_linear_attention(q, k, v, n, L, S, out, static_cast<float*>(workspace),
+                                  static_cast<hipStream_t>(stream)));
   return OETR_OK;
 }
 

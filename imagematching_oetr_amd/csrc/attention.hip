@@ -72,19 +72,12 @@ __global__ __launch_bounds__(256) void k_lin_apply(const float* __restrict__ q,
   }
 }
 
+// `state`: caller-provided n*8 states of 1056 floats between the two kernels
 hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n, int L,
-                                   int S, float* out, hipStream_t s) {
-  // The stand-alone test entry needs n*8 states of 1056 floats between its two kernels:
-  // a stream-ordered temporary (no global state, nothing outlives the call).
-  float* state = nullptr;
-  const size_t need = (size_t)n * NH * (HD * HD + HD);
-  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&state), need * sizeof(float), s);
-  if (e != hipSuccess) return e;
+                                   int S, float* out, float* state, hipStream_t s) {
   hipLaunchKernelGGL(k_lin_state, dim3(n * NH), dim3(256), 0, s, k, v, S, state);
   hipLaunchKernelGGL(k_lin_apply, dim3((L + 63) / 64, n * NH), dim3(256), 0, s, q, state, L, S, out);
-  e = hipGetLastError();
-  const hipError_t e2 = hipFreeAsync(state, s);
-  return e != hipSuccess ? e : e2;
+  return hipGetLastError();
 }
 
 // -------------------------------------------------------------------- full

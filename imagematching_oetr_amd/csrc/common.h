@@ -1115,7 +1115,7 @@ int neck_conv_rows(int M, int items_per_mt, int num_cus);
 hipError_t launch_neck_out(const NeckOutLaunch& p, hipStream_t s);
 
 hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n,
-                                   int L, int S, float* out, hipStream_t s);
+                                   int L, int S, float* out, float* state, hipStream_t s);
 hipError_t launch_full_attention(const float* q, const float* k, const float* v, int n,
                                  int L, int S, float* out, hipStream_t s);
 hipError_t launch_full_attention_split(const float* q, const float* k, const float* v, int n,

@@ -78,7 +78,8 @@ EXPORTS = (
     'oetr_neck_destroy', 'oetr_neck_workspace_bytes', 'oetr_neck_forward',
     'oetr_neck_set_trace', 'oetr_set_encoder_tile', 'oetr_query_flags',
     'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity',
-    'oetr_full_attention_split', 'oetr_set_attention', 'oetr_neck_set_conv_rows')
+    'oetr_full_attention_split', 'oetr_set_attention', 'oetr_neck_set_conv_rows',
+    'oetr_linear_attention_workspace_bytes')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -165,10 +166,12 @@ def load_library(path=None):
     lib.oetr_size_regression.argtypes = [vp, vp, vp, i, vp, vp, vp]
     lib.oetr_box_tlbr_to_xyxy.restype = i
     lib.oetr_box_tlbr_to_xyxy.argtypes = [vp, vp, i, i, i, vp, vp]
-    for name in ('oetr_linear_attention', 'oetr_full_attention'):
-        fn = getattr(lib, name)
-        fn.restype = i
-        fn.argtypes = [vp, vp, vp, i, i, i, vp, vp]
+    lib.oetr_full_attention.restype = i
+    lib.oetr_full_attention.argtypes = [vp, vp, vp, i, i, i, vp, vp]
+    lib.oetr_linear_attention.restype = i
+    lib.oetr_linear_attention.argtypes = [vp, vp, vp, i, i, i, vp, vp, sz, vp]
+    lib.oetr_linear_attention_workspace_bytes.restype = sz
+    lib.oetr_linear_attention_workspace_bytes.argtypes = [i]
     lib.oetr_full_attention_split.restype = i
     lib.oetr_full_attention_split.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
     lib.oetr_trace_create.restype = i
@@ -663,9 +666,13 @@ def _attention(fn_name, q, k, v):
             or v.shape != k.shape:
         raise ValueError('attention expects q [N,L,8,32], k,v [N,S,8,32]')
     out = torch.empty_like(q)
+    extra = ()
+    if fn_name == 'oetr_linear_attention':
+        ws = torch.empty(lib.oetr_linear_attention_workspace_bytes(n), dtype=torch.uint8, device=q.device)
+        extra = (ws.data_ptr(), ws.numel())
     with torch.cuda.device(q.device):
         _check(lib, getattr(lib, fn_name)(
-            q.data_ptr(), k.data_ptr(), v.data_ptr(), n, L, S, out.data_ptr(),
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), n, L, S, out.data_ptr(), *extra,
             _stream(q.device)), fn_name)
     return out
 

@@ -247,12 +247,14 @@ oetr_status oetr_box_tlbr_to_xyxy(const float *cxy, const float *tlbr, int n,
 /* Replaces: LinearAttention.forward (reference
  * src/models/linear_attention.py:22-50), masks None.  Stand-alone entry for
  * parity tests of the attention core.  q [N][L][8][32], k,v [N][S][8][32],
- * out [N][L][8][32].  (Unlike the forward entry points this test entry takes
- * no workspace: it uses a stream-ordered temporary, hipMallocAsync/hipFreeAsync
- * on `stream`, for its n*8 states.) */
+ * out [N][L][8][32].  `workspace`: device buffer of
+ * oetr_linear_attention_workspace_bytes(n) bytes (the n*8 KV states between the
+ * entry's two launches); like every other call: no allocation, enqueue-only. */
+size_t oetr_linear_attention_workspace_bytes(int n);
 oetr_status oetr_linear_attention(const float *q, const float *k,
                                   const float *v, int n, int L, int S,
-                                  float *out, void *stream);
+                                  float *out, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 
 /* Replaces: FullAttention.forward (reference
  * src/models/linear_attention.py:53-87), no mask/dropout - the optional
