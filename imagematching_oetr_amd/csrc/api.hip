@@ -160,6 +160,8 @@ struct oetr_neck_ctx {
   const f32x4 *proj_wh[2], *proj_wl[2];
   const float *proj_b, *ln_w, *ln_b;
   const f32x4 *conv_wh[3], *conv_wl[3];
+  const f32x4 *conv_wh_rw[3], *conv_wl_rw[3];   // k_neck_conv_rw's step order
+  int conv_kernel = 0;   // 0 = auto (row-window when wo >= NECK_RW_MIN_WO), 1 = gather, 2 = row-window
   const float* conv_b[3];
   const f32x4 *out_wh, *out_wl;
   const float* out_b;
@@ -841,6 +843,36 @@ void pack_conv(Packer& pk, const float* W, const NeckConvShape& cs, size_t* hi_o
             }
 }
 
+// The same slabs in k_neck_conv_rw's k16-step order: stage (ky in slice, x parity,
+// 32-channel chunk), then tap (kx = 2*tap + parity), then the two 16-channel steps.
+void pack_conv_rw(Packer& pk, const float* W, const NeckConvShape& cs, size_t* hi_off, size_t* lo_off) {
+  const int ks2 = cs.ks * cs.ks, steps = NECK_PIX * C / 16;
+  const int taps = cs.ks / 2, ksteps = 2 * taps, nky = NECK_PIX / cs.ks;
+  const size_t plane_floats = (size_t)cs.cout * C * ks2 / 2;
+  *hi_off = pk.reserve_aligned(plane_floats);
+  *lo_off = pk.reserve_aligned(plane_floats);
+  _Float16* hi = reinterpret_cast<_Float16*>(pk.buf.data() + *hi_off);
+  _Float16* lo = reinterpret_cast<_Float16*>(pk.buf.data() + *lo_off);
+  for (int sp = 0; sp < cs.nsplit; ++sp)
+    for (int nh = 0; nh < cs.nhalf; ++nh)
+      for (int nt = 0; nt < 4; ++nt)
+        for (int st = 0; st < steps; ++st) {
+          const int stage = st / ksteps, kk = st % ksteps;
+          const int ky = sp * nky + (stage >> 4), par = (stage >> 3) & 1, cq = stage & 7;
+          const int kx = 2 * (kk >> 1) + par, c0 = 32 * cq + 16 * (kk & 1);
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int n = nh * 128 + nt * 32 + (lane & 31);
+              const int c = c0 + 8 * (lane >> 5) + j;
+              const float w = W[((size_t)n * C + c) * ks2 + ky * cs.ks + kx];
+              const _Float16 h = (_Float16)w;
+              const size_t idx = (((((size_t)sp * cs.nhalf + nh) * 4 + nt) * steps + st) * 64 + lane) * 8 + j;
+              hi[idx] = h;
+              lo[idx] = (_Float16)((w - (float)h) * SPLIT_SCALE);
+            }
+        }
+}
+
 bool make_neck_geom(int n_img, int hb, int wb, NeckGeom* g) {
   if (n_img <= 0 || hb < 2 || wb < 2 || hb > 400 || wb > 400) return false;
   const long lo = (long)(hb / 2) * (wb / 2);
@@ -910,12 +942,13 @@ oetr_status oetr_neck_create(const oetr_neck_weights* w, int device, oetr_neck_h
   CHECK_W("input_proj2.weight", w->input_proj2_w, (size_t)C * 2 * C, true);
   CHECK_W("input_proj2.bias", w->input_proj2_b, C, false);
   Packer pk;
-  size_t pwh[2], pwl[2], cwh[3], cwl[3], cb[3], owh, owl;
+  size_t pwh[2], pwl[2], cwh[3], cwl[3], rwh[3], rwl[3], cb[3], owh, owl;
   for (int kh = 0; kh < 2; ++kh)  // input_proj, K halves [256][512] of the [256][1024] matrix
     pk.frag_h(GM_SPLIT, w->input_proj_w + kh * 512, C, 512, &pwh[kh], &pwl[kh], BBC);
   const size_t pb = pk.copy(w->input_proj_b, C), lw = pk.copy(w->norm_w, C), lb = pk.copy(w->norm_b, C);
   for (int i = 0; i < 3; ++i) {
     pack_conv(pk, w->reduction_w[i], kNeckConv[i], &cwh[i], &cwl[i]);
+    pack_conv_rw(pk, w->reduction_w[i], kNeckConv[i], &rwh[i], &rwl[i]);
     cb[i] = pk.copy(w->reduction_b[i], kNeckConv[i].cout);
   }
   pk.frag_h(GM_SPLIT, w->input_proj2_w, C, 2 * C, &owh, &owl);
@@ -942,7 +975,10 @@ oetr_status oetr_neck_create(const oetr_neck_weights* w, int device, oetr_neck_h
   auto F4 = [&](size_t off) { return reinterpret_cast<const f32x4*>(B + off); };
   for (int kh = 0; kh < 2; ++kh) { h->proj_wh[kh] = F4(pwh[kh]); h->proj_wl[kh] = F4(pwl[kh]); }
   h->proj_b = B + pb; h->ln_w = B + lw; h->ln_b = B + lb;
-  for (int i = 0; i < 3; ++i) { h->conv_wh[i] = F4(cwh[i]); h->conv_wl[i] = F4(cwl[i]); h->conv_b[i] = B + cb[i]; }
+  for (int i = 0; i < 3; ++i) {
+    h->conv_wh[i] = F4(cwh[i]); h->conv_wl[i] = F4(cwl[i]); h->conv_b[i] = B + cb[i];
+    h->conv_wh_rw[i] = F4(rwh[i]); h->conv_wl_rw[i] = F4(rwl[i]);
+  }
   h->out_wh = F4(owh); h->out_wl = F4(owl); h->out_b = B + ob;
   *out = h;
   return OETR_OK;
@@ -1003,6 +1039,7 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
     NeckConvDesc& d = cp.conv[oi];
     const NeckConvShape& cs = kNeckConv[i];
     d.wh = h->conv_wh[i]; d.wl = h->conv_wl[i];
+    d.wh_rw = h->conv_wh_rw[i]; d.wl_rw = h->conv_wl_rw[i];
     d.part = w.part[i];
     d.log2ks = cs.log2ks; d.pad = (cs.ks - 2) / 2;
     d.nsplit = cs.nsplit; d.nhalf = cs.nhalf; d.ncols = cs.cout;
@@ -1010,7 +1047,13 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
     items += cs.nsplit * cs.nhalf;
   }
   cp.items_per_mt = items;
-  cp.mt_rows = h->conv_rows > 0 ? h->conv_rows : neck_conv_rows(g.M, items, h->num_cus);
+  cp.row_window = h->conv_kernel == 0 ? g.wo >= NECK_RW_MIN_WO : h->conv_kernel == 2;
+  if (cp.row_window)   // no 256-row shape (it spills); 192 rows measured best at every size tried
+    cp.mt_rows = h->conv_rows > 0 ? min(h->conv_rows, 192) : (g.M > 128 ? 192 : 128);
+  else
+    cp.mt_rows = h->conv_rows > 0 ? h->conv_rows : neck_conv_rows(g.M, items, h->num_cus, 256);
+  if (cp.row_window && g.wo < NECK_RW_MIN_WO)
+    return fail(OETR_ERR_BAD_SHAPE, "oetr_neck_forward: the row-window conv kernel needs an output map >= 16 wide");
   cp.nblocks = items * ((g.M + cp.mt_rows - 1) / cp.mt_rows);
   TRACED(h, s, K_NECK_CONV, launch_neck_conv(cp, s));
 
@@ -1047,6 +1090,14 @@ oetr_status oetr_query_flags(oetr_handle h, void* stream, uint32_t* flags, int c
 oetr_status oetr_neck_query_flags(oetr_neck_handle h, void* stream, uint32_t* flags, int clear) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_query_flags: NULL handle");
   return query_flags(h->device, h->flags, stream, flags, clear);
+}
+
+oetr_status oetr_neck_set_conv_kernel(oetr_neck_handle h, int kind) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_set_conv_kernel: NULL handle");
+  if (kind < 0 || kind > 2)
+    return fail(OETR_ERR_BAD_ARG, "oetr_neck_set_conv_kernel: kind must be 0 (auto), 1 (gather) or 2 (row window)");
+  h->conv_kernel = kind;
+  return OETR_OK;
 }
 
 oetr_status oetr_neck_set_conv_rows(oetr_neck_handle h, int rows) {

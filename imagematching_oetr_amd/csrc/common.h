@@ -1071,6 +1071,7 @@ hipError_t launch_boxes(const float* cxy, const float* tlbr, int n, int max_h, i
 constexpr int BBC = 1024;        // backbone (ResNet layer3) channels
 constexpr int NECK_MT = 256;     // output positions per conv workgroup (largest shape; 192 / 128 too)
 constexpr int NECK_PIX = 16;     // kernel pixels per conv workgroup (its K slice = 16 * 256)
+constexpr int NECK_RW_MIN_WO = 16;  // narrowest output map the row-window conv kernel takes
 struct NeckGeom {
   int n_img, hb, wb, ho, wo;
   int HW;        // hb * wb
@@ -1087,6 +1088,7 @@ struct NeckProjLaunch {
 };
 struct NeckConvDesc {
   const f32x4 *wh, *wl;   // [split][nhalf][4 n-tiles][256 k16-steps][64 lanes] 16-byte units
+  const f32x4 *wh_rw, *wl_rw;   // the same values in k_neck_conv_rw's step order
   float* part;            // [nsplit][M][ncols] partial sums
   int log2ks, pad, nsplit, nhalf, ncols;
   int item0;              // first work item of this conv within a tile's items
@@ -1097,6 +1099,7 @@ struct NeckConvLaunch {
   NeckConvDesc conv[3];
   int items_per_mt;       // K slices x column halves of all three convs (22)
   int mt_rows;            // output positions per workgroup: 256, 192 or 128 (neck_conv_rows)
+  int row_window;         // 1: k_neck_conv_rw (wo >= NECK_RW_MIN_WO), 0: k_neck_conv
   int nblocks;            // items_per_mt * number of mt_rows-position tiles
 };
 struct NeckOutLaunch {
@@ -1111,7 +1114,7 @@ struct NeckOutLaunch {
 };
 hipError_t launch_neck_proj(const NeckProjLaunch& p, hipStream_t s);
 hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s);
-int neck_conv_rows(int M, int items_per_mt, int num_cus);
+int neck_conv_rows(int M, int items_per_mt, int num_cus, int max_rows);
 hipError_t launch_neck_out(const NeckOutLaunch& p, hipStream_t s);
 
 hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n,

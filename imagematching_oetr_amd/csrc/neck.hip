@@ -25,6 +25,7 @@
 //   k_neck_out   32 positions per workgroup: fixed-order sum of the partials +
 //                biases -> the 512-channel concat as split planes in LDS, 1x1
 //                conv 512 -> 256, transposed store to NCHW.
+#include <type_traits>
 #include "common.h"
 
 namespace oetr {
@@ -131,8 +132,15 @@ struct ConvB { f32x4 h, l; };                  // one k16-step of B fragments (h
 #ifndef NECK_SLICE_MAJOR
 #define NECK_SLICE_MAJOR 0   // work-item order: 0 = tile-major (X rows of a tile share an L2), 1 = slice-major
 #endif
+#ifndef NECK_RW_SLICE_MAJOR
+#define NECK_RW_SLICE_MAJOR 0   // the row-window kernel's work-item order (see k_neck_conv_rw)
+#endif
+#ifndef NECK_SPREAD
+#define NECK_SPREAD 0   // 1: issue the next stage's gather passes between the k16 steps (measured slower: 460 vs 441 us)
+#endif
 #ifndef NECK_ABL
-#define NECK_ABL 0   // timing experiments only: 1 no A gathers, 2 no B loads, 4 no MFMA, 8 no LDS writes
+#define NECK_ABL 0   // timing experiments only: 1 no A gathers, 2 no B loads, 4 no MFMA, 8 no LDS writes,
+                     // (row-window kernel) 16 no A re-reads from LDS, 32 no stage barrier
 #endif
 
 // RTW = 32-row MFMA tiles per wave: a workgroup covers MT = 64 * RTW output positions
@@ -298,14 +306,225 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_neck_conv_rw : the same three convs with ROW-WINDOW staging
+// ---------------------------------------------------------------------------
+// k_neck_conv gathers, for every kernel pixel (ky, kx), one input pixel per output
+// position: the stride-2 windows of neighbouring positions overlap ks/2-fold along x, so
+// every input pixel of a row is fetched ks/2 times per ky.  Here a stage is
+// (ky, x parity, 32-channel chunk): the pixels ix = 2*(ox + c) - pad + parity of the
+// touched output rows are staged ONCE as "entries" (row r, column c), and the ks/2 taps
+// kx = 2*tau + parity read entry c = ox + tau - i.e. the A operand of tap tau is the same
+// LDS tile shifted by tau entries.  Gathered bytes per k16 step drop ks/2-fold
+// (8x / 4x / 2x for the 16 / 8 / 4 kernels; the tile grows by (ks/2 - 1) entries per row).
+// Work items, partial-sum slabs and the weight VALUES are those of k_neck_conv; only the
+// order of the k16 steps inside a slice differs (pack_conv_rw in api.hip).
+// Needs wo >= 16 (narrower maps touch too many rows per tile for the LDS / register budget).
+constexpr int RW_ENT = 144;   // staged entry: 32 channels hi 64 B | lo 64 B | pad 16 B
+static_assert(RW_ENT % 16 == 0 && (RW_ENT / 4) % 32 == 4, "conflict-free b128 entry stride");
+template <int RTW> struct RwShape {
+  static constexpr int MT = 64 * RTW;
+  static constexpr int NE_MAX = MT + 7 * (MT / NECK_RW_MIN_WO + 2);   // 8 taps, wo >= NECK_RW_MIN_WO
+  static constexpr int NPASS = (NE_MAX + 63) / 64;                    // 64 entries per staging pass
+  static constexpr int BUF = NE_MAX * RW_ENT;
+};
+
+// One body for the three kernel sizes: taps / rows-per-slice are run-time values and
+// the k16 steps of a stage run as ks/4 groups of four (the depth of the weight ring).
+template <int RTW>
+__global__ __launch_bounds__(512) void k_neck_conv_rw(NeckConvLaunch p) {
+  constexpr int MT = 64 * RTW, HALF_ROWS = 32 * RTW, NPASS = RwShape<RTW>::NPASS, BUF = RwShape<RTW>::BUF;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  __shared__ int2 ent[RwShape<RTW>::NE_MAX];
+  const NeckGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int nt = wave & 3, rh = wave >> 2;
+
+  const int logical = xcd_remap(blockIdx.x, p.nblocks);
+#if NECK_RW_SLICE_MAJOR
+  const int mtiles = p.nblocks / p.items_per_mt;
+  const int it = logical / mtiles, mt = logical - it * mtiles;
+#else
+  const int mt = logical / p.items_per_mt, it = logical - mt * p.items_per_mt;
+#endif
+  const int ci = it >= p.conv[2].item0 ? 2 : (it >= p.conv[1].item0 ? 1 : 0);
+  const NeckConvDesc& cd = p.conv[ci];
+  const int rem = it - cd.item0;
+  const int split = rem / cd.nhalf, nh = rem - split * cd.nhalf;
+  const int taps = 1 << (cd.log2ks - 1);       // 2 / 4 / 8
+  const int nky = NECK_PIX >> cd.log2ks;       // kernel rows in a 16-pixel slice: 4 / 2 / 1
+  const int groups = taps >> 1;                // 4-step groups per stage: 1 / 2 / 4
+  const int nstg = nky * 16;                   // stages: (ky in slice, x parity, 32-channel chunk)
+  const size_t wbase = ((size_t)(split * cd.nhalf + nh) * 4 + nt) * (NC_STAGES * 4) * 64 + lane;
+  const f32x4* wh = cd.wh_rw + wbase;
+  const f32x4* wl = cd.wl_rw + wbase;
+
+  // ---- entry geometry of this tile: positions [p0, plast] cover output rows row0 .. ----
+  const int p0 = mt * MT, plast = min(p0 + MT, g.M) - 1;
+  const int row0 = p0 / g.wo, ox_p0 = p0 - row0 * g.wo;
+  const int per_row = g.wo + taps - 1, n0 = g.wo - ox_p0 + taps - 1;   // entries of row 0 / of a full row
+  const int nrows = plast / g.wo - row0 + 1;
+  const int ox_plast = plast - (plast / g.wo) * g.wo;
+  // row 0 from ox_p0, full middle rows, the last row only up to the tile's last position
+  const int NE = nrows == 1 ? ox_plast - ox_p0 + taps : n0 + (nrows - 2) * per_row + ox_plast + taps;
+  for (int e = tid; e < NE; e += 512) {
+    int r = 0, c = e;
+    if (e >= n0) { r = 1 + (e - n0) / per_row; c = (e - n0) - (r - 1) * per_row; }
+    const int grow = row0 + r;                      // output row over all images (< n_img * ho)
+    const int img = grow / g.ho, oy = grow - img * g.ho;
+    const int ox = (r == 0 ? ox_p0 : 0) + c;        // may run taps-1 past the row: bounds-checked below
+    const int iy0 = 2 * oy - cd.pad, ix0 = 2 * ox - cd.pad;
+    ent[e] = make_int2(img * g.HW + iy0 * g.wb + ix0, ((iy0 + 64) << 16) | (ix0 + 64));
+  }
+  int aoff[RTW];   // byte offset of this lane's tap-0 entry (+ its k half) per row tile
+#pragma unroll
+  for (int t = 0; t < RTW; ++t) {
+    const int pos = min(p0 + HALF_ROWS * rh + 32 * t + col, plast);
+    const int grow = pos / g.wo, ox = pos - grow * g.wo, r = grow - row0;
+    const int e0 = r == 0 ? ox - ox_p0 : n0 + (r - 1) * per_row + ox;
+    aoff[t] = e0 * RW_ENT + 16 * half;
+  }
+  __syncthreads();
+
+  // ---- staging role: 8 lanes per entry (4 x 16 B of X_hi, 4 of X_lo) ----
+  const int piece = tid & 7, eslot = tid >> 3;
+  // (the per-lane plane select is an offset from X_hi, not a select between the two
+  //  pointers: hipcc fetches a selected kernel argument with a per-lane global load, and
+  //  that pending load haunts the stage loop's wait counts)
+  const char* xh_bytes = reinterpret_cast<const char*>(p.xh);
+  const long plane_delta = reinterpret_cast<const char*>(p.xl) - xh_bytes;
+  const char* xplane = xh_bytes + (piece < 4 ? 0L : plane_delta) + (piece & 3) * 16;
+  f32x4 sreg[NPASS] = {};
+  // Gather addresses depend on (ky, x parity) only - the eight 32-channel chunks of one
+  // (ky, parity) are 64 B apart - so they are worked out once per eight stages.
+  unsigned src[NPASS];                              // byte offsets of the gathered rows in a plane
+  auto stage_addr = [&](int s) {
+    const int ky = split * nky + (s >> 4), par = (s >> 3) & 1;
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int2 info = ent[min(q * 64 + eslot, NE - 1)];
+      const int iy = (info.y >> 16) - 64 + ky, ix = (info.y & 0xffff) - 64 + par;
+      const bool ok = (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
+      const int m = -(int)ok;
+      const int row = ((info.x + ky * g.wb + par) & m) | (g.rows_in & ~m);
+      src[q] = (unsigned)row * 512u;                // rows_in * 512 < 2^31 (make_neck_geom)
+    }
+  };
+  // (every load in the main loop is unconditional - indices clamped instead: a load behind
+  //  a branch makes the wait counts at the join pessimistic, vmcnt(0) in effect)
+  auto stage_load = [&](int s) {                    // prologue only: every pass at once
+    stage_addr(s);
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) sreg[q] = *reinterpret_cast<const f32x4*>(xplane + src[q] + (s & 7) * 64);
+  };
+  // (unconditional stores too: lanes past the last entry hold its data - the clamped table
+  //  read above - and rewrite it; a store under a lane mask is a branch to the wait counter)
+  auto stage_write = [&](int buf) {
+    char* dst = smem + buf * BUF + piece * 16;
+    if (NECK_ABL & 8) return;
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q)
+      *reinterpret_cast<f32x4*>(dst + min(q * 64 + eslot, NE - 1) * RW_ENT) = sreg[q];
+  };
+
+  f32x16 acc[RTW], cross[RTW];
+#pragma unroll
+  for (int t = 0; t < RTW; ++t) { acc[t] = f32x16{0}; cross[t] = f32x16{0}; }
+  ConvB bf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { bf[kk].h = wh[kk * 64]; bf[kk].l = wl[kk * 64]; }
+
+  stage_load(0); stage_write(0);
+  __syncthreads();
+
+  // The stage loop exists once per kernel size (GR = k16 steps per stage / 4), chosen by a
+  // workgroup-uniform switch: with the step count a run-time value the three paths share
+  // their joins, and hipcc's wait-count merge then drains the whole weight ring before
+  // every staging store (vmcnt(0) at each stage end - a third of the kernel's time).
+  auto stages = [&](auto gr_tag) {
+    constexpr int GR = decltype(gr_tag)::value, KSTEPS = 4 * GR;
+    int gstep = 4;                                  // next k16 step to fetch into the ring
+    for (int s = 0; s < nstg; ++s) {
+      const int cur = s & 1;
+      const char* abase = smem + cur * BUF;
+      // the next stage's gathers go out after the first k16 step (NECK_SPREAD: one pass at
+      // a time between the steps instead - slower); the last stage re-stages itself: unused
+      const int sn = min(s + 1, nstg - 1), cqn = (sn & 7) * 64;
+      if ((sn & 7) == 0) stage_addr(sn);
+      f32x4 ah[RTW], al[RTW];
+#pragma unroll
+      for (int t = 0; t < RTW; ++t) {
+        ah[t] = *reinterpret_cast<const f32x4*>(abase + aoff[t]);
+        al[t] = *reinterpret_cast<const f32x4*>(abase + aoff[t] + 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int st = 0; st < KSTEPS; ++st) {         // tap st >> 1, 16-channel step st & 1
+        constexpr int dummy = 0; (void)dummy;
+        const int kk = st & 3;
+        const f16x8 bh = __builtin_bit_cast(f16x8, bf[kk].h), bl = __builtin_bit_cast(f16x8, bf[kk].l);
+        const int nxt = ((st + 1) >> 1) * RW_ENT + ((st + 1) & 1) * 32;   // the k16 step after this one
+#pragma unroll
+        for (int tp = 0; tp < RTW; tp += 2) {
+          const bool pair = tp + 1 < RTW;
+          const int t1 = pair ? tp + 1 : tp;
+          const f16x8 a0h = __builtin_bit_cast(f16x8, ah[tp]), a0l = __builtin_bit_cast(f16x8, al[tp]);
+          const f16x8 a1h = __builtin_bit_cast(f16x8, ah[t1]), a1l = __builtin_bit_cast(f16x8, al[t1]);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc[tp], 0, 0, 0);
+          if (pair) acc[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc[t1], 0, 0, 0);
+          cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, cross[tp], 0, 0, 0);
+          if (pair) cross[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, cross[t1], 0, 0, 0);
+          cross[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, cross[tp], 0, 0, 0);
+          if (pair) cross[t1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, cross[t1], 0, 0, 0);
+          if (st + 1 < KSTEPS && !(NECK_ABL & 16)) {
+#pragma unroll
+            for (int t = tp; t <= t1; ++t) {
+              ah[t] = *reinterpret_cast<const f32x4*>(abase + aoff[t] + nxt);
+              al[t] = *reinterpret_cast<const f32x4*>(abase + aoff[t] + nxt + 64);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(NECK_ABL & 1)) {                      // gather passes of the next stage due at this step
+#pragma unroll
+          for (int q = 0; q < NPASS; ++q)
+            if (NECK_SPREAD ? q * (KSTEPS - 4 > 0 ? KSTEPS - 4 : 1) / NPASS == st : st == 0) sreg[q] = *reinterpret_cast<const f32x4*>(xplane + src[q] + cqn);
+        }
+        const int gi = min(gstep, NC_STAGES * 4 - 1);   // refill the ring slot just consumed
+        if (!(NECK_ABL & 2)) {
+          bf[kk].h = wh[(size_t)gi * 64];
+          bf[kk].l = wl[(size_t)gi * 64];
+        }
+        ++gstep;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stage_write(cur ^ 1);
+      if (!(NECK_ABL & 32)) __syncthreads();
+    }
+  };
+  if (groups == 4) stages(std::integral_constant<int, 4>{});
+  else if (groups == 2) stages(std::integral_constant<int, 2>{});
+  else stages(std::integral_constant<int, 1>{});
+
+  float* out = cd.part + ((size_t)split * g.M) * cd.ncols + nh * 128 + nt * 32 + col;
+#pragma unroll
+  for (int t = 0; t < RTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * MT + HALF_ROWS * rh + 32 * t + crow(r, half);
+      if (row < g.M) out[(size_t)row * cd.ncols] = fmaf(cross[t][r], SPLIT_INV, acc[t][r]);
+    }
+}
+
 // Rows per workgroup: minimise (rounds over the CUs) x (per-item cost ~ rows + a fixed
 // part for the 2 MB weight slab every item streams).  16 maps of 40x40 (6400 positions,
 // 22 items per tile): 256 rows -> 550 items = 3 rounds; 192 rows -> 748 items = 3 rounds
 // of 3/4 the work each.
-int neck_conv_rows(int M, int items_per_mt, int num_cus) {
+int neck_conv_rows(int M, int items_per_mt, int num_cus, int max_rows) {
   int best = NECK_MT;
   long best_cost = -1;
   for (int rows : {256, 192, 128}) {
+    if (rows > max_rows) continue;
     const long items = (long)items_per_mt * ((M + rows - 1) / rows);
     const long rounds = (items + num_cus - 1) / num_cus;
     const long cost = rounds * (rows + 32);
@@ -316,6 +535,14 @@ int neck_conv_rows(int M, int items_per_mt, int num_cus) {
 
 hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s) {
   const dim3 grid(p.nblocks), block(512);
+  if (p.row_window) {   // (the 256-row shape of this kernel spills - 107 VGPRs - and is not built)
+    switch (p.mt_rows) {
+      case 192: hipLaunchKernelGGL((k_neck_conv_rw<3>), grid, block, 0, s, p); break;
+      case 128: hipLaunchKernelGGL((k_neck_conv_rw<2>), grid, block, 0, s, p); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (p.mt_rows) {
     case 256: hipLaunchKernelGGL((k_neck_conv<4>), grid, block, 0, s, p); break;
     case 192: hipLaunchKernelGGL((k_neck_conv<3>), grid, block, 0, s, p); break;

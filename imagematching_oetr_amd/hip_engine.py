@@ -79,7 +79,7 @@ EXPORTS = (
     'oetr_neck_set_trace', 'oetr_set_encoder_tile', 'oetr_query_flags',
     'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity',
     'oetr_full_attention_split', 'oetr_set_attention', 'oetr_neck_set_conv_rows',
-    'oetr_linear_attention_workspace_bytes')
+    'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -199,6 +199,8 @@ def load_library(path=None):
     lib.oetr_neck_set_trace.argtypes = [vp, vp]
     lib.oetr_neck_set_conv_rows.restype = i
     lib.oetr_neck_set_conv_rows.argtypes = [vp, i]
+    lib.oetr_neck_set_conv_kernel.restype = i
+    lib.oetr_neck_set_conv_kernel.argtypes = [vp, i]
     for name in ('oetr_query_flags', 'oetr_neck_query_flags'):
         fn = getattr(lib, name)
         fn.restype = i
@@ -587,6 +589,13 @@ class NeckEngine:
         """Output positions per workgroup of the conv kernel: 0/None = auto, 256, 192, 128."""
         _check(self.lib, self.lib.oetr_neck_set_conv_rows(self._h, int(rows or 0)),
                'oetr_neck_set_conv_rows')
+
+    CONV_KERNELS = {'auto': 0, 'gather': 1, 'row_window': 2}
+
+    def set_conv_kernel(self, kind):
+        """'auto' (row window when the output map is >= 16 wide), 'gather' or 'row_window'."""
+        _check(self.lib, self.lib.oetr_neck_set_conv_kernel(self._h, self.CONV_KERNELS[kind or 'auto']),
+               'oetr_neck_set_conv_kernel')
 
     def query_flags(self, clear=True):
         """Status word of the neck handle (see ``HotPathEngine.query_flags``)."""

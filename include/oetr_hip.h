@@ -306,6 +306,13 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float *backbone_feat,
  * size), or 256 / 192 / 128.  Results are identical in every shape (same summation
  * order per output).  Mutates the handle. */
 oetr_status oetr_neck_set_conv_rows(oetr_neck_handle h, int rows);
+/* Which PatchMerging conv kernel runs: 0 = auto (default: the row-window kernel when the
+ * output map is at least 16 wide, else the gather kernel), 1 = gather (one input pixel
+ * per output position per kernel pixel), 2 = row window (each input row segment staged
+ * once per kernel row and x parity; needs wo >= 16, else OETR_ERR_BAD_SHAPE at forward).
+ * The two sum the same products in a different order (fp32 rounding-level differences).
+ * Mutates the handle. */
+oetr_status oetr_neck_set_conv_kernel(oetr_neck_handle h, int kind);
 /* Status word of the neck handle (see oetr_query_flags): OETR_FLAG_F16_RANGE when a
  * backbone feature / intermediate reached the f16 range of its split GEMMs. */
 oetr_status oetr_neck_query_flags(oetr_neck_handle h, void *stream,

@@ -44,6 +44,42 @@ def test_neck_edge_shapes_vs_oracle(gpu, n, hb, wb):
     assert err <= FEAT_TOL, f'feat max err {err:.3e}'
 
 
+@pytest.mark.parametrize('n,hb,wb', [(1, 32, 32), (3, 33, 35), (2, 9, 40), (1, 40, 99), (7, 40, 40), (1, 100, 36),
+                                     (1, 6, 400)])
+def test_neck_conv_kernels_agree(gpu, n, hb, wb):
+    """The row-window conv kernel (each input row segment staged once per kernel row and
+    x parity) against the gather kernel and the fp64 oracle: every rows-per-workgroup
+    shape, tiles that start mid-row, cross image boundaries and end ragged."""
+    w = orc.make_neck_weights(45)
+    bb = orc.make_backbone_features(46 + hb, n, hb, wb)
+    ref = orc.neck(bb.double(), {k: v.double() for k, v in w.items()})
+    eng = pkg.NeckEngine(w, device=gpu)
+    outs = {}
+    for kind in ('gather', 'row_window'):
+        eng.set_conv_kernel(kind)
+        for rows in (0, 192, 128):
+            eng.set_conv_rows(rows)
+            feat = eng.forward(bb.to(gpu))
+            err = (feat.cpu().double() - ref).abs().max().item()
+            assert err <= FEAT_TOL, f'{kind}/{rows}: feat max err {err:.3e}'
+            assert torch.equal(outs.setdefault(kind, feat.clone()), feat), f'{kind}: rows={rows} changed the result'
+    assert (outs['gather'] - outs['row_window']).abs().max().item() <= 1e-5
+
+
+def test_neck_row_window_needs_wide_maps(gpu):
+    w = orc.make_neck_weights(47)
+    eng = pkg.NeckEngine(w, device=gpu)
+    bb = orc.make_backbone_features(48, 1, 20, 14).to(gpu)      # output map 7 wide
+    auto = eng.forward(bb)                                      # auto -> gather kernel
+    eng.set_conv_kernel('row_window')
+    with pytest.raises(ValueError):
+        eng.forward(bb)
+    eng.set_conv_kernel('gather')
+    assert torch.equal(eng.forward(bb), auto)
+    with pytest.raises(KeyError):
+        eng.set_conv_kernel('fastest')
+
+
 def test_neck_bench_size_properties(gpu):
     """16 images of 40x40 (both sides of 8 pairs at 640x640): per-image independence
     (a batch equals its images run one by one) and shift of the padding row."""

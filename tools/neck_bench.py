@@ -14,6 +14,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 hb = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bb = torch.relu(torch.randn(n, 1024, hb, hb, device=dev))
 eng = pkg.NeckEngine({k: v for k, v in model.state_dict().items() if k in pkg.neck_keys()}, device=dev)
+if len(sys.argv) > 3:
+    eng.set_conv_kernel(sys.argv[3])        # 'gather' | 'row_window' (default: auto)
 
 def timed(fn, it=20):
     for _ in range(3): out = fn()

@@ -1,4 +1,4 @@
-"""k_neck_conv rows-per-workgroup A/B (256 / 192 / 128 / auto) on the bench shape."""
+"""PatchMerging conv A/B: kernel (gather / row window) x rows per workgroup (256 / 192 / 128 / auto)."""
 import sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parents[1]
@@ -12,9 +12,12 @@ model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
 for n, hb in ((16, 40), (64, 40), (16, 64), (2, 80)):
     bb = torch.relu(torch.randn(n, 1024, hb, hb, device=dev))
     eng = pkg.NeckEngine({k: v for k, v in model.state_dict().items() if k in pkg.neck_keys()}, device=dev)
-    ref = None
+    refs = {}
     line = f'n={n} {hb}x{hb}:'
-    for rows in (256, 192, 128, 0, 256, 192, 128, 0):     # two passes: the first also warms clocks / caches
+    for kind, rows in [(k, r) for _ in range(2) for k in ('gather', 'row_window') for r in (256, 192, 128, 0)]:
+        if kind == 'row_window' and rows == 256:
+            continue
+        eng.set_conv_kernel(kind)
         eng.set_conv_rows(rows)
         for _ in range(3):
             out = eng.forward(bb)
@@ -23,8 +26,8 @@ for n, hb in ((16, 40), (64, 40), (16, 64), (2, 80)):
                 eng.forward(bb)
             torch.cuda.synchronize()
         ks = {k: v[1] / v[0] * 1e3 for k, v in tr.summary().items()}
-        if ref is None:
-            ref = out.clone()
+        ref = refs.setdefault(kind, out.clone())
         assert torch.equal(out, ref), 'rows-per-workgroup changed the result'
-        line += f'  rows={rows or "auto"}: conv {ks["k_neck_conv"]:.1f} us'
+        err = (out - refs['gather']).abs().max().item() / refs['gather'].abs().max().item()
+        line += f'  {kind[:2]}/{rows or "auto"}: {ks["k_neck_conv"]:.1f} us (d={err:.1e})'
     print(line, flush=True)
