@@ -312,8 +312,11 @@ DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w) {
 
 oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, const float* feat1,
                             const float* feat2, const float* pos1, const float* pos2,
-                            int enc_layers, hipStream_t s, bool with_decoder = true) {
-  TRACED(h, s, K_PREP, launch_prep_tokens(g, feat1, feat2, pos1, pos2, w.x, w.pos, s));
+                            int enc_layers, hipStream_t s, bool with_decoder = true,
+                            bool resident = false) {
+  // resident: the caller (oetr_forward_tokens) already holds token-major features and
+  // position tables in the workspace (oetr_token_buffers) - no transpose launch
+  if (!resident) TRACED(h, s, K_PREP, launch_prep_tokens(g, feat1, feat2, pos1, pos2, w.x, w.pos, s));
   EncLaunch p;
   memset(&p, 0, sizeof(p));
   p.tile_rows = encoder_tile_rows(h, g);
@@ -642,13 +645,14 @@ size_t oetr_workspace_bytes(oetr_handle h, int n_pairs, int hf1, int wf1, int hf
   return carve(g, nullptr, h && h->attn_full).bytes;   // (h may be NULL: shape-only query, linear attention)
 }
 
-oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* feat2,
-                                const float* pos1, const float* pos2, int n_pairs, int hf1,
-                                int wf1, int hf2, int wf2, int img_h1, int img_w1, int img_h2,
-                                int img_w2, void* workspace, size_t workspace_bytes,
-                                float* box1, float* box2, const oetr_stage_outputs* st,
-                                void* stream) {
-  if (!h || !feat1 || !feat2 || !pos1 || !pos2)
+namespace {
+oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
+                         const float* pos1, const float* pos2, int n_pairs, int hf1,
+                         int wf1, int hf2, int wf2, int img_h1, int img_w1, int img_h2,
+                         int img_w2, void* workspace, size_t workspace_bytes,
+                         float* box1, float* box2, const oetr_stage_outputs* st,
+                         void* stream, bool resident) {
+  if (!h || (!resident && (!feat1 || !feat2 || !pos1 || !pos2)))
     return fail(OETR_ERR_BAD_ARG, "oetr_forward: NULL handle/input");
   int enc_layers = OETR_N_ENC;
   if (st) {
@@ -670,7 +674,7 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
   oetr_status rc = check_ws(g, workspace, workspace_bytes, &w, h->attn_full);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, enc_layers, s, /*with_decoder=*/false);
+  rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, enc_layers, s, /*with_decoder=*/false, resident);
   if (rc) return rc;
   const size_t r1 = (size_t)g.N * g.L[0], r2 = (size_t)g.N * g.L[1];
   if (st) {
@@ -703,6 +707,43 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
     if ((rc = copy_out(st->tlbr2, tl2, 4 * g.N, s))) return rc;
   }
   return OETR_OK;
+}
+}  // namespace
+
+oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* feat2,
+                                const float* pos1, const float* pos2, int n_pairs, int hf1,
+                                int wf1, int hf2, int wf2, int img_h1, int img_w1, int img_h2,
+                                int img_w2, void* workspace, size_t workspace_bytes,
+                                float* box1, float* box2, const oetr_stage_outputs* st,
+                                void* stream) {
+  return forward_impl(h, feat1, feat2, pos1, pos2, n_pairs, hf1, wf1, hf2, wf2, img_h1, img_w1,
+                      img_h2, img_w2, workspace, workspace_bytes, box1, box2, st, stream, false);
+}
+
+oetr_status oetr_token_buffers(oetr_handle h, int n_pairs, int hf1, int wf1, int hf2, int wf2,
+                               void* workspace, size_t workspace_bytes, float** tokens1,
+                               float** tokens2, float** pos_tokens1, float** pos_tokens2) {
+  if (!h || !tokens1 || !tokens2 || !pos_tokens1 || !pos_tokens2)
+    return fail(OETR_ERR_BAD_ARG, "oetr_token_buffers: NULL argument");
+  Geom g;
+  if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g))
+    return fail(OETR_ERR_BAD_SHAPE, "oetr_token_buffers: invalid shape");
+  Workspace w;
+  oetr_status rc = check_ws(g, workspace, workspace_bytes, &w, h->attn_full);
+  if (rc) return rc;
+  *tokens1 = w.x + (size_t)g.row0[0] * C;
+  *tokens2 = w.x + (size_t)g.row0[1] * C;
+  *pos_tokens1 = w.pos + (size_t)g.prow0[0] * C;
+  *pos_tokens2 = w.pos + (size_t)g.prow0[1] * C;
+  return OETR_OK;
+}
+
+oetr_status oetr_forward_tokens(oetr_handle h, int n_pairs, int hf1, int wf1, int hf2, int wf2,
+                                int img_h1, int img_w1, int img_h2, int img_w2, void* workspace,
+                                size_t workspace_bytes, float* box1, float* box2, void* stream) {
+  return forward_impl(h, nullptr, nullptr, nullptr, nullptr, n_pairs, hf1, wf1, hf2, wf2, img_h1,
+                      img_w1, img_h2, img_w2, workspace, workspace_bytes, box1, box2, nullptr,
+                      stream, true);
 }
 
 oetr_status oetr_forward(oetr_handle h, const float* feat1, const float* feat2,
@@ -1004,9 +1045,10 @@ size_t oetr_neck_workspace_bytes(oetr_neck_handle h, int n_images, int hb, int w
   return neck_carve(g, nullptr).bytes;
 }
 
-oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, int n_images,
+namespace {
+oetr_status neck_forward_impl(oetr_neck_handle h, const float* backbone_feat, int n_images,
                               int hb, int wb, void* workspace, size_t workspace_bytes,
-                              float* feat_out, void* stream) {
+                              float* feat_out, void* stream, bool token_major) {
   if (!h || !backbone_feat || !feat_out)
     return fail(OETR_ERR_BAD_ARG, "oetr_neck_forward: NULL argument");
   NeckGeom g;
@@ -1061,10 +1103,26 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, in
   op.g = g;
   for (int i = 0; i < 3; ++i) { op.part[i] = w.part[i]; op.nsplit[i] = kNeckConv[i].nsplit; op.bias[i] = h->conv_b[i]; }
   op.wh = h->out_wh; op.wl = h->out_wl; op.bias2 = h->out_b;
-  op.feat = feat_out;
+  op.feat = token_major ? nullptr : feat_out;
+  op.tokens = token_major ? feat_out : nullptr;
   op.flags = h->flags;
   TRACED(h, s, K_NECK_OUT, launch_neck_out(op, s));
   return OETR_OK;
+}
+}  // namespace
+
+oetr_status oetr_neck_forward(oetr_neck_handle h, const float* backbone_feat, int n_images,
+                              int hb, int wb, void* workspace, size_t workspace_bytes,
+                              float* feat_out, void* stream) {
+  return neck_forward_impl(h, backbone_feat, n_images, hb, wb, workspace, workspace_bytes,
+                           feat_out, stream, false);
+}
+
+oetr_status oetr_neck_forward_tokens(oetr_neck_handle h, const float* backbone_feat, int n_images,
+                                     int hb, int wb, void* workspace, size_t workspace_bytes,
+                                     float* tokens_out, void* stream) {
+  return neck_forward_impl(h, backbone_feat, n_images, hb, wb, workspace, workspace_bytes,
+                           tokens_out, stream, true);
 }
 
 namespace {

@@ -1109,7 +1109,8 @@ struct NeckOutLaunch {
   const float* bias[3];
   const f32x4 *wh, *wl;   // input_proj2 weight [256][512]
   const float* bias2;
-  float* feat;            // [n_img][256][ho*wo]
+  float* feat;            // [n_img][256][ho*wo]  (NCHW), or
+  float* tokens;          // [n_img * ho*wo][256] (token-major: the hot path's x rows); one of the two
   uint32_t* flags;
 };
 hipError_t launch_neck_proj(const NeckProjLaunch& p, hipStream_t s);

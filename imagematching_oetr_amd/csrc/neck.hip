@@ -596,6 +596,17 @@ __global__ __launch_bounds__(512) void k_neck_out(NeckOutLaunch p) {
   ws.template gemm<512, 0, 0>(A, p.wh, p.wl, wave, lane, acc, nullptr, nullptr, 0, 0);
   acc_to_lds<1>(S0, LDA, 32 * wave, lane, acc);
   __syncthreads();
+  if (p.tokens) {   // token-major: the rows as they are (256 contiguous floats each)
+    const int lrow = tid >> 4, lpart = tid & 15;
+    const int r = r0 + lrow;
+    if (r < g.M) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = 4 * (i * 16 + lpart);
+        *reinterpret_cast<f32x4*>(p.tokens + (size_t)r * C + c4) = *reinterpret_cast<const f32x4*>(&S0[lrow * LDA + c4]);
+      }
+    }
+  } else {
   // transposed store: one channel, 32 consecutive positions per half-wave
   {
     const int pos = tid & 31, cg = tid >> 5;
@@ -610,6 +621,7 @@ __global__ __launch_bounds__(512) void k_neck_out(NeckOutLaunch p) {
         dst[(size_t)c * hw_o] = S0[pos * LDA + c];
       }
     }
+  }
   }
   range_report<GM_SPLIT>(rg, p.flags);
 }

@@ -79,7 +79,8 @@ EXPORTS = (
     'oetr_neck_set_trace', 'oetr_set_encoder_tile', 'oetr_query_flags',
     'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity',
     'oetr_full_attention_split', 'oetr_set_attention', 'oetr_neck_set_conv_rows',
-    'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel')
+    'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel',
+    'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -195,6 +196,12 @@ def load_library(path=None):
     lib.oetr_neck_workspace_bytes.argtypes = [vp, i, i, i]
     lib.oetr_neck_forward.restype = i
     lib.oetr_neck_forward.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp]
+    lib.oetr_neck_forward_tokens.restype = i
+    lib.oetr_neck_forward_tokens.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp]
+    lib.oetr_token_buffers.restype = i
+    lib.oetr_token_buffers.argtypes = [vp, i, i, i, i, i, vp, sz] + [C.POINTER(vp)] * 4
+    lib.oetr_forward_tokens.restype = i
+    lib.oetr_forward_tokens.argtypes = [vp, i, i, i, i, i, i, i, i, i, vp, sz, vp, vp, vp]
     lib.oetr_neck_set_trace.restype = i
     lib.oetr_neck_set_trace.argtypes = [vp, vp]
     lib.oetr_neck_set_conv_rows.restype = i
@@ -342,6 +349,8 @@ class HotPathEngine:
                                               C.byref(handle)), 'oetr_create')
         self._h = handle
         self._ws = {}
+        self._ws_shape = {}     # stream -> geometry the workspace was last carved for
+        self._pos_loaded = {}   # stream -> key of the token-major position tables it holds
         if enc_tile is not None:
             self.set_encoder_tile(enc_tile)
         if attention not in self.ATTENTIONS:
@@ -392,6 +401,10 @@ class HotPathEngine:
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._pos_loaded.pop(key, None)
+        if self._ws_shape.get(key) != (n, hf1, wf1, hf2, wf2):   # another carve: tables gone
+            self._ws_shape[key] = (n, hf1, wf1, hf2, wf2)
+            self._pos_loaded.pop(key, None)
         return ws
 
     @staticmethod
@@ -418,6 +431,7 @@ class HotPathEngine:
         hf1, wf1 = self._grid(feat1, pos1, 'feat1')
         hf2, wf2 = self._grid(feat2, pos2, 'feat2')
         ws = self.workspace(n, hf1, wf1, hf2, wf2)
+        self._pos_loaded.pop(torch.cuda.current_stream(self.device).cuda_stream, None)
         dev = self.device
         box1 = torch.empty(n, 4, device=dev)
         box2 = torch.empty(n, 4, device=dev)
@@ -454,6 +468,56 @@ class HotPathEngine:
                 out = {k: out[k] for k in ('memory1', 'memory2')}
             return out
 
+    # ---- token-resident entry: the neck stores straight into the workspace ----
+    def token_buffers(self, n, hf1, wf1, hf2, wf2):
+        """Where this stream's workspace keeps the hot path's token-major inputs for the
+        shape: dict of float32 tensor VIEWS of the workspace - ``tokens1`` [n*L1,256],
+        ``tokens2`` [n*L2,256] (contiguous after tokens1), ``pos1`` [L1,256], ``pos2``
+        [L2,256] (``oetr_token_buffers``)."""
+        ws = self.workspace(n, hf1, wf1, hf2, wf2)
+        ptrs = [C.c_void_p() for _ in range(4)]
+        _check(self.lib, self.lib.oetr_token_buffers(
+            self._h, n, hf1, wf1, hf2, wf2, ws.data_ptr(), ws.numel(),
+            *[C.byref(p) for p in ptrs]), 'oetr_token_buffers')
+        rows = (n * hf1 * wf1, n * hf2 * wf2, hf1 * wf1, hf2 * wf2)
+        out = {}
+
+        def view(ptr, r):
+            off = ptr - ws.data_ptr()
+            return ws[off:off + r * D_MODEL * 4].view(torch.float32).view(r, D_MODEL)
+        for name, p, r in zip(('tokens1', 'tokens2', 'pos1', 'pos2'), ptrs, rows):
+            out[name] = view(p.value, r)
+        if ptrs[1].value != ptrs[0].value + rows[0] * D_MODEL * 4:
+            raise OetrError('oetr_token_buffers: tokens2 does not follow tokens1')
+        out['tokens'] = view(ptrs[0].value, rows[0] + rows[1])   # both sides: one 2n-image neck call
+        return out
+
+    def load_pos_tokens(self, bufs, pos1, pos2):
+        """Write the position tables [1,256,hf,wf] token-major into ``bufs['pos1/2']``
+        unless this workspace already holds them (they survive forward calls)."""
+        skey = torch.cuda.current_stream(self.device).cuda_stream
+        key = (bufs['pos1'].data_ptr(), bufs['pos2'].data_ptr(),
+               pos1.data_ptr(), pos1._version, tuple(pos1.shape),
+               pos2.data_ptr(), pos2._version, tuple(pos2.shape))
+        if self._pos_loaded.get(skey) != key:
+            bufs['pos1'].copy_(pos1.reshape(D_MODEL, -1).t())
+            bufs['pos2'].copy_(pos2.reshape(D_MODEL, -1).t())
+            self._pos_loaded[skey] = key
+
+    def forward_tokens(self, n, hf1, wf1, hf2, wf2, img_hw1, img_hw2):
+        """``forward`` on the tokens / position tables the workspace holds
+        (``token_buffers``): -> (box1, box2) [n,4]."""
+        ws = self.workspace(n, hf1, wf1, hf2, wf2)
+        dev = self.device
+        box1 = torch.empty(n, 4, device=dev)
+        box2 = torch.empty(n, 4, device=dev)
+        with torch.cuda.device(dev):
+            _check(self.lib, self.lib.oetr_forward_tokens(
+                self._h, n, hf1, wf1, hf2, wf2, int(img_hw1[0]), int(img_hw1[1]),
+                int(img_hw2[0]), int(img_hw2[1]), ws.data_ptr(), ws.numel(),
+                box1.data_ptr(), box2.data_ptr(), _stream(dev)), 'oetr_forward_tokens')
+        return box1, box2
+
     def feature_correlation(self, feat1, feat2, pos1, pos2):
         feat1, feat2 = _dev(feat1, 'feat1'), _dev(feat2, 'feat2')
         pos1, pos2 = _dev(pos1, 'pos1'), _dev(pos2, 'pos2')
@@ -461,6 +525,7 @@ class HotPathEngine:
         hf1, wf1 = self._grid(feat1, pos1, 'feat1')
         hf2, wf2 = self._grid(feat2, pos2, 'feat2')
         ws = self.workspace(n, hf1, wf1, hf2, wf2)
+        self._pos_loaded.pop(torch.cuda.current_stream(self.device).cuda_stream, None)
         dev = self.device
         hs1 = torch.empty(n, 1, D_MODEL, device=dev)
         hs2 = torch.empty(n, 1, D_MODEL, device=dev)
@@ -584,6 +649,31 @@ class NeckEngine:
                 self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
                 feat.data_ptr(), _stream(self.device)), 'oetr_neck_forward')
         return feat
+
+    def forward_tokens(self, backbone_feat, tokens_out):
+        """Same as ``forward`` with the result stored token-major into ``tokens_out``
+        [n*(hb//2)*(wb//2), 256] (a ``HotPathEngine.token_buffers`` view)."""
+        x = _dev(backbone_feat, 'backbone_feat')
+        if x.dim() != 4 or x.shape[1] != self.BACKBONE_C:
+            raise ValueError(f'backbone_feat must be [n,{self.BACKBONE_C},hb,wb], '
+                             f'got {tuple(x.shape)}')
+        n, hb, wb = int(x.shape[0]), int(x.shape[2]), int(x.shape[3])
+        if tuple(tokens_out.shape) != (n * (hb // 2) * (wb // 2), D_MODEL) or \
+                tokens_out.dtype != torch.float32 or not tokens_out.is_contiguous():
+            raise ValueError(f'tokens_out must be contiguous float32 '
+                             f'[{n * (hb // 2) * (wb // 2)},{D_MODEL}], got {tuple(tokens_out.shape)}')
+        need = self.lib.oetr_neck_workspace_bytes(self._h, n, hb, wb)
+        if need == 0:
+            raise ValueError(f'invalid neck shape n={n} grid {hb}x{wb}')
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.oetr_neck_forward_tokens(
+                self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
+                tokens_out.data_ptr(), _stream(self.device)), 'oetr_neck_forward_tokens')
+        return tokens_out
 
     def set_conv_rows(self, rows):
         """Output positions per workgroup of the conv kernel: 0/None = auto, 256, 192, 128."""

@@ -137,6 +137,10 @@ class OETR(nn.Module):
         #: run input_proj -> PatchMerging -> input_proj2 as HIP kernels when the
         #: features are on a GPU (False: the torch modules, as on CPU)
         self.hip_neck = True
+        #: forward_dummy hands the trunk output to the HIP neck and lets it store token-major
+        #: into the hot path's workspace (no NCHW feat tensors, no transpose launch);
+        #: False: feature_extraction + boxes_from_features as separate steps
+        self.hip_fuse_neck = True
         self._engine = None
         self._engine_key = None
         self._engine_f32 = None
@@ -288,9 +292,49 @@ class OETR(nn.Module):
         h1, w1 = image1.shape[1:3]
         h2, w2 = image2.shape[1:3]
         self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
+        if self.hip_neck and self.hip_fuse_neck and image1.is_cuda and not self.training:
+            # trunk -> HIP neck storing token-major straight into the hot path's workspace
+            if image1.shape == image2.shape:
+                n = image1.shape[0]
+                bb = self.backbone(torch.cat([image1, image2], dim=0))
+                return self.boxes_from_backbone(bb[:n], bb[n:], (h1, w1), (h2, w2), both=bb)
+            return self.boxes_from_backbone(self.backbone(image1), self.backbone(image2),
+                                            (h1, w1), (h2, w2))
         feat1, feat2, pos1, pos2, _, _, _, _ = self.feature_extraction(
             image1, image2)
         return self.boxes_from_features(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2))
+
+    def boxes_from_backbone(self, bb1, bb2, hw1, hw2, both=None):
+        """Trunk outputs [N,1024,hb,wb] -> (box1, box2): the HIP neck writes its result
+        token-major into the hot-path workspace (``oetr_neck_forward_tokens`` ->
+        ``oetr_forward_tokens``), so the NCHW ``feat`` tensors of reference
+        ``src/model.py:113-118`` and their ``flatten(2).permute(0, 2, 1)``
+        (``transformer.py:338-345``) never exist.  ``both``: the 2N-image tensor
+        ``bb1``/``bb2`` are halves of (one neck call).  Same values as
+        ``feature_extraction`` + ``boxes_from_features``, which is also the route taken
+        when a range flag trips."""
+        eng, neck = self.engine(), self.neck_engine()
+        n = int(bb1.shape[0])
+        hf1, wf1 = int(bb1.shape[2]) // 2, int(bb1.shape[3]) // 2
+        hf2, wf2 = int(bb2.shape[2]) // 2, int(bb2.shape[3]) // 2
+        bufs = eng.token_buffers(n, hf1, wf1, hf2, wf2)
+        meta = lambda h, w: torch.empty(1, 1, h, w, device='meta')   # pos_encoding reads sizes only
+        eng.load_pos_tokens(bufs, self.pos_encoding(meta(hf1, wf1)), self.pos_encoding(meta(hf2, wf2)))
+        if both is not None:
+            neck.forward_tokens(both, bufs['tokens'])
+        else:
+            neck.forward_tokens(bb1, bufs['tokens1'])
+            neck.forward_tokens(bb2, bufs['tokens2'])
+        boxes = eng.forward_tokens(n, hf1, wf1, hf2, wf2, hw1, hw2)
+        if self.hip_on_overflow != 'ignore':
+            tripped = neck.query_flags() & FLAG_F16_RANGE
+            if eng.precision in eng.F16_RANGE:
+                tripped |= eng.query_flags() & FLAG_F16_RANGE
+            if tripped:    # the unfused route carries the per-stage handling (raise / exact fp32)
+                feat1, feat2 = self.neck(bb1), self.neck(bb2)
+                return self.boxes_from_features(feat1, feat2, self.pos_encoding(feat1),
+                                                self.pos_encoding(feat2), hw1, hw2)
+        return boxes
 
     def boxes_from_features(self, feat1, feat2, pos1, pos2, hw1, hw2):
         """Everything after ``feature_extraction`` (reference ``src/model.py:239-252``)

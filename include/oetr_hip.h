@@ -199,6 +199,28 @@ oetr_status oetr_forward(oetr_handle h, const float *feat1, const float *feat2,
                          size_t workspace_bytes, float *box1, float *box2,
                          void *stream);
 
+/* The same call for a caller that produces the features on the device itself (the HIP
+ * neck): the `flatten(2).permute(0, 2, 1)` of features and position tables that opens
+ * QueryTransformer.forward (reference src/models/transformer.py:338-345) is then the
+ * producer's store, not a launch of its own.
+ *   oetr_token_buffers   where in `workspace` the hot path keeps its token-major inputs for
+ *                        this shape: tokens1 [N*hf1*wf1][256], tokens2 [N*hf2*wf2][256]
+ *                        (tokens2 == tokens1 + N*hf1*wf1*256: one 2N-image neck call fills
+ *                        both), pos_tokens1/2 [hf*wf][256] (pos[c][l] transposed).  The
+ *                        position tables survive forward calls; the tokens do not (the
+ *                        encoder works in place).
+ *   oetr_forward_tokens  oetr_forward on what those four buffers hold.                    */
+oetr_status oetr_token_buffers(oetr_handle h, int n_pairs, int hf1, int wf1,
+                               int hf2, int wf2, void *workspace,
+                               size_t workspace_bytes, float **tokens1,
+                               float **tokens2, float **pos_tokens1,
+                               float **pos_tokens2);
+oetr_status oetr_forward_tokens(oetr_handle h, int n_pairs, int hf1, int wf1,
+                                int hf2, int wf2, int img_h1, int img_w1,
+                                int img_h2, int img_w2, void *workspace,
+                                size_t workspace_bytes, float *box1,
+                                float *box2, void *stream);
+
 /* Same as oetr_forward, additionally exporting intermediates. box1/box2 may
  * be NULL when stages->enc_layers < 8. */
 oetr_status oetr_forward_stages(oetr_handle h, const float *feat1,
@@ -301,6 +323,14 @@ oetr_status oetr_neck_forward(oetr_neck_handle h, const float *backbone_feat,
                               int n_images, int hb, int wb, void *workspace,
                               size_t workspace_bytes, float *feat_out,
                               void *stream);
+/* The same with a token-major result: tokens_out [n_images * (hb/2)*(wb/2)][256], i.e.
+ * feat_out[n][c][l] stored at tokens_out[(n*L + l)*256 + c] - what oetr_token_buffers
+ * hands out (same values as oetr_neck_forward, bit for bit). */
+oetr_status oetr_neck_forward_tokens(oetr_neck_handle h,
+                                     const float *backbone_feat, int n_images,
+                                     int hb, int wb, void *workspace,
+                                     size_t workspace_bytes, float *tokens_out,
+                                     void *stream);
 /* Output positions per workgroup of the fused PatchMerging conv kernel: 0 = auto
  * (default: the shape with the fewest workgroup rounds over the CUs for this problem
  * size), or 256 / 192 / 128.  Results are identical in every shape (same summation

@@ -149,6 +149,60 @@ def test_forward_pairs_equals_the_per_pair_loop_on_the_real_model(gpu):
         assert torch.equal(one[0][0], full[0][j]) and torch.equal(one[1][0], full[1][j])
 
 
+def test_neck_stores_tokens_straight_into_the_hot_path(gpu):
+    """forward_dummy's fused route (trunk -> ``oetr_neck_forward_tokens`` into the
+    workspace -> ``oetr_forward_tokens``: no NCHW feat, no transpose launch) against the
+    stepwise route on the SAME trunk output: bit-identical boxes, for equal and unequal
+    image sizes, across shape changes on one workspace (the cached token-major position
+    tables must be reloaded) and interleaved with the ordinary entry."""
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    sd = model.state_dict()
+    sd.update(orc.make_hot_weights(6, sharpen=True))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    g = torch.Generator().manual_seed(10)
+    eng, neck = model.engine(), model.neck_engine()
+
+    def stepwise(bb1, bb2, hw1, hw2):
+        f1, f2 = neck.forward(bb1), neck.forward(bb2)
+        return eng.forward(f1, f2, model.pos_encoding(f1), model.pos_encoding(f2), hw1, hw2)
+    for (h1, w1), (h2, w2), n in (((640, 640), (640, 640), 3), ((640, 1280), (640, 640), 2),
+                                  ((640, 640), (640, 640), 3), ((480, 640), (480, 640), 1)):
+        im1 = torch.rand(n, h1, w1, 3, generator=g).to(gpu)
+        im2 = torch.rand(n, h2, w2, 3, generator=g).to(gpu)
+        if (h1, w1) == (h2, w2):
+            bb = model.backbone(torch.cat([im1, im2]))
+            bb1, bb2, both = bb[:n], bb[n:], bb
+        else:
+            bb1, bb2, both = model.backbone(im1), model.backbone(im2), None
+        want = stepwise(bb1.contiguous(), bb2.contiguous(), (h1, w1), (h2, w2))
+        got = model.boxes_from_backbone(bb1, bb2, (h1, w1), (h2, w2), both=both)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), ((h1, w1), (h2, w2))
+        again = model.boxes_from_backbone(bb1, bb2, (h1, w1), (h2, w2), both=both)   # tables cached
+        assert torch.equal(again[0], want[0]) and torch.equal(again[1], want[1])
+    # the neck's token-major store is its NCHW result transposed, bit for bit
+    bb = model.backbone(torch.rand(2, 480, 640, 3, generator=g).to(gpu))
+    feat = neck.forward(bb)
+    tok = torch.empty(2 * feat.shape[2] * feat.shape[3], 256, device=gpu)
+    neck.forward_tokens(bb, tok)
+    assert torch.equal(tok.view(2, -1, 256), feat.flatten(2).permute(0, 2, 1))
+    with pytest.raises(ValueError):
+        neck.forward_tokens(bb, tok[:-1])
+    # the public switch
+    im = torch.rand(2, 640, 640, 3, generator=g).to(gpu)
+    fused = model.forward_dummy(im, im.flip(0))
+    model.hip_fuse_neck = False
+    plain = model.forward_dummy(im, im.flip(0))
+    # (two trunk runs: MIOpen's convolutions are not run-to-run bit-stable; box tolerance)
+    assert float((fused[0] - plain[0]).abs().max()) <= 5e-2 and float((fused[1] - plain[1]).abs().max()) <= 5e-2
+    # a tripped range flag sends the fused route through the stepwise one (here: raise)
+    model.hip_fuse_neck, model.hip_on_overflow = True, 'raise'
+    bb = model.backbone(torch.cat([im, im]))
+    with pytest.raises(pkg.OetrRangeError):
+        model.boxes_from_backbone(bb[:2] * 1e6, bb[2:] * 1e6, (640, 640), (640, 640))
+
+
 def test_training_forward_matches_the_reference_results(gpu, golden_dir):
     """``OETR.forward(data)`` on the HIP stages vs the result dict the
     REFERENCE model's forward produced on CPU for the same seeded weights and batch
