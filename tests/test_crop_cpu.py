@@ -78,3 +78,22 @@ def test_gate_and_geometry_edge_cases():
     assert geo[0]['crop'] == (10, 10) and geo[0]['box'] == (90, 90, 120, 130)
     assert geo[0]['new'] == (100, 100) and geo[0]['out'] == (104, 104)
     assert geo[1]['ratio'] == (2.0, 2.0) and geo[1]['out'] == (104, 104)
+
+
+def test_bicubic_agrees_with_an_independent_implementation():
+    """cv2 is not installed, so OpenCV's own output cannot pin :func:`bicubic_resize`; what
+    can be checked is that the restatement agrees with an INDEPENDENT implementation of the
+    same published algorithm - torch's ``F.interpolate(mode='bicubic',
+    align_corners=False)``: cubic convolution with a = -0.75, pixel centres
+    ``(d + 0.5) * scale - 0.5``, taps clamped to the border, no antialiasing.  The two
+    differ only in fp32 rounding (torch evaluates all four tap polynomials, OpenCV gets the
+    fourth as 1 - the others; separable passes in the other order): observed <= 7e-4 on
+    the 0..255 scale the reference resizes on (3e-6 relative), up- and down-scaling."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    for h, w, nh, nw in ((13, 17, 31, 23), (40, 50, 20, 25), (33, 21, 64, 64), (64, 48, 17, 5), (7, 9, 7, 30)):
+        img = (rng.random((h, w, 3)) * 255).astype(np.float32)
+        ours = cro.bicubic_resize(img, nw, nh)
+        ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(nh, nw), mode='bicubic',
+                            align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(ours - ref).max() <= 2e-3, (h, w, nh, nw, np.abs(ours - ref).max())
