@@ -1089,8 +1089,10 @@ oetr_status neck_forward_impl(oetr_neck_handle h, const float* backbone_feat, in
     items += cs.nsplit * cs.nhalf;
   }
   cp.items_per_mt = items;
-  cp.row_window = h->conv_kernel == 0 ? g.wo >= NECK_RW_MIN_WO : h->conv_kernel == 2;
-  if (cp.row_window)   // no 256-row shape (it spills); 192 rows measured best at every size tried
+  // auto: the row-window kernel in its one-wave-per-SIMD shape (fastest at every size tried)
+  cp.row_window = h->conv_kernel == 0 ? (g.wo >= NECK_RW_MIN_WO ? 2 : 0)
+                                      : (h->conv_kernel == 3 ? 2 : h->conv_kernel == 2);
+  if (cp.row_window)   // no 256-row shapes (they spill); 192 rows measured best at every size tried
     cp.mt_rows = h->conv_rows > 0 ? min(h->conv_rows, 192) : (g.M > 128 ? 192 : 128);
   else
     cp.mt_rows = h->conv_rows > 0 ? h->conv_rows : neck_conv_rows(g.M, items, h->num_cus, 256);
@@ -1152,8 +1154,8 @@ oetr_status oetr_neck_query_flags(oetr_neck_handle h, void* stream, uint32_t* fl
 
 oetr_status oetr_neck_set_conv_kernel(oetr_neck_handle h, int kind) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_set_conv_kernel: NULL handle");
-  if (kind < 0 || kind > 2)
-    return fail(OETR_ERR_BAD_ARG, "oetr_neck_set_conv_kernel: kind must be 0 (auto), 1 (gather) or 2 (row window)");
+  if (kind < 0 || kind > 3)
+    return fail(OETR_ERR_BAD_ARG, "oetr_neck_set_conv_kernel: kind must be 0 (auto), 1 (gather), 2 (row window) or 3 (row window, one wave per SIMD)");
   h->conv_kernel = kind;
   return OETR_OK;
 }

@@ -135,6 +135,9 @@ struct ConvB { f32x4 h, l; };                  // one k16-step of B fragments (h
 #ifndef NECK_RW_SLICE_MAJOR
 #define NECK_RW_SLICE_MAJOR 0   // the row-window kernel's work-item order (see k_neck_conv_rw)
 #endif
+#ifndef NECK_RING8
+#define NECK_RING8 0   // 8-deep weight ring in the one-wave-per-SIMD shape: measured slower (433 vs 414 us)
+#endif
 #ifndef NECK_SPREAD
 #define NECK_SPREAD 0   // 1: issue the next stage's gather passes between the k16 steps (measured slower: 460 vs 441 us)
 #endif
@@ -322,20 +325,27 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
 // Needs wo >= 16 (narrower maps touch too many rows per tile for the LDS / register budget).
 constexpr int RW_ENT = 144;   // staged entry: 32 channels hi 64 B | lo 64 B | pad 16 B
 static_assert(RW_ENT % 16 == 0 && (RW_ENT / 4) % 32 == 4, "conflict-free b128 entry stride");
-template <int RTW> struct RwShape {
-  static constexpr int MT = 64 * RTW;
+// RTW = 32-row MFMA tiles per wave, NW = waves per workgroup: 8 (two per SIMD; wave = n-tile
+// x row half) or 4 (one per SIMD with up to 512 registers; wave = n-tile over ALL the
+// workgroup's rows - every weight fragment is fetched once per workgroup, not twice).
+template <int RTW, int NW> struct RwShape {
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int MT = 32 * RTW * (NW / 4);
+  static constexpr int EPP = THREADS / 8;                             // entries per staging pass
   static constexpr int NE_MAX = MT + 7 * (MT / NECK_RW_MIN_WO + 2);   // 8 taps, wo >= NECK_RW_MIN_WO
-  static constexpr int NPASS = (NE_MAX + 63) / 64;                    // 64 entries per staging pass
+  static constexpr int NPASS = (NE_MAX + EPP - 1) / EPP;
   static constexpr int BUF = NE_MAX * RW_ENT;
 };
 
 // One body for the three kernel sizes: taps / rows-per-slice are run-time values and
 // the k16 steps of a stage run as ks/4 groups of four (the depth of the weight ring).
-template <int RTW>
-__global__ __launch_bounds__(512) void k_neck_conv_rw(NeckConvLaunch p) {
-  constexpr int MT = 64 * RTW, HALF_ROWS = 32 * RTW, NPASS = RwShape<RTW>::NPASS, BUF = RwShape<RTW>::BUF;
+template <int RTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
+  using SH = RwShape<RTW, NW>;
+  constexpr int MT = SH::MT, HALF_ROWS = 32 * RTW, NPASS = SH::NPASS, BUF = SH::BUF, EPP = SH::EPP,
+                THREADS = SH::THREADS;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  __shared__ int2 ent[RwShape<RTW>::NE_MAX];
+  __shared__ int2 ent[SH::NE_MAX];
   const NeckGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
   const int nt = wave & 3, rh = wave >> 2;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(512) void k_neck_conv_rw(NeckConvLaunch p) {
   const int ox_plast = plast - (plast / g.wo) * g.wo;
   // row 0 from ox_p0, full middle rows, the last row only up to the tile's last position
   const int NE = nrows == 1 ? ox_plast - ox_p0 + taps : n0 + (nrows - 2) * per_row + ox_plast + taps;
-  for (int e = tid; e < NE; e += 512) {
+  for (int e = tid; e < NE; e += THREADS) {
     int r = 0, c = e;
     if (e >= n0) { r = 1 + (e - n0) / per_row; c = (e - n0) - (r - 1) * per_row; }
     const int grow = row0 + r;                      // output row over all images (< n_img * ho)
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(512) void k_neck_conv_rw(NeckConvLaunch p) {
     const int ky = split * nky + (s >> 4), par = (s >> 3) & 1;
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
-      const int2 info = ent[min(q * 64 + eslot, NE - 1)];
+      const int2 info = ent[min(q * EPP + eslot, NE - 1)];
       const int iy = (info.y >> 16) - 64 + ky, ix = (info.y & 0xffff) - 64 + par;
       const bool ok = (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
       const int m = -(int)ok;
@@ -424,16 +434,12 @@ __global__ __launch_bounds__(512) void k_neck_conv_rw(NeckConvLaunch p) {
     if (NECK_ABL & 8) return;
 #pragma unroll
     for (int q = 0; q < NPASS; ++q)
-      *reinterpret_cast<f32x4*>(dst + min(q * 64 + eslot, NE - 1) * RW_ENT) = sreg[q];
+      *reinterpret_cast<f32x4*>(dst + min(q * EPP + eslot, NE - 1) * RW_ENT) = sreg[q];
   };
 
   f32x16 acc[RTW], cross[RTW];
 #pragma unroll
   for (int t = 0; t < RTW; ++t) { acc[t] = f32x16{0}; cross[t] = f32x16{0}; }
-  ConvB bf[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) { bf[kk].h = wh[kk * 64]; bf[kk].l = wl[kk * 64]; }
-
   stage_load(0); stage_write(0);
   __syncthreads();
 
@@ -443,7 +449,13 @@ __global__ __launch_bounds__(512) void k_neck_conv_rw(NeckConvLaunch p) {
   // every staging store (vmcnt(0) at each stage end - a third of the kernel's time).
   auto stages = [&](auto gr_tag) {
     constexpr int GR = decltype(gr_tag)::value, KSTEPS = 4 * GR;
-    int gstep = 4;                                  // next k16 step to fetch into the ring
+    // weight ring: RING k16 steps in flight (a divisor of KSTEPS, so slots are static);
+    // the one-wave-per-SIMD shape has the registers - and no second wave - for 8
+    constexpr int RING = (NW == 4 && GR >= 2 && NECK_RING8) ? 8 : 4;
+    ConvB bf[RING];
+#pragma unroll
+    for (int kk = 0; kk < RING; ++kk) { bf[kk].h = wh[kk * 64]; bf[kk].l = wl[kk * 64]; }
+    int gstep = RING;                               // next k16 step to fetch into the ring
     for (int s = 0; s < nstg; ++s) {
       const int cur = s & 1;
       const char* abase = smem + cur * BUF;
@@ -461,7 +473,7 @@ __global__ __launch_bounds__(512) void k_neck_conv_rw(NeckConvLaunch p) {
 #pragma unroll
       for (int st = 0; st < KSTEPS; ++st) {         // tap st >> 1, 16-channel step st & 1
         constexpr int dummy = 0; (void)dummy;
-        const int kk = st & 3;
+        const int kk = st & (RING - 1);
         const f16x8 bh = __builtin_bit_cast(f16x8, bf[kk].h), bl = __builtin_bit_cast(f16x8, bf[kk].l);
         const int nxt = ((st + 1) >> 1) * RW_ENT + ((st + 1) & 1) * 32;   // the k16 step after this one
 #pragma unroll
@@ -536,9 +548,17 @@ int neck_conv_rows(int M, int items_per_mt, int num_cus, int max_rows) {
 hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s) {
   const dim3 grid(p.nblocks), block(512);
   if (p.row_window) {   // (the 256-row shape of this kernel spills - 107 VGPRs - and is not built)
+    if (p.row_window == 2) {   // one wave per SIMD (its 256-row shape needs 256 + 256 registers and spills: not built)
+      switch (p.mt_rows) {
+        case 192: hipLaunchKernelGGL((k_neck_conv_rw<6, 4>), grid, dim3(256), 0, s, p); break;
+        case 128: hipLaunchKernelGGL((k_neck_conv_rw<4, 4>), grid, dim3(256), 0, s, p); break;
+        default: return hipErrorInvalidValue;
+      }
+      return hipGetLastError();
+    }
     switch (p.mt_rows) {
-      case 192: hipLaunchKernelGGL((k_neck_conv_rw<3>), grid, block, 0, s, p); break;
-      case 128: hipLaunchKernelGGL((k_neck_conv_rw<2>), grid, block, 0, s, p); break;
+      case 192: hipLaunchKernelGGL((k_neck_conv_rw<3, 8>), grid, block, 0, s, p); break;
+      case 128: hipLaunchKernelGGL((k_neck_conv_rw<2, 8>), grid, block, 0, s, p); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

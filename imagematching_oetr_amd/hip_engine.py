@@ -680,10 +680,11 @@ class NeckEngine:
         _check(self.lib, self.lib.oetr_neck_set_conv_rows(self._h, int(rows or 0)),
                'oetr_neck_set_conv_rows')
 
-    CONV_KERNELS = {'auto': 0, 'gather': 1, 'row_window': 2}
+    CONV_KERNELS = {'auto': 0, 'gather': 1, 'row_window': 2, 'row_window_1w': 3}
 
     def set_conv_kernel(self, kind):
-        """'auto' (row window when the output map is >= 16 wide), 'gather' or 'row_window'."""
+        """'auto' (= 'row_window_1w' when the output map is >= 16 wide, else 'gather'),
+        'gather', 'row_window' (two waves per SIMD) or 'row_window_1w' (one, AGPR accumulators)."""
         _check(self.lib, self.lib.oetr_neck_set_conv_kernel(self._h, self.CONV_KERNELS[kind or 'auto']),
                'oetr_neck_set_conv_kernel')
 

@@ -336,11 +336,13 @@ oetr_status oetr_neck_forward_tokens(oetr_neck_handle h,
  * size), or 256 / 192 / 128.  Results are identical in every shape (same summation
  * order per output).  Mutates the handle. */
 oetr_status oetr_neck_set_conv_rows(oetr_neck_handle h, int rows);
-/* Which PatchMerging conv kernel runs: 0 = auto (default: the row-window kernel when the
- * output map is at least 16 wide, else the gather kernel), 1 = gather (one input pixel
- * per output position per kernel pixel), 2 = row window (each input row segment staged
- * once per kernel row and x parity; needs wo >= 16, else OETR_ERR_BAD_SHAPE at forward).
- * The two sum the same products in a different order (fp32 rounding-level differences).
+/* Which PatchMerging conv kernel runs: 0 = auto (default: kind 3 when the output map is
+ * at least 16 wide, else the gather kernel), 1 = gather (one input pixel per output
+ * position per kernel pixel), 2 = row window (each input row segment staged once per
+ * kernel row and x parity; needs wo >= 16, else OETR_ERR_BAD_SHAPE at forward), 3 = row
+ * window with one wave per SIMD (4-wave workgroups, accumulators in AGPRs: each weight
+ * fragment fetched once per workgroup; bit-identical to kind 2).  Gather and row window
+ * sum the same products in a different order (fp32 rounding-level differences).
  * Mutates the handle. */
 oetr_status oetr_neck_set_conv_kernel(oetr_neck_handle h, int kind);
 /* Status word of the neck handle (see oetr_query_flags): OETR_FLAG_F16_RANGE when a

@@ -55,7 +55,7 @@ def test_neck_conv_kernels_agree(gpu, n, hb, wb):
     ref = orc.neck(bb.double(), {k: v.double() for k, v in w.items()})
     eng = pkg.NeckEngine(w, device=gpu)
     outs = {}
-    for kind in ('gather', 'row_window'):
+    for kind in ('gather', 'row_window', 'row_window_1w'):
         eng.set_conv_kernel(kind)
         for rows in (0, 192, 128):
             eng.set_conv_rows(rows)
@@ -64,6 +64,7 @@ def test_neck_conv_kernels_agree(gpu, n, hb, wb):
             assert err <= FEAT_TOL, f'{kind}/{rows}: feat max err {err:.3e}'
             assert torch.equal(outs.setdefault(kind, feat.clone()), feat), f'{kind}: rows={rows} changed the result'
     assert (outs['gather'] - outs['row_window']).abs().max().item() <= 1e-5
+    assert torch.equal(outs['row_window'], outs['row_window_1w'])   # same step order per output
 
 
 def test_neck_row_window_needs_wide_maps(gpu):

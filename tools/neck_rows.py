@@ -14,8 +14,8 @@ for n, hb in ((16, 40), (64, 40), (16, 64), (2, 80)):
     eng = pkg.NeckEngine({k: v for k, v in model.state_dict().items() if k in pkg.neck_keys()}, device=dev)
     refs = {}
     line = f'n={n} {hb}x{hb}:'
-    for kind, rows in [(k, r) for _ in range(2) for k in ('gather', 'row_window') for r in (256, 192, 128, 0)]:
-        if kind == 'row_window' and rows == 256:
+    for kind, rows in [(k, r) for _ in range(2) for k in ('gather', 'row_window', 'row_window_1w') for r in (256, 192, 128, 0)]:
+        if kind != 'gather' and rows == 256:
             continue
         eng.set_conv_kernel(kind)
         eng.set_conv_rows(rows)
@@ -29,5 +29,5 @@ for n, hb in ((16, 40), (64, 40), (16, 64), (2, 80)):
         ref = refs.setdefault(kind, out.clone())
         assert torch.equal(out, ref), 'rows-per-workgroup changed the result'
         err = (out - refs['gather']).abs().max().item() / refs['gather'].abs().max().item()
-        line += f'  {kind[:2]}/{rows or "auto"}: {ks["k_neck_conv"]:.1f} us (d={err:.1e})'
+        line += f'  {kind[:2] + kind[-2:] if kind.endswith("1w") else kind[:2]}/{rows or "auto"}: {ks["k_neck_conv"]:.1f} us (d={err:.1e})'
     print(line, flush=True)

@@ -18,6 +18,7 @@ engines = {}
 for name in names:
     hip_engine._lib = hip_engine.load_library(str(REPO / 'tools' / 'variants' / name / 'liboetr_hip.so'))
     engines[name] = pkg.NeckEngine(w, device=dev)
+    engines[name].set_conv_kernel(os.environ.get('KIND', 'auto'))   # gather | row_window | row_window_1w
 acc = {k: {} for k in names}
 for rnd in range(3):
     for name in names:
