@@ -918,7 +918,8 @@ bool make_neck_geom(int n_img, int hb, int wb, NeckGeom* g) {
   if (n_img <= 0 || hb < 2 || wb < 2 || hb > 400 || wb > 400) return false;
   const long lo = (long)(hb / 2) * (wb / 2);
   if (lo > OETR_MAX_TOKENS) return false;
-  if ((long)n_img * hb * wb > (1L << 30) / C || n_img >= (1 << 13)) return false;
+  // (32-bit byte offsets into X: (rows_in + 1) rows of 1024 B must stay below 2^32)
+  if ((long)n_img * hb * wb > (1L << 22) - 2 || n_img >= (1 << 13)) return false;
   g->n_img = n_img; g->hb = hb; g->wb = wb; g->ho = hb / 2; g->wo = wb / 2;
   g->HW = hb * wb;
   g->rows_in = n_img * g->HW;
@@ -939,9 +940,12 @@ NeckWorkspace neck_carve(const NeckGeom& g, void* base) {
     off += (bytes + 255) & ~size_t(255);
     return p;
   };
-  const size_t plane = ((size_t)g.rows_in + 1) * C * sizeof(_Float16);
-  w.xh = reinterpret_cast<_Float16*>(take(plane));
-  w.xl = reinterpret_cast<_Float16*>(take(plane));
+  // X: per input pixel (+ one all-zero padding row) eight 128-byte chunks
+  // [32 channels hi | 32 channels lo] - what one conv stage gathers per pixel is one
+  // cache line.  xl = xh + 32 halves: "the lo plane" of the same buffer.
+  const size_t xbytes = ((size_t)g.rows_in + 1) * NECK_XROW * sizeof(_Float16);
+  w.xh = reinterpret_cast<_Float16*>(take(xbytes));
+  w.xl = w.xh ? w.xh + 32 : nullptr;
   for (int i = 0; i < 3; ++i)
     w.part[i] = reinterpret_cast<float*>(
         take((size_t)kNeckConv[i].nsplit * g.M * kNeckConv[i].cout * sizeof(float)));

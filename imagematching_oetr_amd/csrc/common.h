@@ -1071,6 +1071,7 @@ hipError_t launch_boxes(const float* cxy, const float* tlbr, int n, int max_h, i
 constexpr int BBC = 1024;        // backbone (ResNet layer3) channels
 constexpr int NECK_MT = 256;     // output positions per conv workgroup (largest shape; 192 / 128 too)
 constexpr int NECK_PIX = 16;     // kernel pixels per conv workgroup (its K slice = 16 * 256)
+constexpr int NECK_XROW = 2 * C;    // halves per pixel of the neck's X buffer: 8 chunks of [32 hi | 32 lo]
 constexpr int NECK_RW_MIN_WO = 16;  // narrowest output map the row-window conv kernel takes
 struct NeckGeom {
   int n_img, hb, wb, ho, wo;

@@ -76,8 +76,7 @@ __global__ __launch_bounds__(512) void k_neck_proj(NeckProjLaunch p) {
   if (tid < 2 * C) par[tid] = tid < C ? p.ln_w[tid] : p.ln_b[tid - C];
   if (blockIdx.x == 0 && tid < 64) {  // the padding row of both planes
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4* zr = reinterpret_cast<f32x4*>((tid < 32 ? p.xh : p.xl) + (size_t)g.rows_in * C);
-    zr[tid & 31] = z;
+    reinterpret_cast<f32x4*>(p.xh + (size_t)g.rows_in * NECK_XROW)[tid] = z;   // 64 x 16 B = one X row
   }
   f32x16 acc[1];
   {
@@ -110,7 +109,11 @@ __global__ __launch_bounds__(512) void k_neck_proj(NeckProjLaunch p) {
     const f32x4* gb = reinterpret_cast<const f32x4*>(par + C) + lpart;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      store_split4(p.xh + row * C, p.xl + row * C, 4 * (i * 16 + lpart), xn[i] * gw[i * 16] + gb[i * 16], rg);
+    {   // channel c -> chunk c >> 5: hi at halves 64*(c>>5) + (c&31), lo 32 further
+      const int c = 4 * (i * 16 + lpart);
+      _Float16* hrow = p.xh + row * NECK_XROW + (c >> 5) * 32;   // (+ c inside store_split4)
+      store_split4(hrow, hrow + 32, c, xn[i] * gw[i * 16] + gb[i * 16], rg);
+    }
   }
   range_report<GM_SPLIT>(rg, p.flags);
 }
@@ -186,7 +189,9 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
 
   // ---- staging role: 16 lanes per input row (8 x 16 B of X_hi, 8 of X_lo) ----
   const int slot = tid & 15;
-  const f32x4* xplane = reinterpret_cast<const f32x4*>(slot < 8 ? p.xh : p.xl) + (slot & 7);
+  // piece j = slot & 7 (8 channels) of a 64-channel quarter sits in chunk j >> 2 at 16-byte
+  // unit j & 3, its lo half 4 units further (X layout: api.hip neck_carve)
+  const f32x4* xplane = reinterpret_cast<const f32x4*>(p.xh) + ((slot & 7) >> 2) * 8 + (slot & 3) + (slot < 8 ? 0 : 4);
   // per output row: {index of its window origin in X (may be negative), (iy0+64)<<16 | ix0+64}
   // kept in LDS - eight rows' worth of loop-invariant registers would not fit
   if (tid < MT) {
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
     const bool ok = (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
     const int m = -(int)ok;  // branch-free select (a branch here serialises the row-info reads)
     const int row = ((info.x + ky * g.wb + kx) & m) | (g.rows_in & ~m);
-    return (size_t)row * 32 + cq * 8;  // 16-byte units: 256 halves per row, 64 per quarter
+    return (size_t)row * 64 + cq * 16;  // 16-byte units: 64 per pixel, 16 per 64-channel quarter
   };
   f32x4 sreg[RTW] = {};
   auto stage_load = [&](int s, int jh) {  // rows (tid>>4) + 32*(RTW*jh + j), j < RTW, of stage s -> registers
@@ -398,12 +403,8 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
 
   // ---- staging role: 8 lanes per entry (4 x 16 B of X_hi, 4 of X_lo) ----
   const int piece = tid & 7, eslot = tid >> 3;
-  // (the per-lane plane select is an offset from X_hi, not a select between the two
-  //  pointers: hipcc fetches a selected kernel argument with a per-lane global load, and
-  //  that pending load haunts the stage loop's wait counts)
-  const char* xh_bytes = reinterpret_cast<const char*>(p.xh);
-  const long plane_delta = reinterpret_cast<const char*>(p.xl) - xh_bytes;
-  const char* xplane = xh_bytes + (piece < 4 ? 0L : plane_delta) + (piece & 3) * 16;
+  // a stage's 32-channel chunk of a pixel is 128 contiguous bytes [hi | lo]: piece = 16-byte unit
+  const char* xplane = reinterpret_cast<const char*>(p.xh) + piece * 16;
   f32x4 sreg[NPASS] = {};
   // Gather addresses depend on (ky, x parity) only - the eight 32-channel chunks of one
   // (ky, parity) are 64 B apart - so they are worked out once per eight stages.
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
       const bool ok = (unsigned)iy < (unsigned)g.hb && (unsigned)ix < (unsigned)g.wb;
       const int m = -(int)ok;
       const int row = ((info.x + ky * g.wb + par) & m) | (g.rows_in & ~m);
-      src[q] = (unsigned)row * 512u;                // rows_in * 512 < 2^31 (make_neck_geom)
+      src[q] = (unsigned)row * 1024u;               // (rows_in + 1) * 1024 <= 2^32 (make_neck_geom)
     }
   };
   // (every load in the main loop is unconditional - indices clamped instead: a load behind
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
   auto stage_load = [&](int s) {                    // prologue only: every pass at once
     stage_addr(s);
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q) sreg[q] = *reinterpret_cast<const f32x4*>(xplane + src[q] + (s & 7) * 64);
+    for (int q = 0; q < NPASS; ++q) sreg[q] = *reinterpret_cast<const f32x4*>(xplane + src[q] + (s & 7) * 128);
   };
   // (unconditional stores too: lanes past the last entry hold its data - the clamped table
   //  read above - and rewrite it; a store under a lane mask is a branch to the wait counter)
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
       const char* abase = smem + cur * BUF;
       // the next stage's gathers go out after the first k16 step (NECK_SPREAD: one pass at
       // a time between the steps instead - slower); the last stage re-stages itself: unused
-      const int sn = min(s + 1, nstg - 1), cqn = (sn & 7) * 64;
+      const int sn = min(s + 1, nstg - 1), cqn = (sn & 7) * 128;
       if ((sn & 7) == 0) stage_addr(sn);
       f32x4 ah[RTW], al[RTW];
 #pragma unroll
