@@ -339,7 +339,12 @@ template <int RTW, int NW> struct RwShape {
   static constexpr int EPP = THREADS / 8;                             // entries per staging pass
   static constexpr int NE_MAX = MT + 7 * (MT / NECK_RW_MIN_WO + 2);   // 8 taps, wo >= NECK_RW_MIN_WO
   static constexpr int NPASS = (NE_MAX + EPP - 1) / EPP;
-  static constexpr int BUF = NE_MAX * RW_ENT;
+  // LDS slots: every output row's run of entries is padded so that the FIRST position of the
+  // next row lands 17 slots after the LAST of this one (1 mod 16): the 32 positions of an
+  // MFMA row tile then keep distinct slot indices mod 16 across row breaks and their
+  // ds_read_b128 stay conflict-free (unpadded: 37 M conflict cycles per launch)
+  static constexpr int SLOT_MAX = MT + 16 * (MT / NECK_RW_MIN_WO + 2);
+  static constexpr int BUF = SLOT_MAX * RW_ENT;
 };
 
 // One body for the three kernel sizes: taps / rows-per-slice are run-time values and
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
   const int ox_plast = plast - (plast / g.wo) * g.wo;
   // row 0 from ox_p0, full middle rows, the last row only up to the tile's last position
   const int NE = nrows == 1 ? ox_plast - ox_p0 + taps : n0 + (nrows - 2) * per_row + ox_plast + taps;
+  const int padx = 17 - taps;                       // slot(e) = e + row(e) * padx
   for (int e = tid; e < NE; e += THREADS) {
     int r = 0, c = e;
     if (e >= n0) { r = 1 + (e - n0) / per_row; c = (e - n0) - (r - 1) * per_row; }
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
     const int pos = min(p0 + HALF_ROWS * rh + 32 * t + col, plast);
     const int grow = pos / g.wo, ox = pos - grow * g.wo, r = grow - row0;
     const int e0 = r == 0 ? ox - ox_p0 : n0 + (r - 1) * per_row + ox;
-    aoff[t] = e0 * RW_ENT + 16 * half;
+    aoff[t] = (e0 + r * padx) * RW_ENT + 16 * half;
   }
   __syncthreads();
 
@@ -430,12 +436,18 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
   };
   // (unconditional stores too: lanes past the last entry hold its data - the clamped table
   //  read above - and rewrite it; a store under a lane mask is a branch to the wait counter)
+  int woff[NPASS];                                  // LDS byte offset of this thread's piece per pass
+#pragma unroll
+  for (int q = 0; q < NPASS; ++q) {
+    const int e = min(q * EPP + eslot, NE - 1);
+    const int r = e < n0 ? 0 : 1 + (e - n0) / per_row;
+    woff[q] = (e + r * padx) * RW_ENT + piece * 16;
+  }
   auto stage_write = [&](int buf) {
-    char* dst = smem + buf * BUF + piece * 16;
+    char* dst = smem + buf * BUF;
     if (NECK_ABL & 8) return;
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q)
-      *reinterpret_cast<f32x4*>(dst + min(q * EPP + eslot, NE - 1) * RW_ENT) = sreg[q];
+    for (int q = 0; q < NPASS; ++q) *reinterpret_cast<f32x4*>(dst + woff[q]) = sreg[q];
   };
 
   f32x16 acc[RTW], cross[RTW];
