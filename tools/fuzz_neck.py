@@ -19,11 +19,15 @@ for case in range(ncase):
         engines[ws] = (engines[ws][0], pkg.NeckEngine(engines[ws][0], device=dev))
     w, eng = engines[ws]
     n, hb, wb = rng.randrange(1, 5), rng.randrange(2, 48), rng.randrange(2, 48)
+    if case % 3 == 0:      # wide maps: the row-window conv kernel (output map >= 16 wide)
+        wb = rng.randrange(32, 130)
+    kind = ('auto', 'row_window', 'row_window_1w', 'gather')[case % 4] if wb // 2 >= 16 else 'auto'
+    eng.set_conv_kernel(kind)
     bb = orc.make_backbone_features(5000 + case, n, hb, wb)
     out = eng.forward(bb.to(dev)).cpu()
     ref = orc.neck(bb, w)
     e = (out - ref).abs().max().item()
     ok = e <= 5e-5 and out.shape == ref.shape
     bad += not ok
-    print(f'{"OK " if ok else "BAD"} case {case}: n={n} {hb}x{wb} err={e:.2e}', flush=True)
+    print(f'{"OK " if ok else "BAD"} case {case}: n={n} {hb}x{wb} {kind} err={e:.2e}', flush=True)
 print(f'{bad} bad of {ncase}')
