@@ -181,6 +181,20 @@ def test_neck_stores_tokens_straight_into_the_hot_path(gpu):
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), ((h1, w1), (h2, w2))
         again = model.boxes_from_backbone(bb1, bb2, (h1, w1), (h2, w2), both=both)   # tables cached
         assert torch.equal(again[0], want[0]) and torch.equal(again[1], want[1])
+    # every arithmetic / attention mode of the hot path takes the resident tokens the same way
+    im1 = torch.rand(2, 480, 640, 3, generator=g).to(gpu)
+    im2 = torch.rand(2, 480, 640, 3, generator=g).to(gpu)
+    bb = model.backbone(torch.cat([im1, im2]))
+    for prec, attn in (('f32', 'linear'), ('bf16', 'linear'), ('f16', 'linear'), ('f32_split_f16', 'full')):
+        model.hip_precision, model.hip_attention = prec, attn
+        model.invalidate_engine()
+        eng, neck = model.engine(), model.neck_engine()
+        want = stepwise(bb[:2].contiguous(), bb[2:].contiguous(), (480, 640), (480, 640))
+        got = model.boxes_from_backbone(bb[:2], bb[2:], (480, 640), (480, 640), both=bb)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (prec, attn)
+    model.hip_precision, model.hip_attention = 'f32_split_f16', 'linear'
+    model.invalidate_engine()
+    eng, neck = model.engine(), model.neck_engine()
     # the neck's token-major store is its NCHW result transposed, bit for bit
     bb = model.backbone(torch.rand(2, 480, 640, 3, generator=g).to(gpu))
     feat = neck.forward(bb)
