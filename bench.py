@@ -221,7 +221,7 @@ def mangled_encoder(tile, mode_id):
     return f'k_encoderILb1ELi0ELi{mode_id}ELi{4 if mode_id == 0 else 8}ELb0EE'
 
 
-def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload, extra_flop=0):
+def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload, extra_flop=0, grids=None):
     if not kern or DOMINANT not in kern:
         return None
     launches, total_ms = kern[DOMINANT]
@@ -240,6 +240,14 @@ def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_work
         'avg_launch_us': round(avg_ms * 1e3, 2), 'launches': launches, 'flop_per_launch': flop,
         'share_of_step': round(total_ms / (traced_s * 1e3), 4),
         'traced_ms_per_step': round(traced_s / steps * 1e3, 4)}
+    if grids:   # one workgroup per CU (LDS): how much of the chip a launch of this batch can occupy
+        n_pairs, l1, l2 = grids
+        wgs = n_pairs * (-(-l1 // tile) + -(-l2 // tile))
+        block['workgroups_per_launch'] = wgs
+        block['cu_share'] = round(min(wgs, 256) / 256, 4)
+        block['note'] = ('frac is this kernel ALONE on the chip; its launch has %d workgroups for 256 CUs '
+                         '(one per CU), the overlapped streams fill the rest - the chip-level figure is '
+                         'hot_path_frac_of_mfma_peak' % wgs)
     traffic, src = (pmc_traffic(mangled_encoder(tile, MODE_ID[precision]))
                     if standard_workload else (None, None))
     block['traffic'] = traffic
@@ -475,14 +483,16 @@ def main():
                      'ms_per_step_max': round(s_max / args.steps * 1e3, 4)}
     if 'trace_overlap_shape' in main_res:
         kern, t_s = main_res['trace_overlap_shape']
-        rb = roofline_block(kern, args.precision, tokens, tile_overlap or 32, args.steps, t_s, standard, extra_flop)
+        rb = roofline_block(kern, args.precision, tokens, tile_overlap or 32, args.steps, t_s, standard, extra_flop,
+                            grids=(n, hf * hf, hf2 * hf2))
         if rb:
             out['roofline'] = rb
             out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
                                  for k, v in kern.items()}
     if 'trace_serial_shape' in main_res:
         kern, t_s = main_res['trace_serial_shape']
-        rb = roofline_block(kern, args.precision, tokens, args.enc_tile or 32, args.steps, t_s, standard, extra_flop)
+        rb = roofline_block(kern, args.precision, tokens, args.enc_tile or 32, args.steps, t_s, standard, extra_flop,
+                            grids=(n, hf * hf, hf2 * hf2))
         if rb:
             out['serial']['roofline'] = rb
             out['serial']['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
