@@ -117,11 +117,11 @@ namespace oetr {
 int set_last_error(int status, const char* msg) { return fail((oetr_status)status, msg); }
 }  // namespace oetr
 
-enum KernelId { K_PREP, K_ENC_A, K_ENC_BA, K_ENC_BDEC, K_ENC_B, K_DECODER, K_HEAT_CONV,
+enum KernelId { K_ENC_A, K_ENC_BA, K_ENC_BDEC, K_ENC_B, K_DECODER, K_HEAT_CONV,
                 K_HEAT_FINAL, K_SIZE_REG, K_BOXES, K_DEC_CONVP, K_HEAT_COMBINE, K_NECK_PROJ,
                 K_NECK_CONV, K_NECK_OUT, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {
-    "k_prep_tokens", "k_encoder<A>", "k_encoder<B,A>", "k_encoder<B,dec>", "k_encoder<B>",
+    "k_encoder<A>", "k_encoder<B,A>", "k_encoder<B,dec>", "k_encoder<B>",
     "k_decoder", "k_heat_conv", "k_heat_final", "k_size_reg", "k_boxes", "k_decoder_convp",
     "k_heat_combine", "k_neck_proj", "k_neck_conv", "k_neck_out"};
 
@@ -316,9 +316,13 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
                             bool resident = false) {
   // resident: the caller (oetr_forward_tokens) already holds token-major features and
   // position tables in the workspace (oetr_token_buffers) - no transpose launch
-  if (!resident) TRACED(h, s, K_PREP, launch_prep_tokens(g, feat1, feat2, pos1, pos2, w.x, w.pos, s));
   EncLaunch p;
   memset(&p, 0, sizeof(p));
+  if (!resident) {   // the first launch transposes its tiles itself (round 1 had a k_prep_tokens launch for it)
+    p.feat_nchw[0] = feat1; p.feat_nchw[1] = feat2;
+    p.pos_nchw[0] = pos1; p.pos_nchw[1] = pos2;
+    p.pos_out = w.pos;
+  }
   p.tile_rows = encoder_tile_rows(h, g);
   p.g = encoder_geom(g, p.tile_rows);
 #ifdef OETR_ABLATE
@@ -341,6 +345,7 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   p.a = h->enc[0];
   p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];
   TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, h->mode, s));
+  p.feat_nchw[0] = p.feat_nchw[1] = p.pos_nchw[0] = p.pos_nchw[1] = nullptr;
   for (int l = 0; l < enc_layers; ++l) {
     p.b = h->enc[l];
     p.b_cross = l & 1;

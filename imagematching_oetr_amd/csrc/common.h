@@ -991,13 +991,18 @@ struct EncLaunch {
   int dbg;               // ablation flags (OETR_ABLATE builds only)
   long long* tbuf;       // per-phase cycle stamps (OETR_PHASE_TIMING builds only)
   uint32_t* flags;       // the handle's status word (FLAG_F16_RANGE), see Range
+  // First launch only (has_b == false): the inputs as the reference hands them over - NCHW
+  // features [N][256][L] and position windows [256][L] per side.  The launch then does the
+  // `flatten(2).permute(0, 2, 1)` of transformer.py:338-345 in its tile load (and writes x /
+  // the position table back token-major for the later launches) instead of a launch of its
+  // own.  NULL: x and pos already hold the token-major data (oetr_forward_tokens).
+  const float* feat_nchw[2];
+  const float* pos_nchw[2];
+  float* pos_out;        // = pos, writable (the token-major table the n == 0 tiles fill in)
 };
 
 // has_b: run phase B (finish a layer); tail: 0 = phase A of next encoder layer,
 // 1 = decoder K/V preparation, 2 = nothing.
-hipError_t launch_prep_tokens(const Geom& g, const float* feat1, const float* feat2,
-                              const float* pos1, const float* pos2, float* x,
-                              float* pos_tok, hipStream_t s);
 hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, int mode, hipStream_t s);
 
 struct MhaDev {

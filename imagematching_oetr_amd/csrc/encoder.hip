@@ -41,61 +41,6 @@
 namespace oetr {
 
 // ---------------------------------------------------------------------------
-// NCHW -> token-major transpose of the feature maps and position tables.
-// grid.x = (2N + 2) images * ceil(L/64) * 4 channel chunks.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep_tokens(Geom g, const float* __restrict__ feat1,
-                                                     const float* __restrict__ feat2,
-                                                     const float* __restrict__ pos1,
-                                                     const float* __restrict__ pos2,
-                                                     float* __restrict__ x,
-                                                     float* __restrict__ pos_tok) {
-  __shared__ float tile[64][65];
-  // decode block -> (image, l-chunk, c-chunk)
-  const int lch0 = (g.L[0] + 63) / 64, lch1 = (g.L[1] + 63) / 64;
-  const int per0 = lch0 * 4, per1 = lch1 * 4;
-  int b = blockIdx.x;
-  int side, img;  // img: 0..N-1 features, N = position table
-  const int side0_blocks = (g.N + 1) * per0;
-  if (b < side0_blocks) { side = 0; img = b / per0; b -= img * per0; }
-  else { b -= side0_blocks; side = 1; img = b / per1; b -= img * per1; }
-  const int L = g.L[side];
-  const int lc = b >> 2, cc = b & 3;
-  const float* src;
-  float* dst;
-  if (img < g.N) {
-    src = (side ? feat2 : feat1) + (size_t)img * C * L;
-    dst = x + (size_t)(g.row0[side] + img * L) * C;
-  } else {
-    src = side ? pos2 : pos1;
-    dst = pos_tok + (size_t)g.prow0[side] * C;
-  }
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int l = lc * 64 + tx;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = cc * 64 + ty * 16 + i;
-    tile[ty * 16 + i][tx] = (l < L) ? src[(size_t)c * L + l] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int ll = lc * 64 + ty * 16 + i;
-    if (ll < L) dst[(size_t)ll * C + cc * 64 + tx] = tile[tx][ty * 16 + i];
-  }
-}
-
-hipError_t launch_prep_tokens(const Geom& g, const float* feat1, const float* feat2,
-                              const float* pos1, const float* pos2, float* x,
-                              float* pos_tok, hipStream_t s) {
-  const int lch0 = (g.L[0] + 63) / 64, lch1 = (g.L[1] + 63) / 64;
-  const int blocks = (g.N + 1) * 4 * (lch0 + lch1);
-  hipLaunchKernelGGL(k_prep_tokens, dim3(blocks), dim3(256), 0, s, g, feat1, feat2, pos1,
-                     pos2, x, pos_tok);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
 // Fused  B(l) ; A(l+1)  kernel.
 // ---------------------------------------------------------------------------
 // LDS regions (floats).  S1/S2/H hold a GEMM A operand: an f32 tile [32][260]
@@ -219,6 +164,34 @@ __device__ __forceinline__ void load_tile(float* S, const float* __restrict__ sr
     const int r = idx >> 6, c4 = idx & 63;
     *reinterpret_cast<f32x4*>(S + r * LDA + 4 * c4) =
         reinterpret_cast<const f32x4*>(src + (size_t)min(r, nvalid - 1) * C)[c4];
+  }
+}
+
+// The same tile from the reference's layout: src -> element (channel 0, token l0) of an
+// image's [256][L] map; S[r][c] = src[c * L + r].  A half-wave reads 32 consecutive tokens
+// of one channel (128 B); the transposed LDS writes are 2-way conflicted (row stride 260).
+template <int THREADS, int ROWS>
+__device__ __forceinline__ void load_tile_nchw(float* S, const float* __restrict__ src, int L,
+                                               int nvalid, int tid) {
+  constexpr int CG = THREADS / ROWS;
+  const int r = tid % ROWS, cg = tid / ROWS;
+  const float* s = src + min(r, nvalid - 1);
+#pragma unroll
+  for (int i = 0; i < C / CG; ++i) {
+    const int c = cg + CG * i;
+    S[r * LDA + c] = s[(size_t)c * L];
+  }
+}
+// ... and back out token-major (rows of 1 KB): dst -> row l0 of a [L][256] table
+template <int THREADS, int ROWS>
+__device__ __forceinline__ void store_tile_tokens(float* __restrict__ dst, const float* S, int nvalid,
+                                                  int tid) {
+#pragma unroll
+  for (int i = 0; i < (ROWS * C / 4) / THREADS; ++i) {
+    const int idx = tid + THREADS * i;
+    const int r = idx >> 6, c4 = idx & 63;
+    if (r < nvalid)
+      reinterpret_cast<f32x4*>(dst + (size_t)r * C)[c4] = *reinterpret_cast<const f32x4*>(S + r * LDA + 4 * c4);
   }
 }
 
@@ -360,6 +333,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   const int nvalid = min(TM, L - l0);
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
+  const bool nchw = !HAS_B && p.feat_nchw[0] != nullptr;   // first launch on NCHW inputs (launch-uniform)
 
   // LayerNorm affines -> LDS once (the row-wise phases then issue no global loads
   // that would queue behind the weight stream's run-ahead fetches)
@@ -569,10 +543,19 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     __syncthreads();  // also: every wave is done reading Hh before S2 (alias) is written
     PHASE_STAMP(p, 6);
   } else {
-    load_tile<THREADS>(S0, p.x + row_base * C, nvalid, tid);  // first launch: x from HBM
+    if (nchw) {  // first launch, reference layout: transpose on the way in (S1 is free until phase A writes it)
+      load_tile_nchw<THREADS, TM>(S0, p.feat_nchw[side] + (size_t)n * C * L + l0, L, nvalid, tid);
+      load_tile_nchw<THREADS, TM>(smem + S1_OFF, p.pos_nchw[side] + l0, L, nvalid, tid);
+    } else {
+      load_tile<THREADS>(S0, p.x + row_base * C, nvalid, tid);  // first launch: x from HBM
+    }
     if (TAIL == 0) ws.template prime<C, P_T0>(p.a.wq, p.a.wq_l, NT * wave, lane);
     if (TAIL == 1) ws.template prime<C, P_T0>(p.d.wk[0], p.d.wk_l[0], NT * wave, lane);
     __syncthreads();
+    if (nchw) {  // token-major copies for the later launches (residual reads, position rows)
+      store_tile_tokens<THREADS, TM>(p.x + row_base * C, S0, nvalid, tid);
+      if (n == 0) store_tile_tokens<THREADS, TM>(p.pos_out + (size_t)(g.prow0[side] + l0) * C, smem + S1_OFF, nvalid, tid);
+    }
   }
 
   const f32x4* pos = reinterpret_cast<const f32x4*>(
@@ -581,17 +564,25 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     // ================= phase A: start layer l+1 =================
     // q_in = LN_q(x)+pos -> S1 ; kv_in = LN_kv(x)+pos -> S2 (one set of row stats)
     {
-      f32x4 xn[F4];
+      f32x4 xn[F4], ps[F4];
+      if (!HAS_B && nchw) {   // the position tile sits (f32, transposed on load) where S1 goes
+        const f32x4* pl = reinterpret_cast<const f32x4*>(smem + S1_OFF + lrow * LDA) + lpart;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) ps[i] = pl[i * TPR];
+      } else {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) ps[i] = pos[i * TPR];
+      }
       ln_rows<TPR, F4>(S0, tid, xn, p.dbg);
+      if (!HAS_B && nchw) __syncthreads();   // every thread holds its position values: S1 may be written
       const f32x4* qw = reinterpret_cast<const f32x4*>(lnp_s + 2 * C) + lpart;
       const f32x4* qb = reinterpret_cast<const f32x4*>(lnp_s + 3 * C) + lpart;
       const f32x4* kw = reinterpret_cast<const f32x4*>(lnp_s + 4 * C) + lpart;
       const f32x4* kb = reinterpret_cast<const f32x4*>(lnp_s + 5 * C) + lpart;
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
-        const f32x4 ps = pos[i * TPR];
-        S1.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * qw[i * TPR] + qb[i * TPR]) + ps);
-        S2.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * kw[i * TPR] + kb[i * TPR]) + ps);
+        S1.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * qw[i * TPR] + qb[i * TPR]) + ps[i]);
+        S2.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * kw[i * TPR] + kb[i * TPR]) + ps[i]);
       }
     }
     __syncthreads();
@@ -848,6 +839,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
   const int nvalid = min(RT, L - l0);
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
+  const bool nchw = !HAS_B && p.feat_nchw[0] != nullptr;   // first launch on NCHW inputs (launch-uniform)
   ws.set_rows(nvalid);
 
   for (int i = tid; i < 6 * C; i += THREADS) {
@@ -1072,24 +1064,39 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
       acc_to_lds<1>(R1f + mt * 32 * LDA, LDA, wcol, lane, *reinterpret_cast<f32x16(*)[1]>(&xacc[mt]));
     __syncthreads();
   } else {
+    if (nchw) {  // first launch, reference layout: transpose on the way in (R2 is free until phase A writes P2)
+      load_tile_nchw<THREADS, RT>(R1f, p.feat_nchw[side] + (size_t)n * C * L + l0, L, nvalid, tid);
+      load_tile_nchw<THREADS, RT>(R2f, p.pos_nchw[side] + l0, L, nvalid, tid);
+    } else {
 #pragma unroll
-    for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {  // first launch: x from HBM
-      const int idx = tid + THREADS * i;
-      const int r = idx >> 6, c4 = idx & 63;
-      *reinterpret_cast<f32x4*>(R1f + r * LDA + 4 * c4) =
-          reinterpret_cast<const f32x4*>(p.x + (row_base + min(r, nvalid - 1)) * C)[c4];
+      for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {  // first launch: x from HBM
+        const int idx = tid + THREADS * i;
+        const int r = idx >> 6, c4 = idx & 63;
+        *reinterpret_cast<f32x4*>(R1f + r * LDA + 4 * c4) =
+            reinterpret_cast<const f32x4*>(p.x + (row_base + min(r, nvalid - 1)) * C)[c4];
+      }
     }
     if (TAIL == 0) ws.template prime<C, P_T0>(p.a.wq, p.a.wq_l, wave, 0, lane);
     if (TAIL == 1) ws.template prime<C, P_T0>(p.d.wk[0], p.d.wk_l[0], wave, 0, lane);
     __syncthreads();
+    if (nchw) {  // token-major copies for the later launches (residual reads, position rows)
+      store_tile_tokens<THREADS, RT>(p.x + row_base * C, R1f, nvalid, tid);
+      if (n == 0) store_tile_tokens<THREADS, RT>(p.pos_out + (size_t)(g.prow0[side] + l0) * C, R2f, nvalid, tid);
+    }
   }
 
   if (TAIL == 0) {
     // ================= phase A: start layer l+1 =================
     {
       f32x4 xn[F4], ps[F4];
+      if (!HAS_B && nchw) {   // the position tile sits (f32, transposed on load) where P2 goes
+        const f32x4* pl = reinterpret_cast<const f32x4*>(R2f + lrow * LDA) + lpart;
 #pragma unroll
-      for (int i = 0; i < F4; ++i) ps[i] = pos[i * TPR];
+        for (int i = 0; i < F4; ++i) ps[i] = pl[i * TPR];
+      } else {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) ps[i] = pos[i * TPR];
+      }
       ln_rows<TPR, F4>(R1f, tid, xn, 0);
       __syncthreads();
       const f32x4* qw = reinterpret_cast<const f32x4*>(lnp_s + 2 * C) + lpart;
