@@ -13,18 +13,26 @@
 //
 //   k_neck_proj  32 positions per workgroup: NCHW gather -> LDS split planes,
 //                1x1 conv (K = 1024 in two halves, weights streamed as B
-//                fragments), LayerNorm, result stored token-major as two f16
-//                planes X_hi / X_lo (+ one all-zero row used as padding source).
-//   k_neck_conv  the three convs in ONE grid.  A workgroup owns 256 output
-//                positions x 128 output channels x 16 kernel pixels (K = 4096,
-//                split-K over the kernel window: 16 / 4 / 1 slices for k = 16 /
-//                8 / 4): per 64-channel stage the gathered input rows go
-//                through a double-buffered LDS tile, the weights straight from
-//                L2 into B-fragment registers one stage ahead; every weight
-//                fragment feeds four 32-row MFMA tiles.  Partials -> HBM.
+//                fragments), LayerNorm, result stored token-major as f16 hi / lo
+//                halves in X: per pixel eight 128-byte chunks [32 ch hi | 32 ch lo]
+//                (+ one all-zero row used as padding source).
+//   k_neck_conv_rw  (default) the three convs in ONE grid.  A workgroup owns 192
+//                output positions x 128 output channels x 16 kernel pixels
+//                (K = 4096, split-K over the kernel window: 16 / 4 / 1 slices for
+//                k = 16 / 8 / 4).  Row-window staging: per (kernel row, x parity,
+//                32-channel chunk) the pixels of the tile's output rows go once
+//                into a double-buffered LDS tile and tap tau reads it shifted by
+//                tau entries; weights straight from L2 into B-fragment registers
+//                four k16 steps ahead; one wave per SIMD, every weight fragment
+//                feeds six 32-row MFMA tiles (accumulators in AGPRs).  Partials
+//                -> HBM.
+//   k_neck_conv  the round-1 form (one gathered pixel per output position per
+//                kernel pixel, 64-channel stages, two waves per SIMD): kept for
+//                output maps narrower than 16 and as the A/B reference.
 //   k_neck_out   32 positions per workgroup: fixed-order sum of the partials +
 //                biases -> the 512-channel concat as split planes in LDS, 1x1
-//                conv 512 -> 256, transposed store to NCHW.
+//                conv 512 -> 256, transposed store to NCHW - or token-major
+//                straight into the hot path's workspace (oetr_neck_forward_tokens).
 #include <type_traits>
 #include "common.h"
 
