@@ -60,14 +60,22 @@ __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restri
 // workgroup) feeds two MFMA row tiles, and the weight stream runs ahead from tap to
 // tap.  Tiles are 64 consecutive tokens of one image: tile index over
 // N x (ceil(L0/64) + ceil(L1/64)), pair-major like the encoder's.
+// The nine taps of a tile are shared by CONVP_SPLIT workgroups (adjacent in the grid: the tile's
+// rows are staged by each, from L2): three times as many, shorter work items - at 8 pairs
+// 336 instead of 112, which fill the chip next to the decoder's 16 workgroups.
+#ifndef OETR_CONVP_SPLIT
+#define OETR_CONVP_SPLIT 1   // 3: measured slower (decoder_convp 53.5 -> 58.6 us: the decoder chain, the critical path of that launch, slows down under the extra streaming workgroups)
+#endif
+constexpr int CONVP_SPLIT = OETR_CONVP_SPLIT, CONVP_TAPS = 9 / CONVP_SPLIT;
 template <int MODE>
-__device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __restrict__ P, int tile,
+__device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __restrict__ P, int item,
                                               float* smem) {
   static_assert(16 % WStream2T<MODE>::D == 0, "tap loop below assumes a ring phase of 0 after every GEMM");
   constexpr int THREADS = 512, TPR = THREADS / RT, F4 = 64 / TPR;
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
   const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
+  const int tile = item / CONVP_SPLIT, tap0 = (item - tile * CONVP_SPLIT) * CONVP_TAPS;
   const int logical = xcd_remap(tile, g.N * (nt0 + nt1));
   const int per = nt0 + nt1;
   const int n = logical / per;
@@ -90,9 +98,9 @@ __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __rest
   }
   WStream2T<MODE> ws;
   ws.set_rows(nvalid);
-  ws.template prime<C, 0>(p.w.conv_w, p.w.conv_w_l, wave, 0, lane);
-  __syncthreads();
   constexpr size_t TAP_UNITS = (size_t)C * C / 8;
+  ws.template prime<C, 0>(p.w.conv_w + tap0 * TAP_UNITS, p.w.conv_w_l + tap0 * TAP_UNITS, wave, 0, lane);
+  __syncthreads();
   float* dst0 = P + row_base * C + 32 * wave + col + (size_t)4 * half * C;
   const int nv2 = nvalid - 4 * half;
   auto store = [&](int tap, const f32x16 (&acc)[2]) {
@@ -106,7 +114,7 @@ __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __rest
       }
   };
 #pragma unroll 1
-  for (int tap = 0; tap < 8; ++tap) {
+  for (int tap = tap0; tap < tap0 + CONVP_TAPS - 1; ++tap) {
     f32x16 acc[2] = {f32x16{0}, f32x16{0}};
     const f32x4* w = p.w.conv_w + tap * TAP_UNITS;
     const f32x4* wl = p.w.conv_w_l + tap * TAP_UNITS;
@@ -114,10 +122,12 @@ __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __rest
     store(tap, acc);
   }
   {
+    constexpr int dummy = 0; (void)dummy;
+    const int tap = tap0 + CONVP_TAPS - 1;
     f32x16 acc[2] = {f32x16{0}, f32x16{0}};
-    ws.template gemm<C, 0, false, C>(A, p.w.conv_w + 8 * TAP_UNITS, p.w.conv_w_l + 8 * TAP_UNITS, wave,
+    ws.template gemm<C, 0, false, C>(A, p.w.conv_w + tap * TAP_UNITS, p.w.conv_w_l + tap * TAP_UNITS, wave,
                                      0, lane, acc, nullptr, nullptr, 0, 0);
-    store(8, acc);
+    store(tap, acc);
   }
   range_report<MODE>(rg, p.flags);
 }

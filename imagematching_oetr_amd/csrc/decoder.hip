@@ -156,6 +156,9 @@ hipError_t launch_decoder_consts(const DecConstLaunch& p, hipStream_t s) {
 // been multiplied in, the NEXT batch (of this or the following stage - weights
 // do not depend on data) is issued into the same registers, so its L2 round trip
 // runs under the current stage's partial-sum exchange, barriers and LayerNorm.
+// (Two register sets / two batches in flight were tried in round 2: 48.9 vs 49.1 us for
+//  the chain alone - it runs at 45-50 B/clk, the fill rate of ONE CU's L1, for its 3.9 MB
+//  of fp32 weights per image; only more CUs per image would shorten it.)
 template <int T, int K, int NOUT>
 struct GemvShape {
   static constexpr int NO4 = NOUT / 4;
@@ -429,18 +432,26 @@ __global__ __launch_bounds__(512) void k_decoder_convp(DecLaunch d, HeatLaunch h
   constexpr int LDS_FLOATS = DecSmem<512>::TOTAL > TILE ? DecSmem<512>::TOTAL : TILE;
   __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
   const int nd = 2 * d.g.N;
+#ifdef OETR_ROLE_ABL   // timing experiments only: 1 = decoder workgroups only, 2 = conv-P only
+  if ((OETR_ROLE_ABL == 1) != ((int)blockIdx.x < nd)) return;
+#endif
   if ((int)blockIdx.x < nd) decoder_body<512>(d, blockIdx.x, smem);
   else if constexpr (T64) conv_p_body64<MODE>(h, P, blockIdx.x - nd, smem);
   else conv_p_body<MODE>(h, P, blockIdx.x - nd, smem);
 }
 
+#ifndef OETR_CONVP64
+#define OETR_CONVP64 1   // 0: the round-1 rule (64-token conv-P tiles only when the encoder runs 64-token tiles)
+#endif
 template <int MODE>
 static hipError_t launch_decoder_convp_mode(const DecLaunch& d, const HeatLaunch& h, float* P,
                                             hipStream_t s) {
-  // conv-P tiles: 64 tokens in the 16-bit-plane modes when the encoder runs 64-token
-  // workgroups too (d.g carries the encoder's tile bookkeeping), else TM tokens (h.g)
-  const bool t64 = gm_half(MODE) && d.g.ntiles != h.g.ntiles;
-  const int ptiles = t64 ? h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT) : h.g.ntiles;
+  // conv-P work items: in the 16-bit-plane modes 64-token tiles (x CONVP_SPLIT tap groups)
+  // whatever tile the encoder runs - P is indexed by row; fewer, longer workgroups leave the
+  // decoder chain, this launch's critical path, more of the L2 (52.0 vs 53.5 us) -
+  // else TM-token tiles (h.g)
+  const bool t64 = gm_half(MODE) && (OETR_CONVP64 || d.g.ntiles != h.g.ntiles);
+  const int ptiles = t64 ? CONVP_SPLIT * h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT) : h.g.ntiles;
   const dim3 grid(2 * d.g.N + ptiles);
   if constexpr (gm_half(MODE)) {
     if (t64) {
