@@ -123,6 +123,9 @@ HOT_CASES = [
     ('s2_20x20_40x40', 2, False, 12, 2, (20, 20), (40, 40), (640, 640), (1280, 1280)),
     ('s3_32x32_sharp', 3, True, 13, 2, (32, 32), (32, 32), (1024, 1024), (1024, 1024)),
     ('s4_15x20_25x10', 4, True, 14, 3, (15, 20), (25, 10), (480, 640), (800, 320)),
+    # mixed scale with boxes OFF the clamp (s2's box1 saturates at [0,0,640,640] and carries
+    # no information): BASELINE configs[4]'s shape, sharpened heads
+    ('s5_20x20_40x40_sharp', 5, True, 15, 2, (20, 20), (40, 40), (640, 640), (1280, 1280)),
 ]
 
 
@@ -434,6 +437,8 @@ def main():
         return gen_hot(out_dir, build_reference_model(), FULL_ATTN_CASES, 'fullattn_', True)
     if args.only == 'train':
         return gen_train_forward(out_dir, build_reference_model())
+    if args.only == 'hot':
+        return gen_hot(out_dir, build_reference_model())
     gen_misc(out_dir)
     gen_crop(out_dir)
     gen_attention(out_dir)
@@ -442,7 +447,9 @@ def main():
     gen_hot(out_dir, model, FULL_ATTN_CASES, 'fullattn_', True)
     gen_full(out_dir, model)
     gen_neck(out_dir, model)
-    gen_train_forward(out_dir, model)
+    # a FRESH reference model: gen_neck has loaded seeded neck weights into `model`, and the
+    # committed train_forward.npz is what `--only train` (fresh model) produces
+    gen_train_forward(out_dir, build_reference_model())
 
 
 if __name__ == '__main__':
