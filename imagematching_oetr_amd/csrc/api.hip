@@ -135,7 +135,8 @@ struct oetr_trace {
 struct oetr_ctx {
   oetr_trace* trace = nullptr;
   int device = 0;
-  int mode = GM_SPLIT;  // oetr_dtype == GM_* (common.h)
+  int mode = GM_SPLIT;  // GEMM mode GM_* (common.h) of the oetr_dtype
+  int policy = 0;       // precision policy (SitePolicy<>) of the oetr_dtype: 1 = OETR_DTYPE_F32_SPLIT_QK16
   int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
   int attn_full = 0;   // OETR_ATTENTION_FULL (oetr_set_attention)
   int num_cus = 256;
@@ -175,7 +176,7 @@ long long* g_tbuf = nullptr;
 
 struct Workspace {
   float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
-      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2];
+      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *dump;
   size_t bytes;
 };
 
@@ -203,6 +204,7 @@ bool make_geom(int n, int hf1, int wf1, int hf2, int wf2, Geom* g) {
 // workgroups; oetr_set_encoder_tile overrides.  The heads keep TM.
 int encoder_tile_rows(const oetr_ctx* h, const Geom& g) {
   if (!gm_half(h->mode) || h->attn_full) return TM;
+  if (h->policy != 0) return RT;   // the reduced-site kernels exist in the 64-token shape
   const int want = h->enc_tile;
   if (want == TM || want == 64) return want;
   return g.ntiles > h->num_cus ? 64 : TM;
@@ -237,6 +239,7 @@ Workspace carve(const Geom& g, void* base, bool attn_full = false) {
   w.cxy = take((size_t)2 * g.N * 2);
   w.tlbr = take((size_t)2 * g.N * 4);
   w.convp = take((size_t)9 * rows * C);  // P_tap = W_tap . memory (forward path)
+  w.dump = take(C);                      // write-only scratch row (EncLaunch::dump)
   for (int i = 0; i < 2; ++i) {           // attention == full: K rows and V^T, per layer parity
     w.kbuf[i] = attn_full ? take(rows * C) : nullptr;
     w.vt[i] = attn_full ? take((size_t)g.N * C * TM * (g.nt[0] + g.nt[1])) : nullptr;
@@ -337,8 +340,10 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   }
 #endif
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
+  p.dump = w.dump;
   p.flags = h->flags;
   p.attn_full = h->attn_full;
+  p.policy = h->policy;
   for (int i = 0; i < 2; ++i) p.lpad[i] = g.nt[i] * TM;
   p.vt_off[0] = 0; p.vt_off[1] = (size_t)g.N * C * p.lpad[0];
   p.kbuf_out = w.kbuf[0]; p.vt_out = w.vt[0];
@@ -422,9 +427,11 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   static_assert(OETR_DTYPE_F32 == GM_F32 && OETR_DTYPE_F32_SPLIT_F16 == GM_SPLIT &&
                     OETR_DTYPE_F16 == GM_F16 && OETR_DTYPE_BF16 == GM_BF16, "oetr_dtype == GM_*");
   if (dtype != OETR_DTYPE_F32 && dtype != OETR_DTYPE_F32_SPLIT_F16 && dtype != OETR_DTYPE_F16 &&
-      dtype != OETR_DTYPE_BF16)
-    return fail(OETR_ERR_UNSUPPORTED, "dtype must be one of OETR_DTYPE_{F32,F32_SPLIT_F16,F16,BF16}");
-  const int split = (int)dtype;  // GEMM mode (name kept: selects the weight representation)
+      dtype != OETR_DTYPE_BF16 && dtype != OETR_DTYPE_F32_SPLIT_QK16)
+    return fail(OETR_ERR_UNSUPPORTED, "dtype must be one of OETR_DTYPE_{F32,F32_SPLIT_F16,F16,BF16,F32_SPLIT_QK16}");
+  // GEMM mode (name kept: selects the weight representation); QK16 = the split mode's planes
+  // with a per-site precision policy (SitePolicy<1>)
+  const int split = dtype == OETR_DTYPE_F32_SPLIT_QK16 ? (int)GM_SPLIT : (int)dtype;
   {  // every pointer must be set
     const float* const* p = reinterpret_cast<const float* const*>(&w->enc[0]);
     const size_t n = (sizeof(oetr_weights) - offsetof(oetr_weights, enc)) / sizeof(float*);
@@ -491,6 +498,7 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   oetr_ctx* h = new oetr_ctx();
   h->device = device;
   h->mode = split;
+  h->policy = dtype == OETR_DTYPE_F32_SPLIT_QK16 ? 1 : 0;
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   Packer pk;
   struct EncOff { size_t wq, wk, wv, wm, w1, w2, wq_l, wk_l, wv_l, wm_l, w1_l, w2_l, v[6]; } eo[OETR_N_ENC];
@@ -1206,6 +1214,8 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_encoder_tile: NULL handle");
   if (rows != 0 && rows != TM && rows != 64)
     return fail(OETR_ERR_BAD_ARG, "oetr_set_encoder_tile: rows must be 0 (auto), 32 or 64");
+  if (rows == TM && h->policy != 0)
+    return fail(OETR_ERR_UNSUPPORTED, "OETR_DTYPE_F32_SPLIT_QK16 runs 64-token encoder workgroups only");
   h->enc_tile = rows;
   return OETR_OK;
 }
@@ -1214,6 +1224,8 @@ oetr_status oetr_set_attention(oetr_handle h, oetr_attention mode) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_attention: NULL handle");
   if (mode != OETR_ATTENTION_LINEAR && mode != OETR_ATTENTION_FULL)
     return fail(OETR_ERR_BAD_ARG, "oetr_set_attention: unknown mode");
+  if (mode == OETR_ATTENTION_FULL && h->policy != 0)
+    return fail(OETR_ERR_UNSUPPORTED, "attention 'full' is not built for OETR_DTYPE_F32_SPLIT_QK16");
   if (mode == OETR_ATTENTION_FULL && !gm_f16_range(h->mode))
     return fail(OETR_ERR_UNSUPPORTED, "attention 'full' is built for OETR_DTYPE_F32_SPLIT_F16 and OETR_DTYPE_F16");
   h->attn_full = mode == OETR_ATTENTION_FULL;

@@ -805,14 +805,18 @@ __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int
   if (lane < 32) ks_out[(size_t)slot * C + wave * HD + lane] = ksum;
 }
 
-template <bool HAS_B, int TAIL, int MODE>
+template <bool HAS_B, int TAIL, int MODE, int POL = 0>
 __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
   constexpr int THREADS = 512, TPR = 8, F4 = 8;
+  using SP = SitePolicy<POL>;   // arithmetic per GEMM site (two-plane mode only)
   __shared__ __attribute__((aligned(16))) float smem[E2_SMEM];
   float* R1f = smem + E2_R1;
   float* R2f = smem + E2_R2;
   Range rg;
   const PlanesT<MODE> P1(R1f, &rg), P2(R2f, &rg);
+  // f32 staging tile of the residual stream between phase B and the tail (LayerNorm input):
+  // R2 after phase B (R1 then holds the second hidden half until MLP2b has read it)
+  float* Xf = HAS_B ? R2f : R1f;
   float* ksum_s = smem + E2_KSUM;
   float* z_s = smem + E2_Z;
   float* lnp_s = smem + E2_LNP;
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
         const int row = min(32 * mt + crow(r, half), nvalid - 1);
         xacc[mt][r] = p.x[(row_base + row) * C + wcol + col];
       }
-    ws.template prime<C, P_MERGE>(p.b.wmerge, p.b.wmerge_l, wave, 0, lane);
+    ws.template prime<C, P_MERGE, SP::MERGE>(p.b.wmerge, p.b.wmerge_l, wave, 0, lane);
     __syncthreads();
     PHASE_STAMP(p, 1);
 
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      if (mt == 1 && !ws.two) break;  // ragged tile: rows 32.. are never stored
+      if (mt == 1 && !ws.two()) break;  // ragged tile: rows 32.. are never stored
       float zr[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) zr[r] = z_s[(32 * mt + crow(r, half)) * NH + wave];
@@ -969,8 +973,8 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     PHASE_STAMP(p, 2);
 
     // x1 = x + message . Wmerge^T
-    ws.template gemm<C, P_MERGE, true, C>(P1, p.b.wmerge, p.b.wmerge_l, wave, 0, lane, xacc,
-                                          p.b.w1, p.b.w1_l, wave, 0);
+    ws.template gemm<C, P_MERGE, true, C, SP::MERGE, SP::MLP1>(P1, p.b.wmerge, p.b.wmerge_l, wave, 0, lane,
+                                                               xacc, p.b.w1, p.b.w1_l, wave, 0);
     __syncthreads();  // every wave is done reading the message planes
     PHASE_STAMP(p, 3);
 #pragma unroll
@@ -989,58 +993,38 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     __syncthreads();
 
     PHASE_STAMP(p, 4);
-    // MLP in two hidden halves: hidden_h = gelu(LN2(x1) . W1[h]^T) -> R2 ; x += hidden_h . W2[:,h]^T
+    // MLP in two hidden halves, the GELU epilogue of each half issued under the NEXT GEMM's MFMAs:
+    //   MLP1a | MLP1b + gelu(a) -> R2 | barrier | MLP2a(R2) + gelu(b) -> R1 | barrier | MLP2b(R1)
+    // (R1 = the LN2 planes, free once every wave has finished MLP1b: the first barrier)
     {
-      f32x16 hacc[2] = {f32x16{0}, f32x16{0}};
-      ws.template gemm<C, P_1A, true, FF>(P1, p.b.w1, p.b.w1_l, wave, 0, lane, hacc, p.b.w2,
-                                          p.b.w2_l, wave, 0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        if (mt == 1 && !ws.two) break;  // (hidden rows 32.. stay unwritten: never consumed)
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 4) {  // four at a time: bounded register pressure
-#pragma unroll
-          for (int r = r0; r < r0 + 4; r += 2) {
-            const f32x2 ge = gelu_erf2(f32x2{hacc[mt][r], hacc[mt][r + 1]});
-            hacc[mt][r] = ge[0];
-            hacc[mt][r + 1] = ge[1];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        P2.put_acc(mt, wcol, lane, hacc[mt]);
-      }
+      constexpr int SNEXT = TAIL == 0 ? SP::Q : SP::DEC_K;   // first GEMM of the tail
+      f32x16 haccA[2] = {f32x16{0}, f32x16{0}}, haccB[2] = {f32x16{0}, f32x16{0}};
+      ws.template gemm<C, P_1A, true, C, SP::MLP1, SP::MLP1>(P1, p.b.w1, p.b.w1_l, wave, 0, lane, haccA,
+                                                             p.b.w1, p.b.w1_l, 8 + wave, 0);
+      const bool two = ws.two();
+      auto gelu_to = [&](const PlanesT<MODE>& dst, const f32x16 (&h)[2]) {
+        return [&, two](auto CI_) {   // two accumulator values (one packed GELU) per k16 step
+          constexpr int CI = decltype(CI_)::value, mt = CI / 8, r = 2 * (CI % 8);
+          if (mt == 1 && !two) return;   // (hidden rows 32.. stay unwritten: never consumed)
+          const f32x2 ge = gelu_erf2(f32x2{h[mt][r], h[mt][r + 1]});
+          dst.template put_pair<r, site_act_lo(SP::MLP2)>(mt, wcol, lane, ge[0], ge[1]);
+        };
+      };
+      auto epiA = gelu_to(P2, haccA);
+      ws.template gemm_epi<C, P_1B, true, FF, SP::MLP1, SP::MLP2>(P1, p.b.w1, p.b.w1_l, 8 + wave, 0, lane,
+                                                                  haccB, p.b.w2, p.b.w2_l, wave, 0, epiA);
+      __syncthreads();   // hidden half a complete; every wave is done reading the LN2 planes
+      PHASE_STAMP(p, 5);
+      auto epiB = gelu_to(P1, haccB);
+      ws.template gemm_epi<FF, P_2A, true, FF, SP::MLP2, SP::MLP2>(P2, p.b.w2, p.b.w2_l, wave, 0, lane, xacc,
+                                                                   p.b.w2, p.b.w2_l, wave, 16, epiB);
+      __syncthreads();   // hidden half b complete
+      PHASE_STAMP(p, 6);
+      PHASE_STAMP(p, 7);
+      ws.template gemm<FF, P_2B, (TAIL != 2), C, SP::MLP2, SNEXT>(P1, p.b.w2, p.b.w2_l, wave, 16, lane, xacc,
+                                                                  TAIL == 0 ? p.a.wq : p.d.wk[0],
+                                                                  TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], wave, 0);
     }
-    __syncthreads();
-    PHASE_STAMP(p, 5);
-    ws.template gemm<FF, P_2A, true, C>(P2, p.b.w2, p.b.w2_l, wave, 0, lane, xacc, p.b.w1, p.b.w1_l,
-                                        8 + wave, 0);
-    __syncthreads();  // hidden half a consumed
-    PHASE_STAMP(p, 6);
-    {
-      f32x16 hacc[2] = {f32x16{0}, f32x16{0}};
-      ws.template gemm<C, P_1B, true, FF>(P1, p.b.w1, p.b.w1_l, 8 + wave, 0, lane, hacc, p.b.w2,
-                                          p.b.w2_l, wave, 16);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        if (mt == 1 && !ws.two) break;  // (hidden rows 32.. stay unwritten: never consumed)
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 4) {  // four at a time: bounded register pressure
-#pragma unroll
-          for (int r = r0; r < r0 + 4; r += 2) {
-            const f32x2 ge = gelu_erf2(f32x2{hacc[mt][r], hacc[mt][r + 1]});
-            hacc[mt][r] = ge[0];
-            hacc[mt][r + 1] = ge[1];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        P2.put_acc(mt, wcol, lane, hacc[mt]);
-      }
-    }
-    __syncthreads();
-    PHASE_STAMP(p, 7);
-    ws.template gemm<FF, P_2B, (TAIL != 2), C>(P2, p.b.w2, p.b.w2_l, wave, 16, lane, xacc,
-                                               TAIL == 0 ? p.a.wq : p.d.wk[0],
-                                               TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], wave, 0);
     {
       // (pointer laundered: otherwise the 32 store addresses are CSE'd with the residual
       //  loads' at the top of the kernel and live - spilled - across every GEMM)
@@ -1058,10 +1042,11 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     }
     PHASE_STAMP(p, 8);
     if (TAIL == 2) { range_report<MODE>(rg, p.flags); return; }
-    // (R1 planes were last read by MLP1b, which every wave finished before the barrier above)
+    // (the staging region's planes were last read by a GEMM every wave finished before a barrier
+    //  above: R2 by MLP2a; R1 holds the second hidden half, which MLP2b reads)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
-      acc_to_lds<1>(R1f + mt * 32 * LDA, LDA, wcol, lane, *reinterpret_cast<f32x16(*)[1]>(&xacc[mt]));
+      acc_to_lds<1>(Xf + mt * 32 * LDA, LDA, wcol, lane, *reinterpret_cast<f32x16(*)[1]>(&xacc[mt]));
     __syncthreads();
   } else {
     if (nchw) {  // first launch, reference layout: transpose on the way in (R2 is free until phase A writes P2)
@@ -1076,8 +1061,8 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
             reinterpret_cast<const f32x4*>(p.x + (row_base + min(r, nvalid - 1)) * C)[c4];
       }
     }
-    if (TAIL == 0) ws.template prime<C, P_T0>(p.a.wq, p.a.wq_l, wave, 0, lane);
-    if (TAIL == 1) ws.template prime<C, P_T0>(p.d.wk[0], p.d.wk_l[0], wave, 0, lane);
+    if (TAIL == 0) ws.template prime<C, P_T0, SP::Q>(p.a.wq, p.a.wq_l, wave, 0, lane);
+    if (TAIL == 1) ws.template prime<C, P_T0, SP::DEC_K>(p.d.wk[0], p.d.wk_l[0], wave, 0, lane);
     __syncthreads();
     if (nchw) {  // token-major copies for the later launches (residual reads, position rows)
       store_tile_tokens<THREADS, RT>(p.x + row_base * C, R1f, nvalid, tid);
@@ -1097,7 +1082,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
 #pragma unroll
         for (int i = 0; i < F4; ++i) ps[i] = pos[i * TPR];
       }
-      ln_rows<TPR, F4>(R1f, tid, xn, 0);
+      ln_rows<TPR, F4>(Xf, tid, xn, 0);
       __syncthreads();
       const f32x4* qw = reinterpret_cast<const f32x4*>(lnp_s + 2 * C) + lpart;
       const f32x4* qb = reinterpret_cast<const f32x4*>(lnp_s + 3 * C) + lpart;
@@ -1105,40 +1090,45 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
       const f32x4* kb = reinterpret_cast<const f32x4*>(lnp_s + 5 * C) + lpart;
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
-        P1.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * qw[i * TPR] + qb[i * TPR]) + ps[i]);
-        P2.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * kw[i * TPR] + kb[i * TPR]) + ps[i]);
+        P1.template put4<site_act_lo(SP::Q)>(lrow, 4 * (i * TPR + lpart), (xn[i] * qw[i * TPR] + qb[i * TPR]) + ps[i]);
+        P2.template put4<site_act_lo(SP::K) || site_act_lo(SP::V)>(lrow, 4 * (i * TPR + lpart),
+                                                                   (xn[i] * kw[i * TPR] + kb[i * TPR]) + ps[i]);
       }
     }
     __syncthreads();
     PHASE_STAMP(p, 9);
-    {  // phi(Q) -> HBM
-      f32x16 acc[2] = {f32x16{0}, f32x16{0}};
-      ws.template gemm<C, P_T0, true, C>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, acc, p.a.wk, p.a.wk_l,
-                                         wave, 0);
+    // phi(Q) -> HBM, issued under the K GEMM's MFMAs (two accumulator values per k16 step; rows
+    // past a ragged tile's end go to the scratch row: an address select, no divergent branch)
+    f32x16 accQ[2] = {f32x16{0}, f32x16{0}};
+    ws.template gemm<C, P_T0, true, C, SP::Q, SP::K>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
+                                                     p.a.wk_l, wave, 0);
+    PHASE_STAMP(p, 10);
+    f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
+    {
       int l2 = lane;  // laundered like the x store: no address CSE across the kernel
       asm volatile("" : "+v"(l2));
       float* qs = p.qp + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
       const int nv2 = nvalid - 4 * (l2 >> 5);
+      float* qdump = p.dump + wcol + (l2 & 31);
+      auto qepi = [&](auto CI_) {
+        constexpr int CI = decltype(CI_)::value, mt = CI / 8, r0 = 2 * (CI % 8);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        if (mt == 1 && !ws.two) break;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = r0; r < r0 + 2; ++r) {
           const int row = 32 * mt + crow(r, 0);
-          if (row < nv2) qs[row * C] = elu1(acc[mt][r]);
+          const float x = accQ[mt][r];
+          float* dst = row < nv2 ? qs + row * C : qdump;
+          *dst = fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f));   // == elu(x) + 1
         }
-      }
+      };
+      ws.template gemm_epi<C, P_T1, true, C, SP::K, SP::V>(P2, p.a.wk, p.a.wk_l, wave, 0, lane, accK, p.a.wv,
+                                                           p.a.wv_l, wave, 0, qepi);
     }
-    PHASE_STAMP(p, 10);
-    f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
-    ws.template gemm<C, P_T1, true, C>(P2, p.a.wk, p.a.wk_l, wave, 0, lane, accK, p.a.wv, p.a.wv_l,
-                                       wave, 0);
-    ws.template gemm<C, P_T2, false, C>(P2, p.a.wv, p.a.wv_l, wave, 0, lane, accV, nullptr, nullptr,
-                                        0, 0);
+    ws.template gemm<C, P_T2, false, C, SP::V>(P2, p.a.wv, p.a.wv_l, wave, 0, lane, accV, nullptr, nullptr,
+                                               0, 0);
     PHASE_STAMP(p, 11);
     f32x16 kv;
     float ksum;
-    kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two, kv, ksum, rg);
+    kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
   } else if (TAIL == 1) {
@@ -1151,14 +1141,14 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     }
     {
       f32x4 xv[F4], ps[F4];
-      const f32x4* src = reinterpret_cast<const f32x4*>(R1f + lrow * LDA) + lpart;
+      const f32x4* src = reinterpret_cast<const f32x4*>(Xf + lrow * LDA) + lpart;
 #pragma unroll
       for (int i = 0; i < F4; ++i) { xv[i] = src[i * TPR]; ps[i] = pos[i * TPR]; }
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
-        P1.put4(lrow, 4 * (i * TPR + lpart), xv[i] + ps[i]);  // k input: memory + pos
-        P2.put4(lrow, 4 * (i * TPR + lpart), xv[i]);          // v input: memory
+        P1.template put4<site_act_lo(SP::DEC_K)>(lrow, 4 * (i * TPR + lpart), xv[i] + ps[i]);  // k input: memory + pos
+        P2.template put4<site_act_lo(SP::DEC_V)>(lrow, 4 * (i * TPR + lpart), xv[i]);          // v input: memory
       }
     }
     __syncthreads();
@@ -1170,15 +1160,15 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accK[mt][r] = bias_k[dl]; accV[mt][r] = bias_v[dl]; }
-      ws.template gemm<C, PK, true, C>(P1, p.d.wk[dl], p.d.wk_l[dl], wave, 0, lane, accK, p.d.wv[dl],
-                                       p.d.wv_l[dl], wave, 0);
+      ws.template gemm<C, PK, true, C, SP::DEC_K, SP::DEC_V>(P1, p.d.wk[dl], p.d.wk_l[dl], wave, 0, lane, accK,
+                                                             p.d.wv[dl], p.d.wv_l[dl], wave, 0);
       // (no run-ahead across the state epilogue below: K, V, the state and the exp
       //  temporaries already fill the register file; layer 1's K slab is primed after it)
-      ws.template gemm<C, PV, false, C>(P2, p.d.wv[dl], p.d.wv_l[dl], wave, 0, lane, accV, nullptr,
-                                        nullptr, 0, 0);
+      ws.template gemm<C, PV, false, C, SP::DEC_V>(P2, p.d.wv[dl], p.d.wv_l[dl], wave, 0, lane, accV, nullptr,
+                                                   nullptr, 0, 0);
       f32x16 kv;
       float ksum;
-      kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two, kv, ksum, rg);
+      kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
       if constexpr (dl == 1) {
         kv_state_write(kv, ksum, lane, wave, p.dkv1_out, p.dks1_out, slot);
       } else {
@@ -1196,7 +1186,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
         z += __shfl_xor(z, 16, 64);
         if (half == 0) p.att0_out[(size_t)slot * C + wave * HD + col] = a;
         if (lane == 0) p.z0_out[(size_t)slot * NH + wave] = z;
-        ws.template prime<C, P_T2>(p.d.wk[1], p.d.wk_l[1], wave, 0, lane);
+        ws.template prime<C, P_T2, SP::DEC_K>(p.d.wk[1], p.d.wk_l[1], wave, 0, lane);
       }
     };
     dec_layer(std::integral_constant<int, 0>{});
@@ -1218,6 +1208,23 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
   if constexpr (gm_half(MODE)) {
     if (p.tile_rows == RT) {
 #define OETR_LAUNCH64(B, T) hipLaunchKernelGGL((k_encoder64<B, T, MODE>), grid, dim3(512), 0, s, p)
+      if constexpr (MODE == GM_SPLIT) {   // precision policies exist for the two-plane mode
+        if (p.policy == 1) {
+#define OETR_LAUNCH64P(B, T) hipLaunchKernelGGL((k_encoder64<B, T, MODE, 1>), grid, dim3(512), 0, s, p)
+          if (has_b) {
+            if (tail == 0) OETR_LAUNCH64P(true, 0);
+            else if (tail == 1) OETR_LAUNCH64P(true, 1);
+            else OETR_LAUNCH64P(true, 2);
+          } else {
+            if (tail == 0) OETR_LAUNCH64P(false, 0);
+            else if (tail == 1) OETR_LAUNCH64P(false, 1);
+            else return hipErrorInvalidValue;
+          }
+#undef OETR_LAUNCH64P
+          return hipGetLastError();
+        }
+      }
+      if (p.policy != 0) return hipErrorInvalidValue;
       if (has_b) {
         if (tail == 0) OETR_LAUNCH64(true, 0);
         else if (tail == 1) OETR_LAUNCH64(true, 1);
@@ -1231,6 +1238,7 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
       return hipGetLastError();
     }
   }
+  if (p.policy != 0) return hipErrorInvalidValue;   // policies: 64-token workgroups only (api.hip)
   constexpr int NW = gm_half(MODE) ? OETR_SPLIT_WAVES : OETR_F32_WAVES;
   if (p.attn_full) {
     if constexpr (gm_f16_range(MODE) && NW == 8) {

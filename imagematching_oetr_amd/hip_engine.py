@@ -269,9 +269,9 @@ class HotPathEngine:
     fills 208 of 256 CUs, a second stream fills the rest: +23 % throughput)."""
 
     #: GEMM arithmetic modes (oetr_dtype in the header)
-    PRECISIONS = {'f32': 0, 'f32_split_f16': 1, 'f16': 2, 'bf16': 3}
+    PRECISIONS = {'f32': 0, 'f32_split_f16': 1, 'f16': 2, 'bf16': 3, 'f32_split_qk16': 4}
     #: precisions whose GEMM operands are f16 values (|x| < 65504, see query_flags)
-    F16_RANGE = ('f32_split_f16', 'f16')
+    F16_RANGE = ('f32_split_f16', 'f16', 'f32_split_qk16')
 
     #: encoder attention cores (oetr_attention in the header)
     ATTENTIONS = {'linear': 0, 'full': 1}

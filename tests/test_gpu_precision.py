@@ -1,5 +1,10 @@
 """GPU tests of the GEMM arithmetic modes beyond the fp32-class default:
 
+* the per-GEMM-site precision POLICY ``f32_split_qk16`` (``OETR_DTYPE_F32_SPLIT_QK16``): the
+  encoder's Q / K projections and the decoder's K projection on single f16 MFMAs, every other
+  site fp32-class.  It is the reduced mode that MEETS the north_star bar - plain passing
+  tests below, on every golden incl. the sharpened-head ones;
+
 * the single-pass 16-bit operand modes ``f16`` (BASELINE configs[4]: "fp16 with fp32
   accumulate") and ``bf16`` (configs[2]: "bf16 MFMA attention"), gated on the
   north_star bar - boxes within 1e-3 IoU of the reference's - on every golden, with
@@ -30,7 +35,7 @@ torch.set_grad_enabled(False)
 
 HOT = sorted(glob.glob(str(Path(__file__).parent / 'golden' / 'hot_*.npz')))
 REDUCED = ['f16', 'f16@64', 'bf16', 'bf16@64']
-# Measured on MI355X, round 2 (profiles/r2_precision_drift.json), worst case over the
+# Measured on MI355X, round 2 (profiles/r3_precision_drift.json), worst case over the
 # five reference goldens + the full-forward golden, either tile shape:
 #            memory   hs      tlbr     min IoU (plain heads)  min IoU (sharpened heads)
 #   f16      8.6e-3   1.1e-2  7.2e-4   0.9975                 0.935   (cxy off by up to 7 px)
@@ -45,7 +50,7 @@ DRIFT_TOL = {'f16': dict(memory=2.5e-2, hs=3e-2, tlbr=2e-3),
 IOU_FLOOR = {'f16': dict(plain=0.995, sharp=0.90), 'bf16': dict(plain=0.95, sharp=0.80)}
 BAR_XFAIL = ('single-pass 16-bit GEMM operands miss the 1e-3 IoU bar on the seeded goldens: '
              'measured min IoU f16 0.9975 (plain heads) / 0.935 (sharpened), bf16 0.973 / 0.883 '
-             '(profiles/r2_precision_drift.json); kept as an expected failure, not dropped')
+             '(profiles/r3_precision_drift.json); kept as an expected failure, not dropped')
 DRIFT_LOG = Path(os.environ.get('OETR_DRIFT_LOG',
                                 Path(__file__).resolve().parents[1] / 'gpurun_out' / 'precision_drift.json'))
 
@@ -124,6 +129,59 @@ def test_reduced_precision_meets_the_north_star_iou_bar(path, precision, gpu):
     assert all(v >= 1 - 1e-3 for v in ious), f'{precision}: IoU bar missed: {entry}'
 
 
+# --------------------------------------------------------------- precision policy (QK16)
+# Which GEMM sites may be reduced is a measured property (profiles/r3_site_drift.json, one
+# site at a time on the goldens; tools/site_drift.py emulates the same on the CPU oracle):
+#   site reduced to f16 operands      worst 1 - IoU      verdict
+#   Q                                 8e-5               ok   (phi(Q) enters numerator and normaliser)
+#   K                                 9e-5               ok   (K only enters sums over all source tokens)
+#   decoder K                         1e-5               ok
+#   V                                 3e-2               no   (weight rounding is systematic across tokens)
+#   merge / MLP1 / MLP2               1e-2 / 3e-2 / 1e-2 no   (feed the residual stream directly)
+#   attention contractions (KV, apply) 1e-2 (bf16: 1e-1) no   - what configs[2] literally names
+# Q + K + decoder K together: 1.1e-4 = the policy.
+POLICY = 'f32_split_qk16'
+POLICY_TOL = dict(memory=3e-4, hs=3e-4, tlbr=5e-5, cxy=0.15)   # observed 6e-5 / 6e-5 / 1e-5 / 0.035 px
+
+
+@pytest.mark.parametrize('path', HOT, ids=lambda p: p.split('hot_')[-1][:-4])
+def test_precision_policy_meets_the_north_star_iou_bar(path, gpu):
+    """The north_star bar (IoU >= 1 - 1e-3 vs the REFERENCE's boxes) under the QK16 policy, on
+    every golden - 20x20, 32x32, mixed 20x20 vs 40x40 (configs[4]'s shape), ragged grids,
+    plain and sharpened heads - plus bounds on the intermediate tensors.  A plain test."""
+    entry, drift, ious = _golden_drift(path, POLICY, gpu)
+    assert all(v >= 1 - 1e-3 for v in ious), f'{POLICY}: IoU bar missed: {entry}'
+    for key, v in drift.items():
+        if key[:-1] in POLICY_TOL:
+            assert v <= POLICY_TOL[key[:-1]], f'{POLICY} {key}: drift {v:.3e} ({entry})'
+
+
+def test_precision_policy_full_forward_golden_boxes(gpu, golden_dir):
+    """Boxes the reference's forward_dummy produced from 640x640 images under the policy."""
+    g = np.load(golden_dir / 'full_640.npz')
+    eng = _engine(orc.make_hot_weights(int(g['weight_seed']), sharpen=True), gpu, POLICY)
+    t = [torch.from_numpy(g[k]).to(gpu) for k in ('feat1', 'feat2', 'pos1', 'pos2')]
+    b1, b2 = eng.forward(*t, (640, 640), (640, 640))
+    iou = orc.bbox_iou_aligned(torch.cat([b1, b2]).cpu(),
+                               torch.from_numpy(np.concatenate([g['box1'], g['box2']])))
+    _record(dict(case='full_640', precision=POLICY, sharpened_heads=True, min_iou=float(iou.min()),
+                 box1=maxerr(b1, g['box1']), box2=maxerr(b2, g['box2'])))
+    assert (iou >= 1 - 1e-3).all(), iou
+
+
+def test_precision_policy_is_a_64_token_mode(gpu):
+    """The reduced-site kernels exist in the 64-token workgroup shape, linear attention."""
+    from imagematching_oetr_amd import HotPathEngine, OetrError
+    w = orc.make_hot_weights(0)
+    eng = _engine(w, gpu, POLICY)
+    with pytest.raises(OetrError):
+        eng.set_encoder_tile(32)
+    eng.set_encoder_tile(64)
+    eng.set_encoder_tile(0)
+    with pytest.raises(OetrError):
+        HotPathEngine(w, device=gpu, precision=POLICY, attention='full')
+
+
 @pytest.mark.parametrize('precision', REDUCED)
 def test_reduced_precision_full_forward_golden_boxes(gpu, golden_dir, precision):
     """Boxes the reference's forward_dummy produced from 640x640 images (real
@@ -139,7 +197,7 @@ def test_reduced_precision_full_forward_golden_boxes(gpu, golden_dir, precision)
     assert (iou >= IOU_FLOOR[precision.partition('@')[0]]['sharp']).all(), iou
 
 
-@pytest.mark.parametrize('precision', ['f16', 'bf16'])
+@pytest.mark.parametrize('precision', ['f16', 'bf16', 'f32_split_qk16'])
 def test_reduced_precision_batch_properties(gpu, precision):
     """configs[2]'s per-GPU workload (8 pairs @640x640) in the reduced modes: pairs stay
     independent (bit-exact under batch permutation / slicing), results repeat bit for
@@ -164,7 +222,9 @@ def test_reduced_precision_batch_properties(gpu, precision):
     iou = torch.cat([orc.bbox_iou_aligned(b1.cpu(), r1), orc.bbox_iou_aligned(b2.cpu(), r2)])
     _record(dict(case='bench_8x640_sharp_vs_oracle', precision=precision, sharpened_heads=True,
                  min_iou=float(iou.min()), mean_iou=float(iou.mean())))
-    assert float(iou.min()) >= 0.5      # sanity only: the bar is tracked by the xfail test above
+    # (all-rounded modes: sanity only, their bar is tracked by the xfail test above; the policy
+    #  meets the bar here too)
+    assert float(iou.min()) >= (1 - 1e-3 if precision == POLICY else 0.5)
 
 
 # ----------------------------------------------------------------- range guard
@@ -174,7 +234,7 @@ def test_out_of_range_weights_are_rejected_at_create(gpu):
     big = dict(w)
     big['transformer.encoder.3.mlp.0.weight'] = w['transformer.encoder.3.mlp.0.weight'].clone()
     big['transformer.encoder.3.mlp.0.weight'][5, 7] = 7.0e4
-    for prec in ('f32_split_f16', 'f16'):
+    for prec in ('f32_split_f16', 'f16', 'f32_split_qk16'):
         with pytest.raises(OetrError, match='f16 range'):
             HotPathEngine(big, device=gpu, precision=prec)
     for prec in ('bf16', 'f32'):       # representable there
@@ -187,7 +247,7 @@ def test_out_of_range_weights_are_rejected_at_create(gpu):
             HotPathEngine(nan, device=gpu, precision=prec)
 
 
-@pytest.mark.parametrize('precision', ['f32_split_f16', 'f32_split_f16@64', 'f16'])
+@pytest.mark.parametrize('precision', ['f32_split_f16', 'f32_split_f16@64', 'f16', 'f32_split_qk16'])
 def test_out_of_range_activations_set_the_flag(gpu, precision):
     """Features of magnitude 2e5: `memory` (the un-normalised residual stream) exceeds
     65504 where it enters the decoder K/V and conv-P GEMMs.  The call must report it;
