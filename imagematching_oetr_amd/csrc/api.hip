@@ -142,7 +142,6 @@ struct oetr_ctx {
   int num_cus = 256;
   float* dev = nullptr;  // all repacked weights
   size_t dev_floats = 0;
-  uint32_t* flags = nullptr;  // device status word (OETR_FLAG_*), set by kernels with atomicOr
   EncLayerDev enc[OETR_N_ENC];
   DecKVDev dkv;
   DecLayerDev dec[OETR_N_DEC];
@@ -157,7 +156,6 @@ struct oetr_neck_ctx {
   int num_cus = 256;
   int conv_rows = 0;     // 0 = auto (neck_conv_rows), else forced 256 / 192 / 128 (A/B timing)
   float* dev = nullptr;  // all repacked weights
-  uint32_t* flags = nullptr;  // device status word (OETR_FLAG_*)
   const f32x4 *proj_wh[2], *proj_wl[2];
   const float *proj_b, *ln_w, *ln_b;
   const f32x4 *conv_wh[3], *conv_wl[3];
@@ -177,6 +175,7 @@ long long* g_tbuf = nullptr;
 struct Workspace {
   float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
       *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *dump;
+  uint32_t* flags;   // the workspace's status word (first 256 bytes: shape-independent position)
   size_t bytes;
 };
 
@@ -226,6 +225,7 @@ Workspace carve(const Geom& g, void* base, bool attn_full = false) {
     return p;
   };
   const size_t rows = g.rows, nt = g.ntiles;
+  w.flags = reinterpret_cast<uint32_t*>(take(OETR_WORKSPACE_STATUS_BYTES / sizeof(float)));
   w.x = take(rows * C);
   w.qp = take(rows * C);
   w.pos = take((size_t)(g.L[0] + g.L[1]) * C);
@@ -275,7 +275,7 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.tlbr[0] = p.tlbr[1] = nullptr;   // stand-alone centre estimation: no fused tail
   p.box[0] = p.box[1] = nullptr;
   p.img_w[0] = p.img_w[1] = 0;
-  p.flags = h->flags;
+  p.flags = w.flags;
   return p;
 }
 
@@ -341,7 +341,7 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
 #endif
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
   p.dump = w.dump;
-  p.flags = h->flags;
+  p.flags = w.flags;
   p.attn_full = h->attn_full;
   p.policy = h->policy;
   for (int i = 0; i < 2; ++i) p.lpad[i] = g.nt[i] * TM;
@@ -400,12 +400,6 @@ oetr_status check_weight(const char* name, const float* w, size_t n, bool f16_ra
     oetr_status rc__ = check_weight(name, ptr, n, f16r);                 \
     if (rc__) return rc__;                                               \
   } while (0)
-
-hipError_t alloc_flags(uint32_t** flags) {
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(flags), 256);
-  if (e == hipSuccess) e = hipMemset(*flags, 0, 256);
-  return e;
-}
 
 oetr_status copy_out(float* dst, const float* src, size_t floats, hipStream_t s) {
   if (!dst) return OETR_OK;
@@ -573,11 +567,9 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   if (e == hipSuccess) e = hipMalloc(&h->dev, pk.buf.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(h->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = alloc_flags(&h->flags);
   (void)hipSetDevice(prev);
   if (e != hipSuccess) {
     if (h->dev) (void)hipFree(h->dev);
-    if (h->flags) (void)hipFree(h->flags);
     delete h;
     return hip_fail(e, "oetr_create: uploading weights");
   }
@@ -622,7 +614,6 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
     (void)hipSetDevice(prev);
     if (ce != hipSuccess) {
       (void)hipFree(h->dev);
-      (void)hipFree(h->flags);
       delete h;
       return hip_fail(ce, "oetr_create: decoder constant folding");
     }
@@ -643,7 +634,6 @@ void oetr_destroy(oetr_handle h) {
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(h->device);
     (void)hipFree(h->dev);
-    if (h->flags) (void)hipFree(h->flags);
     (void)hipSetDevice(prev);
   }
   delete h;
@@ -941,6 +931,7 @@ bool make_neck_geom(int n_img, int hb, int wb, NeckGeom* g) {
 }
 
 struct NeckWorkspace {
+  uint32_t* flags;   // status word (first 256 bytes)
   _Float16 *xh, *xl;
   float* part[3];
   size_t bytes;
@@ -956,6 +947,7 @@ NeckWorkspace neck_carve(const NeckGeom& g, void* base) {
   // X: per input pixel (+ one all-zero padding row) eight 128-byte chunks
   // [32 channels hi | 32 channels lo] - what one conv stage gathers per pixel is one
   // cache line.  xl = xh + 32 halves: "the lo plane" of the same buffer.
+  w.flags = reinterpret_cast<uint32_t*>(take(OETR_WORKSPACE_STATUS_BYTES));
   const size_t xbytes = ((size_t)g.rows_in + 1) * NECK_XROW * sizeof(_Float16);
   w.xh = reinterpret_cast<_Float16*>(take(xbytes));
   w.xl = w.xh ? w.xh + 32 : nullptr;
@@ -1021,11 +1013,9 @@ oetr_status oetr_neck_create(const oetr_neck_weights* w, int device, oetr_neck_h
   if (e == hipSuccess) e = hipMalloc(&h->dev, pk.buf.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(h->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = alloc_flags(&h->flags);
   (void)hipSetDevice(prev);
   if (e != hipSuccess) {
     if (h->dev) (void)hipFree(h->dev);
-    if (h->flags) (void)hipFree(h->flags);
     delete h;
     return hip_fail(e, "oetr_neck_create: uploading weights");
   }
@@ -1049,7 +1039,6 @@ void oetr_neck_destroy(oetr_neck_handle h) {
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(h->device);
     (void)hipFree(h->dev);
-    if (h->flags) (void)hipFree(h->flags);
     (void)hipSetDevice(prev);
   }
   delete h;
@@ -1086,7 +1075,7 @@ oetr_status neck_forward_impl(oetr_neck_handle h, const float* backbone_feat, in
   for (int kh = 0; kh < 2; ++kh) { pp.wh[kh] = h->proj_wh[kh]; pp.wl[kh] = h->proj_wl[kh]; }
   pp.bias = h->proj_b; pp.ln_w = h->ln_w; pp.ln_b = h->ln_b;
   pp.xh = w.xh; pp.xl = w.xl;
-  pp.flags = h->flags;
+  pp.flags = w.flags;
   TRACED(h, s, K_NECK_PROJ, launch_neck_proj(pp, s));
 
   NeckConvLaunch cp;
@@ -1124,7 +1113,7 @@ oetr_status neck_forward_impl(oetr_neck_handle h, const float* backbone_feat, in
   op.wh = h->out_wh; op.wl = h->out_wl; op.bias2 = h->out_b;
   op.feat = token_major ? nullptr : feat_out;
   op.tokens = token_major ? feat_out : nullptr;
-  op.flags = h->flags;
+  op.flags = w.flags;
   TRACED(h, s, K_NECK_OUT, launch_neck_out(op, s));
   return OETR_OK;
 }
@@ -1145,28 +1134,52 @@ oetr_status oetr_neck_forward_tokens(oetr_neck_handle h, const float* backbone_f
 }
 
 namespace {
-oetr_status query_flags(int device, uint32_t* dev_flags, void* stream, uint32_t* flags, int clear) {
-  if (!flags) return fail(OETR_ERR_BAD_ARG, "oetr_query_flags: NULL output");
+// The status word is the first word of a workspace (forward and neck alike): per workspace,
+// hence per stream - a query sees and clears only the calls that used THIS workspace.
+oetr_status read_flags(int device, void* workspace, void* stream, uint32_t* flags, int clear, bool sync,
+                       const char* what) {
+  if (!flags || !workspace) return fail(OETR_ERR_BAD_ARG, std::string(what) + ": NULL workspace / output");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255)
+    return fail(OETR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  uint32_t* dev_flags = static_cast<uint32_t*>(workspace);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int prev = 0;
   (void)hipGetDevice(&prev);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMemcpyAsync(flags, dev_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && clear) e = hipMemsetAsync(dev_flags, 0, sizeof(uint32_t), s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess && sync) e = hipStreamSynchronize(s);
   (void)hipSetDevice(prev);
-  if (e != hipSuccess) return hip_fail(e, "oetr_query_flags");
+  if (e != hipSuccess) return hip_fail(e, what);
   return OETR_OK;
 }
 }  // namespace
 
-oetr_status oetr_query_flags(oetr_handle h, void* stream, uint32_t* flags, int clear) {
-  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_query_flags: NULL handle");
-  return query_flags(h->device, h->flags, stream, flags, clear);
+oetr_status oetr_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+  if (!workspace || workspace_bytes < OETR_WORKSPACE_STATUS_BYTES)
+    return fail(OETR_ERR_WORKSPACE, "oetr_workspace_init: workspace is NULL or smaller than its status block");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255)
+    return fail(OETR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  HIP_TRY(hipMemsetAsync(workspace, 0, OETR_WORKSPACE_STATUS_BYTES, static_cast<hipStream_t>(stream)));
+  return OETR_OK;
 }
-oetr_status oetr_neck_query_flags(oetr_neck_handle h, void* stream, uint32_t* flags, int clear) {
+
+oetr_status oetr_query_flags(oetr_handle h, void* workspace, void* stream, uint32_t* flags, int clear) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_query_flags: NULL handle");
+  return read_flags(h->device, workspace, stream, flags, clear, true, "oetr_query_flags");
+}
+oetr_status oetr_read_flags_async(oetr_handle h, void* workspace, uint32_t* host_flags, int clear, void* stream) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_read_flags_async: NULL handle");
+  return read_flags(h->device, workspace, stream, host_flags, clear, false, "oetr_read_flags_async");
+}
+oetr_status oetr_neck_query_flags(oetr_neck_handle h, void* workspace, void* stream, uint32_t* flags, int clear) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_query_flags: NULL handle");
-  return query_flags(h->device, h->flags, stream, flags, clear);
+  return read_flags(h->device, workspace, stream, flags, clear, true, "oetr_neck_query_flags");
+}
+oetr_status oetr_neck_read_flags_async(oetr_neck_handle h, void* workspace, uint32_t* host_flags, int clear,
+                                       void* stream) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_neck_read_flags_async: NULL handle");
+  return read_flags(h->device, workspace, stream, host_flags, clear, false, "oetr_neck_read_flags_async");
 }
 
 oetr_status oetr_neck_set_conv_kernel(oetr_neck_handle h, int kind) {

@@ -53,6 +53,10 @@ class OETRPluginMixin:
 
     def _forward(self, data):
         box1, box2 = self.net.forward_dummy(data['image0'], data['image1'])
+        # the dloc pipeline reads the boxes right away (Matching.forward, evaluation.py:77-113):
+        # settle the range check of THIS pair before handing them over (the batched front-end,
+        # pipeline.forward_pairs, defers it to the next batch instead)
+        self.net.hip_flush()
         return box1, box2
 
 

@@ -67,7 +67,8 @@ class _CropInfo(C.Structure):
                 ('ratio', (C.c_double * 2) * 2), ('sbox', (C.c_float * 4) * 2)]
 
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+WORKSPACE_STATUS_BYTES = 256   # OETR_WORKSPACE_STATUS_BYTES: the status block that opens a workspace
 EXPORTS = (
     'oetr_last_error', 'oetr_abi_version', 'oetr_create', 'oetr_destroy',
     'oetr_workspace_bytes', 'oetr_forward', 'oetr_forward_stages',
@@ -80,7 +81,8 @@ EXPORTS = (
     'oetr_neck_query_flags', 'oetr_overlap_crop', 'oetr_overlap_crop_capacity',
     'oetr_full_attention_split', 'oetr_set_attention', 'oetr_neck_set_conv_rows',
     'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel',
-    'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens')
+    'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens',
+    'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -211,7 +213,13 @@ def load_library(path=None):
     for name in ('oetr_query_flags', 'oetr_neck_query_flags'):
         fn = getattr(lib, name)
         fn.restype = i
-        fn.argtypes = [vp, vp, C.POINTER(C.c_uint32), i]
+        fn.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), i]      # handle, workspace, stream, out, clear
+    for name in ('oetr_read_flags_async', 'oetr_neck_read_flags_async'):
+        fn = getattr(lib, name)
+        fn.restype = i
+        fn.argtypes = [vp, vp, vp, i, vp]                         # handle, workspace, host word, clear, stream
+    lib.oetr_workspace_init.restype = i
+    lib.oetr_workspace_init.argtypes = [vp, sz, vp]
     lib.oetr_overlap_crop_capacity.restype = sz
     lib.oetr_overlap_crop_capacity.argtypes = [i, i, i, i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.oetr_overlap_crop.restype = i
@@ -246,11 +254,70 @@ def _stream(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _query_flags(lib, fn, handle, device, clear):
+def _query_flags(lib, fn, handle, ws, device, clear):
+    """Synchronising read of a workspace's status word (0 when the stream has no workspace yet)."""
+    if ws is None:
+        return 0
     flags = C.c_uint32(0)
     with torch.cuda.device(device):
-        _check(lib, fn(handle, _stream(device), C.byref(flags), int(bool(clear))), fn.__name__)
+        _check(lib, fn(handle, ws.data_ptr(), _stream(device), C.byref(flags), int(bool(clear))), fn.__name__)
     return int(flags.value)
+
+
+class FlagTicket:
+    """A status word on its way to the host: the copy was ENQUEUED (``oetr_read_flags_async``)
+    behind the calls it reports on, nothing has synchronised.  ``value()`` waits for that copy
+    only (an event recorded right behind it) - by the time the next batch is submitted it has
+    long completed."""
+
+    def __init__(self, slot, event):
+        self._slot, self._event = slot, event
+
+    def ready(self):
+        return self._event is None or self._event.query()
+
+    def value(self):
+        if self._event is not None:
+            self._event.synchronize()
+        return int(self._slot.item())
+
+
+class _FlagReader:
+    """Pinned host words for asynchronous status reads, one set per engine: a ring for eager
+    calls (each word is consumed before the ring comes round: the deferred check settles
+    batch i when batch i+1 is submitted) and words handed out for good to calls captured into
+    a HIP graph (every replay rewrites them).  Allocated up front - pinning host memory is
+    not allowed while a stream is capturing."""
+
+    SLOTS, GRAPH_SLOTS = 16, 16
+
+    def __init__(self):
+        self._words = torch.zeros(self.SLOTS + self.GRAPH_SLOTS, dtype=torch.int32).pin_memory()
+        self._next = 0
+        self._graph_next = 0
+
+    def read(self, lib, fn, handle, ws, device, clear):
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            if self._graph_next >= self.GRAPH_SLOTS:
+                raise OetrError('too many status reads captured into HIP graphs on one engine')
+            i = self.SLOTS + self._graph_next
+            self._graph_next += 1
+        else:
+            i = self._next
+            self._next = (self._next + 1) % self.SLOTS
+        slot = self._words[i:i + 1]
+        if ws is None:
+            slot.zero_()
+            return FlagTicket(slot, None)
+        with torch.cuda.device(device):
+            _check(lib, fn(handle, ws.data_ptr(), slot.data_ptr(), int(bool(clear)), _stream(device)),
+                   fn.__name__)
+            if capturing:
+                return FlagTicket(slot, None)      # valid once a replay has been synchronised
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+        return FlagTicket(slot, ev)
 
 
 def _dev(t, name):
@@ -349,6 +416,7 @@ class HotPathEngine:
                                               C.byref(handle)), 'oetr_create')
         self._h = handle
         self._ws = {}
+        self._flag_reader = _FlagReader()
         self._ws_shape = {}     # stream -> geometry the workspace was last carved for
         self._pos_loaded = {}   # stream -> key of the token-major position tables it holds
         if enc_tile is not None:
@@ -373,12 +441,23 @@ class HotPathEngine:
         _check(self.lib, self.lib.oetr_set_encoder_tile(self._h, int(rows or 0)),
                'oetr_set_encoder_tile')
 
+    def _current_ws(self):
+        return self._ws.get(torch.cuda.current_stream(self.device).cuda_stream)
+
     def query_flags(self, clear=True):
-        """Status word of the handle (``oetr_query_flags``): synchronises
-        torch's current stream on the engine's device.  Bit
-        ``FLAG_F16_RANGE`` = a GEMM operand of an earlier call reached the f16
-        range (f16-based precisions): that call's outputs are invalid."""
-        return _query_flags(self.lib, self.lib.oetr_query_flags, self._h, self.device, clear)
+        """Status word of the CURRENT STREAM's workspace (``oetr_query_flags``): synchronises
+        torch's current stream on the engine's device.  Bit ``FLAG_F16_RANGE`` = a GEMM
+        operand of an earlier call on this stream reached the f16 range (f16-based
+        precisions): that call's outputs are invalid.  Calls on other streams have their own
+        workspace and word."""
+        return _query_flags(self.lib, self.lib.oetr_query_flags, self._h, self._current_ws(),
+                            self.device, clear)
+
+    def read_flags_async(self, clear=True):
+        """The same without synchronising: a :class:`FlagTicket` whose ``value()`` is the word
+        as it stood behind every call enqueued on the current stream so far."""
+        return self._flag_reader.read(self.lib, self.lib.oetr_read_flags_async, self._h,
+                                      self._current_ws(), self.device, clear)
 
     def check_range(self):
         """Raise :class:`OetrRangeError` if any call since the last check
@@ -400,7 +479,12 @@ class HotPathEngine:
         key = torch.cuda.current_stream(self.device).cuda_stream
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
+            old = ws
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            if old is None:
+                ws[:WORKSPACE_STATUS_BYTES].zero_()       # oetr_workspace_init
+            else:                                         # a sticky flag survives the regrowth
+                ws[:WORKSPACE_STATUS_BYTES].copy_(old[:WORKSPACE_STATUS_BYTES])
             self._pos_loaded.pop(key, None)
         if self._ws_shape.get(key) != (n, hf1, wf1, hf2, wf2):   # another carve: tables gone
             self._ws_shape[key] = (n, hf1, wf1, hf2, wf2)
@@ -618,6 +702,7 @@ class NeckEngine:
                'oetr_neck_create')
         self._h = handle
         self._ws = {}
+        self._flag_reader = _FlagReader()
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -626,6 +711,18 @@ class NeckEngine:
                 self.lib.oetr_neck_destroy(h)
             except Exception:
                 pass
+
+    def _workspace(self, need):
+        key = torch.cuda.current_stream(self.device).cuda_stream   # one workspace per stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            old = ws
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            if old is None:
+                ws[:WORKSPACE_STATUS_BYTES].zero_()       # oetr_workspace_init
+            else:
+                ws[:WORKSPACE_STATUS_BYTES].copy_(old[:WORKSPACE_STATUS_BYTES])
+        return ws
 
     def forward(self, backbone_feat):
         """[n,1024,hb,wb] (ResNet layer3 output) -> feat [n,256,hb//2,wb//2]."""
@@ -637,10 +734,7 @@ class NeckEngine:
         need = self.lib.oetr_neck_workspace_bytes(self._h, n, hb, wb)
         if need == 0:
             raise ValueError(f'invalid neck shape n={n} grid {hb}x{wb}')
-        key = torch.cuda.current_stream(self.device).cuda_stream   # one workspace per stream
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._workspace(need)
         feat = torch.empty(n, D_MODEL, hb // 2, wb // 2, device=self.device)
         # launch on the ENGINE's device and on torch's current stream of that device
         # (the model may live on a GPU that is not torch's current device)
@@ -665,10 +759,7 @@ class NeckEngine:
         need = self.lib.oetr_neck_workspace_bytes(self._h, n, hb, wb)
         if need == 0:
             raise ValueError(f'invalid neck shape n={n} grid {hb}x{wb}')
-        key = torch.cuda.current_stream(self.device).cuda_stream
-        ws = self._ws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._workspace(need)
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.oetr_neck_forward_tokens(
                 self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
@@ -689,8 +780,14 @@ class NeckEngine:
                'oetr_neck_set_conv_kernel')
 
     def query_flags(self, clear=True):
-        """Status word of the neck handle (see ``HotPathEngine.query_flags``)."""
-        return _query_flags(self.lib, self.lib.oetr_neck_query_flags, self._h, self.device, clear)
+        """Status word of the current stream's neck workspace (see ``HotPathEngine.query_flags``)."""
+        ws = self._ws.get(torch.cuda.current_stream(self.device).cuda_stream)
+        return _query_flags(self.lib, self.lib.oetr_neck_query_flags, self._h, ws, self.device, clear)
+
+    def read_flags_async(self, clear=True):
+        ws = self._ws.get(torch.cuda.current_stream(self.device).cuda_stream)
+        return self._flag_reader.read(self.lib, self.lib.oetr_neck_read_flags_async, self._h, ws,
+                                      self.device, clear)
 
     def check_range(self):
         if self.query_flags(clear=True) & FLAG_F16_RANGE:

@@ -124,11 +124,18 @@ class OETR(nn.Module):
         #: encoder attention core: 'linear' (the reference's QueryTransformer default) or
         #: 'full' (EncoderLayer(attention='full'), reference transformer.py:86-89)
         self.hip_attention = 'linear'
-        #: what forward_dummy does when an f16-based precision ('f32_split_f16', 'f16',
-        #: and the HIP neck) reports an operand beyond the f16 range (|x| >= 65504):
+        #: what forward_dummy does when an f16-based precision ('f32_split_f16', 'f32_split_qk16',
+        #: 'f16', and the HIP neck) reports an operand beyond the f16 range (|x| >= 65504):
         #: 'f32' = redo the batch with exact-fp32 MFMA (neck: the torch modules),
-        #: 'raise' = OetrRangeError, 'ignore' = do not query (no stream sync)
+        #: 'raise' = OetrRangeError, 'ignore' = do not check
         self.hip_on_overflow = 'f32'
+        #: True (default): forward_dummy only ENQUEUES - the status word of batch i travels to a
+        #: pinned host word behind the batch (oetr_read_flags_async) and is examined when batch
+        #: i+1 is submitted, or by hip_flush(); a tripped batch is then re-run ('f32': its box
+        #: tensors are overwritten in place, in stream order) or reported ('raise').  The boxes
+        #: of the LAST batch are final after hip_flush().  False: check before returning (one
+        #: stream synchronisation per call, as the reference's consumers read boxes at once)
+        self.hip_defer_check = True
         #: True: the engines are bound to the weights once and only rebuilt by
         #: invalidate_engine() (skips the per-call parameter identity check)
         self.hip_freeze_weights = False
@@ -146,6 +153,10 @@ class OETR(nn.Module):
         self._engine_f32 = None
         self._neck_engine = None
         self._neck_key = None
+        self._hot_params = None       # cached parameter lists of the identity checks (engine())
+        self._neck_params = None
+        self._pending = None          # deferred range check of the previous batch (hip_defer_check)
+        self._graph_tickets = []      # status reads captured into HIP graphs (hip_graph_check)
 
     # ---------------------------------------------------------------- host
     def neck(self, x):
@@ -192,10 +203,14 @@ class OETR(nn.Module):
         """Drop the HIP engines (repacked weight copies, folded decoder constants):
         the next call rebuilds them from the module's current parameters.  Needed
         after writes the identity check below cannot see - ``param.data.copy_()``,
-        ``param.data.mul_()``, an EMA swap through ``.data`` - which neither move the
-        storage nor bump ``param._version``."""
+        ``param.data.mul_()``, an EMA swap through ``.data`` (neither move the storage
+        nor bump ``param._version``) - and after REPLACING a Parameter object of a
+        sub-module (the check walks a cached list of the parameter objects; ``.to()``,
+        ``load_state_dict`` and this method refresh it)."""
+        self.hip_flush()
         self._engine = self._engine_key = self._engine_f32 = None
         self._neck_engine = self._neck_key = None
+        self._hot_params = self._neck_params = None
 
     def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .half(): storages move
         self.invalidate_engine()
@@ -212,7 +227,9 @@ class OETR(nn.Module):
         if self.hip_freeze_weights and self._engine is not None and \
                 self._engine_key[:3] == (self.hip_precision, self.hip_enc_tile, self.hip_attention):
             return self._engine
-        params = [self.get_parameter(k) for k in hot_path_keys()]
+        if self._hot_params is None:      # (151 get_parameter() lookups cost ~0.5 ms: done once)
+            self._hot_params = [self.get_parameter(k) for k in hot_path_keys()]
+        params = self._hot_params
         key = (self.hip_precision, self.hip_enc_tile, self.hip_attention) + tuple(
             (p.data_ptr(), p._version) for p in params)
         if self._engine is None or key != self._engine_key:
@@ -247,7 +264,9 @@ class OETR(nn.Module):
         """HIP neck bound to the current neck weights (rebuilt when they change)."""
         if self.hip_freeze_weights and self._neck_engine is not None:
             return self._neck_engine
-        params = [self.get_parameter(k) for k in neck_keys()]
+        if self._neck_params is None:
+            self._neck_params = [self.get_parameter(k) for k in neck_keys()]
+        params = self._neck_params
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._neck_engine is None or key != self._neck_key:
             sd = self.state_dict()
@@ -289,6 +308,7 @@ class OETR(nn.Module):
         """Reference ``src/model.py:229-252``: images [N,H,W,3] in [0,1] ->
         (box1, box2), each [N,4] xyxy pixels."""
         self._no_masks(mask1, mask2)
+        self.hip_flush()          # the previous batch's deferred range check (no-op otherwise)
         h1, w1 = image1.shape[1:3]
         h2, w2 = image2.shape[1:3]
         self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
@@ -326,28 +346,86 @@ class OETR(nn.Module):
             neck.forward_tokens(bb1, bufs['tokens1'])
             neck.forward_tokens(bb2, bufs['tokens2'])
         boxes = eng.forward_tokens(n, hf1, wf1, hf2, wf2, hw1, hw2)
-        if self.hip_on_overflow != 'ignore':
-            tripped = neck.query_flags() & FLAG_F16_RANGE
-            if eng.precision in eng.F16_RANGE:
-                tripped |= eng.query_flags() & FLAG_F16_RANGE
-            if tripped:    # the unfused route carries the per-stage handling (raise / exact fp32)
-                feat1, feat2 = self.neck(bb1), self.neck(bb2)
-                return self.boxes_from_features(feat1, feat2, self.pos_encoding(feat1),
-                                                self.pos_encoding(feat2), hw1, hw2)
+        if self.hip_on_overflow == 'ignore':
+            return boxes
+
+        def rerun():   # the unfused route carries the per-stage handling (raise / exact fp32)
+            feat1, feat2 = self.neck(bb1), self.neck(bb2)
+            return self._boxes_checked(feat1, feat2, self.pos_encoding(feat1), self.pos_encoding(feat2),
+                                       hw1, hw2)
+        tickets = [neck.read_flags_async()]
+        if eng.precision in eng.F16_RANGE:
+            tickets.append(eng.read_flags_async())
+        return self._range_checked(boxes, tickets, rerun)
+
+    # ------------------------------------------------ deferred range check
+    def _range_checked(self, boxes, tickets, rerun):
+        """``boxes`` were enqueued together with ``tickets`` (asynchronous reads of the status
+        words behind them).  Deferred mode: remember them, return at once; the check runs at
+        the next submit / ``hip_flush()``.  Immediate mode: wait for the words now."""
+        if torch.cuda.is_current_stream_capturing():
+            # part of a HIP graph: nothing can be examined now, and every replay rewrites the
+            # words - hip_graph_check() reads them after the caller has synchronised a replay
+            self._graph_tickets += tickets
+            return boxes
+        if self.hip_defer_check:
+            self._pending = (boxes, tickets, rerun)
+            return boxes
+        return self._settle(boxes, tickets, rerun)
+
+    def hip_graph_check(self):
+        """Range guard of forward calls CAPTURED into a HIP graph (their status reads are graph
+        nodes writing pinned host words): call after synchronising a replay.  A captured batch
+        cannot be re-run from here, so a tripped word raises ``OetrRangeError`` whatever
+        ``hip_on_overflow`` says (except 'ignore': nothing was captured)."""
+        tripped = any(t.value() & FLAG_F16_RANGE for t in self._graph_tickets)
+        if tripped:
+            raise OetrRangeError('a batch replayed from a HIP graph overflowed the f16 operand range: '
+                                 're-submit it eagerly (exact-fp32 re-run) or use hip_precision "f32"')
+
+    def _settle(self, boxes, tickets, rerun):
+        if not any(t.value() & FLAG_F16_RANGE for t in tickets):
+            return boxes
+        good = rerun()              # raises under hip_on_overflow == 'raise'
+        for dst, src in zip(boxes, good):
+            dst.copy_(src)          # in place and in stream order: holders of `boxes` see the re-run
         return boxes
+
+    def hip_flush(self):
+        """Complete the deferred range check of the last submitted batch (``hip_defer_check``):
+        waits for that batch's status words only (an event behind an asynchronous 4-byte
+        copy).  A tripped batch is re-run in exact fp32 into the box tensors it returned
+        ('f32') or raises ``OetrRangeError`` ('raise').  Called automatically when the next
+        batch is submitted; call it before consuming the boxes of the LAST batch."""
+        pending, self._pending = getattr(self, '_pending', None), None
+        if pending is not None:
+            self._settle(*pending)
 
     def boxes_from_features(self, feat1, feat2, pos1, pos2, hw1, hw2):
         """Everything after ``feature_extraction`` (reference ``src/model.py:239-252``)
-        as one fused HIP call, with the f16 range guard of the chosen precision."""
+        as one fused HIP call, with the f16 range guard of the chosen precision (deferred
+        like ``forward_dummy``'s under ``hip_defer_check``)."""
+        self.hip_flush()
         eng = self.engine()
         boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2)
-        if self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE \
-                and eng.query_flags() & FLAG_F16_RANGE:
-            if self.hip_on_overflow == 'raise':
-                raise OetrRangeError(
-                    f"a GEMM operand reached |x| >= 65504 under hip_precision="
-                    f"'{eng.precision}'; set hip_precision to 'f32' or 'bf16'")
-            boxes = self.exact_engine().forward(feat1, feat2, pos1, pos2, hw1, hw2)
+        if self.hip_on_overflow == 'ignore' or eng.precision not in eng.F16_RANGE:
+            return boxes
+        return self._range_checked(boxes, [eng.read_flags_async()],
+                                   lambda: self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2))
+
+    def _exact_boxes(self, feat1, feat2, pos1, pos2, hw1, hw2):
+        if self.hip_on_overflow == 'raise':
+            raise OetrRangeError(
+                f"a GEMM operand reached |x| >= 65504 under hip_precision="
+                f"'{self.hip_precision}'; set hip_precision to 'f32' or 'bf16'")
+        return self.exact_engine().forward(feat1, feat2, pos1, pos2, hw1, hw2)
+
+    def _boxes_checked(self, feat1, feat2, pos1, pos2, hw1, hw2):
+        """Immediate (synchronising) form: the re-run route of a tripped fused batch."""
+        eng = self.engine()
+        boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2)
+        if eng.precision in eng.F16_RANGE and eng.query_flags() & FLAG_F16_RANGE:
+            boxes = self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2)
         return boxes
 
     def forward(self, data, validation=False):

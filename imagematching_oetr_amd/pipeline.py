@@ -64,6 +64,9 @@ def _run_plan(model, pairs, plan, device):
         b0, b1 = model.forward_dummy(im0, im1)
         for j, i in enumerate(idx):
             out[i] = (b0[j], b1[j])
+    flush = getattr(model, 'hip_flush', None)
+    if flush is not None:
+        flush()            # deferred range check of the last batch (OETR.hip_defer_check)
     return out
 
 
@@ -80,7 +83,7 @@ def forward_pairs(model, pairs, max_batch=8):
     float in [0,1] (any device; moved to the model's).  Returns ``(box0, box1)``,
     each ``[len(pairs), 4]`` xyxy pixels of the respective image, in input order."""
     if len(pairs) == 0:
-        z = torch.zeros(0, 4)
+        z = torch.zeros(0, 4, device=_model_device(model))
         return z, z.clone()
     shapes = [(tuple(_as_batch1(a).shape[1:3]), tuple(_as_batch1(b).shape[1:3])) for a, b in pairs]
     res = _run_plan(model, pairs, plan_batches(shapes, max_batch), _model_device(model))

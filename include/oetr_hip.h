@@ -14,11 +14,12 @@
  *    repacked copy of the weights (created by oetr_create);
  *  - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*): no
  *    allocation, no synchronisation, so a call sequence is hipGraph-capturable;
- *  - forward calls never modify a handle (its only device-side state is the
- *    sticky status word of oetr_query_flags, updated atomically): concurrent
- *    calls with distinct workspaces on distinct streams are safe.  The explicit
- *    setters (oetr_set_encoder_tile, oetr_set_trace) DO modify it and must not
- *    race with forward calls on the same handle;
+ *  - forward calls never modify a handle (the sticky status word of
+ *    oetr_query_flags lives in the caller's workspace): concurrent calls with
+ *    distinct workspaces on distinct streams are safe.  The explicit setters
+ *    (oetr_set_encoder_tile, oetr_set_attention, oetr_set_trace) DO modify it:
+ *    call them before the first forward call or while no call is in flight, and
+ *    re-query oetr_workspace_bytes after oetr_set_attention;
  *  - no environment variable is read by the library;
  *  - every function returns an oetr_status; oetr_last_error() gives the text
  *    for the calling thread.  Nothing throws.
@@ -35,7 +36,10 @@
 extern "C" {
 #endif
 
-#define OETR_ABI_VERSION 1
+/* 2: the status word moved from the handle into the workspace (oetr_query_flags takes the
+ *    workspace; oetr_workspace_init, oetr_read_flags_async are new), oetr_linear_attention takes
+ *    a workspace, OETR_DTYPE_F32_SPLIT_QK16 */
+#define OETR_ABI_VERSION 2
 #define OETR_D_MODEL 256
 #define OETR_N_HEAD 8
 #define OETR_N_ENC 8 /* self,cross x4  - reference src/models/transformer.py:295 */
@@ -156,20 +160,35 @@ oetr_status oetr_create(const oetr_weights *w, oetr_dtype dtype, int device,
                         oetr_handle *out);
 void oetr_destroy(oetr_handle h);
 
-/* Status word of a handle: bits set (atomically, sticky) by the kernels of any
- * forward call since creation / the last clearing query.
+/* Status word of a WORKSPACE: bits set (atomically, sticky) by the kernels of every forward
+ * call that used this workspace since it was initialised / last cleared.  The word is the
+ * first 4 bytes of the workspace (the first OETR_WORKSPACE_STATUS_BYTES are reserved for it,
+ * at a shape-independent position), so callers that overlap batches on several streams - one
+ * workspace per stream - see and clear only their own stream's calls.
  *   OETR_FLAG_F16_RANGE  a GEMM operand (activation) reached |x| >= 65504 in an
- *                        f16-based dtype (F32_SPLIT_F16, F16) and could not be
+ *                        f16-based dtype (F32_SPLIT_F16, F32_SPLIT_QK16, F16) and could not be
  *                        represented: the outputs of that call are INVALID.  Re-run
  *                        with a handle created as OETR_DTYPE_F32 or OETR_DTYPE_BF16.
- * oetr_query_flags copies the word to *flags (host), optionally clears it, and
- * SYNCHRONISES `stream` (the one call of this library that does): ordered after
- * every forward call previously enqueued on that stream.  Weights are range-checked
- * by oetr_create (OETR_ERR_UNSUPPORTED).  Nothing like this exists in the fp32
- * reference; it guards the reduced-range operand formats. */
+ * oetr_workspace_init   zeroes the status block (enqueued on `stream`); call it once after
+ *                       allocating a workspace (or zero the first 256 bytes yourself).
+ * oetr_query_flags      copies the word to *flags (host), optionally clears it, and
+ *                       SYNCHRONISES `stream` (the one call of this library that does):
+ *                       ordered after every forward call enqueued on that stream before.
+ * oetr_read_flags_async the same WITHOUT the synchronisation: the copy into `host_flags`
+ *                       (pinned host memory for a truly asynchronous copy) and the optional
+ *                       clear are enqueued on `stream`; read *host_flags after an event /
+ *                       synchronisation of your own.  Enqueue-only, hipGraph-capturable:
+ *                       the deferred form of the check (examine batch i's word when batch
+ *                       i+1 is submitted).
+ * Weights are range-checked by oetr_create (OETR_ERR_UNSUPPORTED).  Nothing like this exists
+ * in the fp32 reference; it guards the reduced-range operand formats. */
 #define OETR_FLAG_F16_RANGE 1u
-oetr_status oetr_query_flags(oetr_handle h, void *stream, uint32_t *flags,
-                             int clear);
+#define OETR_WORKSPACE_STATUS_BYTES 256
+oetr_status oetr_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+oetr_status oetr_query_flags(oetr_handle h, void *workspace, void *stream,
+                             uint32_t *flags, int clear);
+oetr_status oetr_read_flags_async(oetr_handle h, void *workspace,
+                                  uint32_t *host_flags, int clear, void *stream);
 
 /* Token rows per encoder workgroup: 0 = auto (default), 32 or 64.  64 exists in
  * the 16-bit-operand dtypes only (ignored for OETR_DTYPE_F32): fewer
@@ -358,10 +377,13 @@ oetr_status oetr_neck_set_conv_rows(oetr_neck_handle h, int rows);
  * sum the same products in a different order (fp32 rounding-level differences).
  * Mutates the handle. */
 oetr_status oetr_neck_set_conv_kernel(oetr_neck_handle h, int kind);
-/* Status word of the neck handle (see oetr_query_flags): OETR_FLAG_F16_RANGE when a
+/* Status word of a NECK workspace (same layout and rules as oetr_query_flags /
+ * oetr_read_flags_async; initialise with oetr_workspace_init): OETR_FLAG_F16_RANGE when a
  * backbone feature / intermediate reached the f16 range of its split GEMMs. */
-oetr_status oetr_neck_query_flags(oetr_neck_handle h, void *stream,
+oetr_status oetr_neck_query_flags(oetr_neck_handle h, void *workspace, void *stream,
                                   uint32_t *flags, int clear);
+oetr_status oetr_neck_read_flags_async(oetr_neck_handle h, void *workspace,
+                                       uint32_t *host_flags, int clear, void *stream);
 
 /* ---- box -> crop step on the device ---------------------------
  * Replaces, for one image pair, the overlap branch of Matching.forward (reference

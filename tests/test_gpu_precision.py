@@ -272,9 +272,7 @@ def test_out_of_range_activations_set_the_flag(gpu, precision):
         assert e2.query_flags() == 0 and torch.isfinite(b1).all() and torch.isfinite(b2).all()
 
 
-def test_module_reruns_an_overflowing_batch_in_exact_fp32(gpu):
-    """Drop-in module: hip_on_overflow='f32' (default) answers an out-of-range batch
-    with the exact-fp32 engine's boxes; 'raise' raises; never a silent wrong box."""
+def _overflow_model(gpu):
     import imagematching_oetr_amd as pkg
     torch.manual_seed(0)
     model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
@@ -285,8 +283,21 @@ def test_module_reruns_an_overflowing_batch_in_exact_fp32(gpu):
     model = model.to(gpu)
     f1, f2 = orc.make_features(95, 2, 8, 10) * 4.0e5, orc.make_features(96, 2, 10, 8)
     p1, p2 = orc.position_table(8, 10), orc.position_table(10, 8)
-    dev = [t.to(gpu) for t in (f1, f2, p1, p2)]
+    return pkg, model, w, [t.to(gpu) for t in (f1, f2, p1, p2)]
+
+
+@pytest.mark.parametrize('defer', [True, False])
+def test_module_reruns_an_overflowing_batch_in_exact_fp32(gpu, defer):
+    """Drop-in module: hip_on_overflow='f32' (default) answers an out-of-range batch
+    with the exact-fp32 engine's boxes; 'raise' raises; never a silent wrong box.
+    Deferred mode (default): the call itself only enqueues; the re-run lands IN the returned
+    tensors when the next batch is submitted or at hip_flush()."""
+    pkg, model, w, dev = _overflow_model(gpu)
+    model.hip_defer_check = defer
     b1, b2 = model.boxes_from_features(*dev, (256, 320), (320, 256))
+    if defer:
+        assert model._pending is not None
+        model.hip_flush()
     exact = pkg.HotPathEngine(w, device=gpu, precision='f32')
     e1, e2 = exact.forward(*dev, (256, 320), (320, 256))
     assert torch.equal(b1, e1) and torch.equal(b2, e2) and torch.isfinite(b1).all()
@@ -295,13 +306,56 @@ def test_module_reruns_an_overflowing_batch_in_exact_fp32(gpu):
     assert model.engine().query_flags() & pkg.FLAG_F16_RANGE
     del raw
     model.hip_on_overflow = 'raise'
-    with pytest.raises(pkg.OetrRangeError):
-        model.boxes_from_features(*dev, (256, 320), (320, 256))
+    if defer:
+        model.boxes_from_features(*dev, (256, 320), (320, 256))       # enqueues, reports later
+        with pytest.raises(pkg.OetrRangeError):
+            model.hip_flush()
+    else:
+        with pytest.raises(pkg.OetrRangeError):
+            model.boxes_from_features(*dev, (256, 320), (320, 256))
     # in-range batches never leave the default engine
     model.hip_on_overflow = 'f32'
     model._engine_f32 = None
     model.boxes_from_features(dev[0] / 4.0e5, *dev[1:], (256, 320), (320, 256))
+    model.hip_flush()
     assert model._engine_f32 is None
+
+
+def test_deferred_check_settles_one_call_later(gpu):
+    """hip_defer_check: batch i's status word is examined when batch i+1 is submitted - the
+    injected x4e5 batch's boxes are overwritten by the exact re-run at that point, and the
+    in-range batch that follows is untouched."""
+    pkg, model, w, dev = _overflow_model(gpu)
+    good = [dev[0] / 4.0e5] + dev[1:]
+    bad1, bad2 = model.boxes_from_features(*dev, (256, 320), (320, 256))      # trips, unnoticed so far
+    assert model._pending is not None and model._engine_f32 is None
+    ok1, ok2 = model.boxes_from_features(*good, (256, 320), (320, 256))       # settles the first
+    assert model._engine_f32 is not None
+    exact = pkg.HotPathEngine(w, device=gpu, precision='f32')
+    e1, e2 = exact.forward(*dev, (256, 320), (320, 256))
+    assert torch.equal(bad1, e1) and torch.equal(bad2, e2)
+    model.hip_flush()
+    r1, r2 = model.engine().forward(*good, (256, 320), (320, 256))
+    assert torch.equal(ok1, r1) and torch.equal(ok2, r2)
+
+
+def test_status_words_are_per_stream(gpu):
+    """the status word lives in the per-stream workspace - an overflow on stream B
+    is neither seen nor cleared by a query on stream A."""
+    pkg, model, w, dev = _overflow_model(gpu)
+    eng = pkg.HotPathEngine(w, device=gpu)
+    good = [dev[0] / 4.0e5] + dev[1:]
+    sa, sb = torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sb):
+        eng.forward(*dev, (256, 320), (320, 256))          # overflows on B
+    with torch.cuda.stream(sa):
+        eng.forward(*good, (256, 320), (320, 256))
+        assert eng.query_flags(clear=True) == 0            # A's own word: clean, and B's untouched
+    with torch.cuda.stream(sb):
+        assert eng.query_flags(clear=True) & pkg.FLAG_F16_RANGE
+        assert eng.query_flags() == 0
+    torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------ magnitude stress
