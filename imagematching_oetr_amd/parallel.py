@@ -71,7 +71,11 @@ class BoxGatherer:
     batch k+1 is submitted, so the latency-bound gather runs under the next
     batch's compute.  ``submit`` returns the gathered boxes of
     the PREVIOUS batch (None the first time); ``flush`` returns the last one.
-    Equal shards only (every rank holds ``n_local`` pairs)."""
+
+    ``submit(box1, box2)``: every rank holds the same number of pairs (the bench's weak
+    scaling).  ``submit(box1, box2, n_pairs=N)``: the ranks hold the contiguous
+    ``shard_bounds`` slices of N pairs (sizes differ by at most one); shards are padded to
+    the largest and the padding dropped after the gather, like ``gather_boxes``."""
 
     def __init__(self, group=None):
         self.group = group
@@ -80,20 +84,40 @@ class BoxGatherer:
     def _finish(self):
         if self._pending is None:
             return None
-        work, everyone, n_pairs = self._pending
+        work, everyone, n_pairs, keep = self._pending
         self._pending = None
         work.wait()
+        if keep is not None:                                   # unequal shards: drop the padding
+            everyone = everyone.index_select(0, keep.to(everyone.device))
+            return everyone[:, 0].contiguous(), everyone[:, 1].contiguous()
         return (everyone[:, 0].reshape(n_pairs, 4), everyone[:, 1].reshape(n_pairs, 4))
 
-    def submit(self, box1, box2):
+    def submit(self, box1, box2, n_pairs=None):
         done = self._finish()
         world = dist.get_world_size(self.group)
-        mine = torch.stack((box1, box2))                          # [2, n_local, 4]
-        flat = torch.empty((world * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype,
-                           device=mine.device)             # concatenation along dim 0
-        work = dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)
-        self._pending = (work, flat.view((world, 2) + tuple(mine.shape[1:])),
-                         world * box1.shape[0])
+        if n_pairs is None or n_pairs % world == 0:
+            if n_pairs is not None and box1.shape[0] * world != n_pairs:
+                raise ValueError(f'this rank holds {box1.shape[0]} pairs, expected {n_pairs // world}')
+            mine = torch.stack((box1, box2))                          # [2, n_local, 4]
+            flat = torch.empty((world * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype,
+                               device=mine.device)             # concatenation along dim 0
+            work = dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)
+            self._pending = (work, flat.view((world, 2) + tuple(mine.shape[1:])),
+                             world * box1.shape[0], None)
+            return done
+        rank = dist.get_rank(self.group)
+        lo, hi = shard_bounds(n_pairs, rank, world)
+        if box1.shape[0] != hi - lo or box2.shape[0] != hi - lo:
+            raise ValueError(f'rank {rank} holds {box1.shape[0]} pairs, expected {hi - lo} of {n_pairs}')
+        cap = -(-n_pairs // world)
+        mine = torch.zeros(cap, 2, 4, dtype=box1.dtype, device=box1.device)
+        mine[:hi - lo, 0] = box1
+        mine[:hi - lo, 1] = box2
+        everyone = torch.empty(world * cap, 2, 4, dtype=box1.dtype, device=box1.device)
+        work = dist.all_gather_into_tensor(everyone, mine, group=self.group, async_op=True)
+        sizes = [shard_bounds(n_pairs, r, world) for r in range(world)]
+        keep = torch.cat([torch.arange(r * cap, r * cap + (b - a)) for r, (a, b) in enumerate(sizes)])
+        self._pending = (work, everyone, n_pairs, keep)
         return done
 
     def flush(self):

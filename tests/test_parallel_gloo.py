@@ -110,6 +110,54 @@ def test_pipelined_box_gatherer_world2_gloo():
         assert outs == [[0.0, 0.0, 1.0, 1.0], [10.0, 10.0, 11.0, 11.0], [20.0, 20.0, 21.0, 21.0]]
 
 
+def _unequal_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from imagematching_oetr_amd.parallel import BoxGatherer
+        g = BoxGatherer()
+        outs = []
+        for k, n_pairs in enumerate((5, 7, 4)):      # 3+2, 4+3, then an equal 2+2 batch
+            lo, hi = shard_bounds(n_pairs, rank, world)
+            idx = torch.arange(lo, hi, dtype=torch.float32) + 100 * k
+            b1 = torch.stack([idx, idx + 0.25, idx + 0.5, idx + 0.75], 1)
+            done = g.submit(b1, -b1, n_pairs=n_pairs)
+            if done is not None:
+                outs.append((done[0].tolist(), done[1].tolist()))
+        last = g.flush()
+        outs.append((last[0].tolist(), last[1].tolist()))
+        try:                                          # a shard of the wrong size is an error, not a hang
+            g.submit(torch.zeros(1, 4), torch.zeros(1, 4), n_pairs=5)
+            bad = False
+        except ValueError:
+            bad = True
+        q.put((rank, outs, bad))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_box_gatherer_unequal_shards_world2_gloo():
+    """BoxGatherer with contiguous shards whose sizes differ by one: padded
+    to the largest shard for the one all_gather_into_tensor, padding dropped afterwards."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_unequal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, bad in results:
+        assert bad, rank
+        for k, n_pairs in enumerate((5, 7, 4)):
+            idx = torch.arange(n_pairs, dtype=torch.float32) + 100 * k
+            expect = torch.stack([idx, idx + 0.25, idx + 0.5, idx + 0.75], 1)
+            assert torch.equal(torch.tensor(outs[k][0]), expect), (rank, k)
+            assert torch.equal(torch.tensor(outs[k][1]), -expect), (rank, k)
+
+
 class _StubModel:
     """forward_dummy with the reference's contract ([N,H,W,3] images -> two [N,4]
     boxes) computed from the images alone, so that sharding is observable."""
