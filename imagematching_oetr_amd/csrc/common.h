@@ -852,9 +852,6 @@ struct PlanesT {  // 16-bit planes [RT][LDAH] (hi, and lo*2^11 in GM_SPLIT) in o
 };
 typedef PlanesT<GM_SPLIT> Planes2;
 
-#ifndef OETR_ALWAYS_TWO
-#define OETR_ALWAYS_TWO 1
-#endif
 #ifndef OETR_RING2
 #define OETR_RING2 4   // k16 steps of B fragments in the ring (one being consumed), split mode
 #endif
@@ -921,32 +918,24 @@ template <> struct SitePolicy<1> {   // OETR_DTYPE_F32_SPLIT_QK16
 };
 constexpr int N_POLICIES = 2;
 
-template <int M>
+// ROWS: how many of the tile's two 32-row MFMA tiles run.  2 / 1: fixed at compile time - the
+// GEMM steps are branch-free, which is what lets hipcc interleave a step's MFMAs with the
+// epilogue slice issued beside them (EPI below); the encoder picks the body per workgroup.
+// 0: decided at run time from the number of valid rows (a wave-uniform branch around every
+// second-tile MFMA: conv-P work items, single-plane modes - measured better there: their steps
+// are two MFMAs long).  With one row tile the accumulators of the second keep their (finite)
+// initial values, which every consumer masks by row validity.
+template <int M, int ROWS = 0>
 struct WStream2T {
   static constexpr bool TWO = gm_planes(M) == 2;
   static constexpr int D = TWO ? OETR_RING2 : OETR_RING2_1P, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
   struct BStep { f32x4 bh, bl; };
   struct AStep { f32x4 ah[2], al[2]; };
   BStep ring[D];
-#if OETR_ALWAYS_TWO
-  // Split mode: both 32-row MFMA tiles always run - rows past the tile's end hold the duplicated
-  // last valid row (finite) and are masked by every consumer.  Branch-free steps are what lets
-  // hipcc interleave a step's MFMAs with the epilogue slice issued beside them (EPI below): a
-  // tile with <= 32 valid rows (one in seven at 400 tokens per image) runs as long as a full
-  // one instead of finishing early - measured: the interleave gains more (58.2 -> 55.7 us per
-  // B;A launch with it, 58.9 without).  The single-plane modes keep the skip (measured slower
-  // without it: their steps are two MFMAs long).
-  static constexpr bool ALWAYS2 = TWO;
-#else
-  static constexpr bool ALWAYS2 = false;
-#endif
-  // false: the tile has <= 32 valid rows and the MFMAs of the second row tile are skipped; its
-  // accumulators keep their finite initial values, which every consumer masks by row
-  // validity.  Wave-uniform (an SGPR branch).
   bool two_rt = true;
-  __device__ __forceinline__ bool two() const { return ALWAYS2 || two_rt; }
+  __device__ __forceinline__ bool two() const { return ROWS == 2 || (ROWS == 0 && two_rt); }
   __device__ __forceinline__ void set_rows(int nvalid) {
-    if constexpr (!ALWAYS2) two_rt = __builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0) != 0;
+    if constexpr (ROWS == 0) two_rt = __builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0) != 0;
   }
   static constexpr int adv(int P) { return (P + NS) % D; }
 

@@ -805,11 +805,13 @@ __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int
   if (lane < 32) ks_out[(size_t)slot * C + wave * HD + lane] = ksum;
 }
 
-template <bool HAS_B, int TAIL, int MODE, int POL = 0>
-__global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
+// Body of k_encoder64 for one workgroup.  ROWS (WStream2T): 2 = both 32-row MFMA tiles hold valid
+// rows, 1 = only the first does (a ragged last tile of an image: every piece of work on the
+// second row tile is compiled out), 0 = decided at run time (single-plane modes).
+template <bool HAS_B, int TAIL, int MODE, int POL, int ROWS>
+__device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) {
   constexpr int THREADS = 512, TPR = 8, F4 = 8;
   using SP = SitePolicy<POL>;   // arithmetic per GEMM site (two-plane mode only)
-  __shared__ __attribute__((aligned(16))) float smem[E2_SMEM];
   float* R1f = smem + E2_R1;
   float* R2f = smem + E2_R2;
   Range rg;
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
   float* ksum_s = smem + E2_KSUM;
   float* z_s = smem + E2_Z;
   float* lnp_s = smem + E2_LNP;
-  using WS = WStream2T<MODE>;
+  using WS = WStream2T<MODE, ROWS>;
   WS ws;
   constexpr int P_MERGE = 0;
   constexpr int P_1A = WS::adv(P_MERGE), P_2A = WS::adv(P_1A), P_1B = WS::adv(P_2A), P_2B = WS::adv(P_1B);
@@ -1193,6 +1195,27 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     dec_layer(std::integral_constant<int, 1>{});
   }
   range_report<MODE>(rg, p.flags);
+}
+
+template <bool HAS_B, int TAIL, int MODE, int POL = 0>
+__global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
+  __shared__ __attribute__((aligned(16))) float smem[E2_SMEM];
+  if constexpr (gm_planes(MODE) == 2) {
+    // split mode: the row-tile count is a compile-time property of the body (branch-free GEMM
+    // steps, which is what lets hipcc interleave the epilogue slices with the MFMAs), chosen
+    // per workgroup - a workgroup-uniform branch at the top instead of one around every MFMA
+    const Geom& g = p.g;
+    const int logical = xcd_remap(blockIdx.x, g.ntiles);
+    const int per = g.nt[0] + g.nt[1];
+    const int rem = logical - (logical / per) * per;
+    const int side = rem >= g.nt[0];
+    const int t_idx = side ? rem - g.nt[0] : rem;
+    const int nvalid = min(RT, g.L[side] - t_idx * RT);
+    if (__builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0)) encoder64_body<HAS_B, TAIL, MODE, POL, 2>(p, smem);
+    else encoder64_body<HAS_B, TAIL, MODE, POL, 1>(p, smem);
+  } else {
+    encoder64_body<HAS_B, TAIL, MODE, POL, 0>(p, smem);
+  }
 }
 
 #ifndef OETR_SPLIT_WAVES
