@@ -263,6 +263,34 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
 #endif
 }
 
+// Four GELUs as TWO interleaved packed chains: the polynomial is a serial chain of dependent
+// FMAs (one chain alone issues an instruction every ~8 cycles beside MFMAs); two independent
+// chains stepping together fill each other's latency.  Same operations per value as gelu_erf2.
+__device__ __forceinline__ f32x4 gelu_erf4(const f32x4& v) {
+#if defined(OETR_OCML_ERF) || OETR_GELU_TWO_BRANCH
+  const f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+#else
+  const f32x2 v0 = f32x2{v[0], v[1]}, v1 = f32x2{v[2], v[3]};
+  const f32x2 a0 = __builtin_elementwise_abs(v0), a1 = __builtin_elementwise_abs(v1);
+  const f32x2 w0 = f32x2{fminf(a0[0], GELU_T), fminf(a0[1], GELU_T)};
+  const f32x2 w1 = f32x2{fminf(a1[0], GELU_T), fminf(a1[1], GELU_T)};
+  f32x2 q0 = splat2(GELU_Q[9]), q1 = splat2(GELU_Q[9]);
+#pragma unroll
+  for (int i = 8; i >= 0; --i) {
+    q0 = __builtin_elementwise_fma(q0, w0, splat2(GELU_Q[i]));
+    q1 = __builtin_elementwise_fma(q1, w1, splat2(GELU_Q[i]));
+  }
+  const f32x2 u0 = w0 * q0, u1 = w1 * q1;
+  f32x4 g;
+  g[0] = fmaf(-0.5f * a0[0], __builtin_amdgcn_exp2f(u0[0]), fmaxf(v[0], 0.f));
+  g[2] = fmaf(-0.5f * a1[0], __builtin_amdgcn_exp2f(u1[0]), fmaxf(v[2], 0.f));
+  g[1] = fmaf(-0.5f * a0[1], __builtin_amdgcn_exp2f(u0[1]), fmaxf(v[1], 0.f));
+  g[3] = fmaf(-0.5f * a1[1], __builtin_amdgcn_exp2f(u1[1]), fmaxf(v[3], 0.f));
+  return g;
+#endif
+}
+
 // XCD-aware bijective remap: hardware block b runs on XCD b % 8; give each
 // XCD a contiguous run of logical tiles so tiles of one image pair share an L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -345,37 +373,44 @@ __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda
 // ---- 16-bit-plane GEMM core (GM_SPLIT / GM_F16 / GM_BF16) -----------------
 // hi/lo halves of two floats: (hi0,hi1) and (lo0,lo1) packed as f16x2.
 __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
-  // Two floats per conversion instruction.  a - (float)hi is exact in f32 and lands in lo;
-  // truncating lo (v_cvt_pkrtz) costs <= 2^-21 relative, inside the budget (tests:
-  // fp32-class vs fp64).
-  hi = __builtin_convertvector(f32x2{a, b}, f16x2);   // RNE (v_cvt_pk_f16_f32): the hi plane alone
-                                                      // is the f16 rounding of the value (SITE_HI)
-  lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((a - (float)hi[0]) * SPLIT_SCALE,
-                                                            (b - (float)hi[1]) * SPLIT_SCALE));
+  // hi = RNE f16 (v_cvt_pk_f16_f32): the hi plane alone is the f16 rounding of the value
+  // (SITE_HI), and an unrepresentable value becomes inf, which the range guard reads off the
+  // bits.  lo = (a - hi) * 2^11, truncated (v_cvt_pkrtz: <= 2^-21 relative, inside the budget -
+  // tests: fp32-class vs fp64), formed as a * 2^11 - hi * 2^11: both products and their
+  // difference are exact (a - hi is representable), and the f16 operand goes straight into
+  // v_fma_mix_f32 - 6 VALU per pair instead of 8 (no v_cvt_f32_f16).
+  hi = __builtin_convertvector(f32x2{a, b}, f16x2);
+  lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(
+                                     __builtin_fmaf((float)hi[0], -SPLIT_SCALE, a * SPLIT_SCALE),
+                                     __builtin_fmaf((float)hi[1], -SPLIT_SCALE, b * SPLIT_SCALE)));
 }
-// Range guard of the f16-based modes (GM_SPLIT, GM_F16): every activation that is
-// converted into a GEMM operand is compared with the f16 maximum (two VALU + one SALU
-// instruction per two values - noise next to the conversion itself); a kernel ends with
-// range_report(),
-// which sets FLAG_F16_RANGE in the handle's device flag word (one atomicOr, only when
-// violated) if any operand was >= 65504 (or inf) and so could not be represented.
-// The host reads the word with oetr_query_flags().  Weights are checked at create.
+// Range guard of the f16-based modes (GM_SPLIT, GM_F16): every activation that is converted
+// into a GEMM operand leaves its f16 bit pattern in a running maximum (Range, two VALU per
+// two values); a kernel ends with range_report(), which sets FLAG_F16_RANGE in the
+// workspace's status word (one atomicOr, only when violated) if any operand could not be
+// represented (|x| >= 65520 rounds to inf; NaN counts too).  The host reads the word with
+// oetr_query_flags() / oetr_read_flags_async().  Weights are checked at create.
 constexpr uint32_t FLAG_F16_RANGE = 1u;   // == OETR_FLAG_F16_RANGE
 constexpr float F16_MAX = 65504.0f;
 constexpr bool gm_f16_range(int m) { return m == GM_SPLIT || m == GM_F16; }
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 struct Range {
-  // Wave-uniform violation mask, kept in an SGPR pair (v_cmp + s_or_b64 per check): the
-  // encoder kernels sit at the 256-VGPR limit and a per-lane running maximum carried
-  // across the whole kernel tips them into scratch spills.
-  unsigned long long bad = 0;
-  __device__ __forceinline__ void see(float a, float b) {
-    bad |= __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a), fabsf(b)) >= F16_MAX);
+  // Running maximum of the f16 BIT PATTERNS (sign cleared) of every converted pair, per lane:
+  // v_and + v_pk_max_u16 per pair, no scalar work.  The conversions round to nearest, so a
+  // value the format cannot hold arrives as inf (0x7c00; NaN is larger) and the ordering of
+  // f16 magnitudes is the ordering of their bit patterns.  (Round 2 kept a wave-uniform mask
+  // in SGPRs - v_max + v_cmp + s_or per pair and ~450 SGPR spills per kernel.)
+  uint32_t mx = 0;
+  __device__ __forceinline__ void see_hi(uint32_t hi_pair) {
+    mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, mx),
+                                                                __builtin_bit_cast(u16x2, hi_pair & 0x7fff7fffu)));
   }
+  __device__ __forceinline__ bool bad() const { return (mx & 0xffffu) >= 0x7c00u || (mx >> 16) >= 0x7c00u; }
 };
 template <int M>
 __device__ __forceinline__ void range_report(const Range& rg, uint32_t* flags) {
   if constexpr (gm_f16_range(M)) {
-    if (rg.bad != 0 && (threadIdx.x & 63) == 0) atomicOr(flags, FLAG_F16_RANGE);
+    if (__builtin_amdgcn_ballot_w64(rg.bad()) != 0 && (threadIdx.x & 63) == 0) atomicOr(flags, FLAG_F16_RANGE);
   }
 }
 // Two floats -> the mode's operand representation: `hi` = the (only, or high) plane's two
@@ -383,7 +418,6 @@ __device__ __forceinline__ void range_report(const Range& rg, uint32_t* flags) {
 // nearest even (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32).
 template <int M>
 __device__ __forceinline__ void cvt_planes2(float a, float b, uint32_t& hi, uint32_t& lo, Range& rg) {
-  if constexpr (gm_f16_range(M)) rg.see(a, b);
   if constexpr (M == GM_SPLIT) {
     f16x2 h, l;
     split2(a, b, h, l);
@@ -396,6 +430,7 @@ __device__ __forceinline__ void cvt_planes2(float a, float b, uint32_t& hi, uint
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
     lo = 0;
   }
+  if constexpr (gm_f16_range(M)) rg.see_hi(hi);
 }
 // One 32x32x16 MFMA on raw 16-byte fragments in the mode's element type.
 template <int M>

@@ -38,6 +38,13 @@
 #define OETR_SPLIT_APPLY 1
 #endif
 
+#ifndef OETR_ABL_EPI
+#define OETR_ABL_EPI 0
+#endif
+#ifndef OETR_MLP1_TR
+#define OETR_MLP1_TR 1
+#endif
+
 namespace oetr {
 
 // ---------------------------------------------------------------------------
@@ -1001,6 +1008,38 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     {
       constexpr int SNEXT = TAIL == 0 ? SP::Q : SP::DEC_K;   // first GEMM of the tail
       f32x16 haccA[2] = {f32x16{0}, f32x16{0}}, haccB[2] = {f32x16{0}, f32x16{0}};
+#if OETR_MLP1_TR
+      // MLP1 runs TRANSPOSED (WStream2T: TR): a lane then holds, per register quad, FOUR
+      // CONSECUTIVE hidden channels of one token - the GELU epilogue writes its planes with
+      // 8-byte LDS stores (2 per quad) instead of 2-byte ones (8 per quad), one quad = two
+      // interleaved packed-GELU chains every other k16 step
+      ws.template gemm<C, P_1A, true, C, SP::MLP1, SP::MLP1, true>(P1, p.b.w1, p.b.w1_l, wave, 0, lane, haccA,
+                                                                   p.b.w1, p.b.w1_l, 8 + wave, 0);
+      const bool two = ws.two();
+      auto gelu_to = [&](const PlanesT<MODE>& dst, const f32x16 (&h)[2]) {
+        return [&, two](auto CI_) {
+          constexpr int CI = decltype(CI_)::value, mt = CI / 8, g4 = (CI % 8) / 2;
+          if constexpr (CI % 2 == 0) {
+            if (mt == 1 && !two) return;   // (hidden rows 32.. stay unwritten: never consumed)
+#if OETR_ABL_EPI == 1      // timing ablation only (wrong results): no GELU arithmetic
+            const f32x4 ge = f32x4{h[mt][4 * g4], h[mt][4 * g4 + 1], h[mt][4 * g4 + 2], h[mt][4 * g4 + 3]};
+#else
+            const f32x4 ge = gelu_erf4(f32x4{h[mt][4 * g4], h[mt][4 * g4 + 1], h[mt][4 * g4 + 2], h[mt][4 * g4 + 3]});
+#endif
+#if OETR_ABL_EPI == 2      // timing ablation only: GELU kept alive, no split conversion / plane stores
+            if (ge[0] + ge[1] + ge[2] + ge[3] == 123.456f) dst.h[lane] = (_Float16)1;
+#elif OETR_ABL_EPI == 3    // timing ablation only: nothing at all
+            (void)ge;
+#else
+            dst.template put4<site_act_lo(SP::MLP2)>(32 * mt + col, wcol + 8 * g4 + 4 * half, ge);
+#endif
+          }
+        };
+      };
+      auto epiA = gelu_to(P2, haccA);
+      ws.template gemm_epi<C, P_1B, true, FF, SP::MLP1, SP::MLP2, true>(P1, p.b.w1, p.b.w1_l, 8 + wave, 0, lane,
+                                                                        haccB, p.b.w2, p.b.w2_l, wave, 0, epiA);
+#else
       ws.template gemm<C, P_1A, true, C, SP::MLP1, SP::MLP1>(P1, p.b.w1, p.b.w1_l, wave, 0, lane, haccA,
                                                              p.b.w1, p.b.w1_l, 8 + wave, 0);
       const bool two = ws.two();
@@ -1015,6 +1054,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       auto epiA = gelu_to(P2, haccA);
       ws.template gemm_epi<C, P_1B, true, FF, SP::MLP1, SP::MLP2>(P1, p.b.w1, p.b.w1_l, 8 + wave, 0, lane,
                                                                   haccB, p.b.w2, p.b.w2_l, wave, 0, epiA);
+#endif
       __syncthreads();   // hidden half a complete; every wave is done reading the LN2 planes
       PHASE_STAMP(p, 5);
       auto epiB = gelu_to(P1, haccB);

@@ -59,8 +59,8 @@ __device__ __forceinline__ void proj_stage(const ATile<GM_SPLIT>& A, const float
     f16x2 h[4], l[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      A.rg->see(v[2 * j], v[2 * j + 1]);
       split2(v[2 * j], v[2 * j + 1], h[j], l[j]);
+      A.rg->see_hi(__builtin_bit_cast(uint32_t, h[j]));
     }
     const f16x8 hv = {h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
     const f16x8 lv = {l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
