@@ -511,7 +511,7 @@ def main():
         return statistics.median(regions), regions[0], regions[-1]
 
     def traced(eng):
-        with pkg.KernelTrace(eng, max_launches=16 * args.steps + 64) as trace:
+        with pkg.KernelTrace(eng, max_launches=24 * args.steps + 64) as trace:
             dt = run_mode(eng, 1)
         return trace.summary(), dt
 

@@ -119,11 +119,11 @@ int set_last_error(int status, const char* msg) { return fail((oetr_status)statu
 
 enum KernelId { K_ENC_A, K_ENC_BA, K_ENC_BDEC, K_ENC_B, K_DECODER, K_HEAT_CONV,
                 K_HEAT_FINAL, K_SIZE_REG, K_BOXES, K_DEC_CONVP, K_HEAT_COMBINE, K_NECK_PROJ,
-                K_NECK_CONV, K_NECK_OUT, K_COUNT };
+                K_NECK_CONV, K_NECK_OUT, K_KV_REDUCE, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {
     "k_encoder<A>", "k_encoder<B,A>", "k_encoder<B,dec>", "k_encoder<B>",
     "k_decoder", "k_heat_conv", "k_heat_final", "k_size_reg", "k_boxes", "k_decoder_convp",
-    "k_heat_combine", "k_neck_proj", "k_neck_conv", "k_neck_out"};
+    "k_heat_combine", "k_neck_proj", "k_neck_conv", "k_neck_out", "k_kv_reduce"};
 
 struct oetr_trace {
   std::vector<hipEvent_t> ev;  // 2 per launch
@@ -136,6 +136,7 @@ struct oetr_ctx {
   oetr_trace* trace = nullptr;
   int device = 0;
   int mode = GM_SPLIT;  // GEMM mode GM_* (common.h) of the oetr_dtype
+  int kv_prereduce = 0; // oetr_set_state_prereduce
   int policy = 0;       // precision policy (SitePolicy<>) of the oetr_dtype: 1 = OETR_DTYPE_F32_SPLIT_QK16
   int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
   int attn_full = 0;   // OETR_ATTENTION_FULL (oetr_set_attention)
@@ -174,7 +175,7 @@ long long* g_tbuf = nullptr;
 
 struct Workspace {
   float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
-      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *dump;
+      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *dump, *kvr, *ksr;
   uint32_t* flags;   // the workspace's status word (first 256 bytes: shape-independent position)
   size_t bytes;
 };
@@ -240,6 +241,8 @@ Workspace carve(const Geom& g, void* base, bool attn_full = false) {
   w.tlbr = take((size_t)2 * g.N * 4);
   w.convp = take((size_t)9 * rows * C);  // P_tap = W_tap . memory (forward path)
   w.dump = take(C);                      // write-only scratch row (EncLaunch::dump)
+  w.kvr = take((size_t)2 * g.N * KV_FLOATS);   // one reduced linear-attention state per image
+  w.ksr = take((size_t)2 * g.N * C);           //   (k_kv_reduce, between the encoder launches)
   for (int i = 0; i < 2; ++i) {           // attention == full: K rows and V^T, per layer parity
     w.kbuf[i] = attn_full ? take(rows * C) : nullptr;
     w.vt[i] = attn_full ? take((size_t)g.N * C * TM * (g.nt[0] + g.nt[1])) : nullptr;
@@ -351,10 +354,23 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];
   TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, h->mode, s));
   p.feat_nchw[0] = p.feat_nchw[1] = p.pos_nchw[0] = p.pos_nchw[1] = nullptr;
+  // Optional (oetr_set_state_prereduce, default off): sum each image's per-tile partial states
+  // ONCE in a launch of their own instead of in every consuming workgroup.  Measured on MI355X:
+  // the consumer launch gets 2.1-2.3 us shorter (64- and 32-token shapes alike), but the extra
+  // launch is a 4-5 us latency chain - serial steps get slower, and with batches overlapped on
+  // three streams the throughput does not move (28.1 vs 28.1 k pairs/s): the 8 extra
+  // dependencies per batch cost what the shorter prologues save.
+  const bool prereduce = h->kv_prereduce && !h->attn_full;
   for (int l = 0; l < enc_layers; ++l) {
     p.b = h->enc[l];
     p.b_cross = l & 1;
     p.kv_in = w.kvp[l & 1]; p.ks_in = w.ksp[l & 1];
+    p.kv_reduced = 0;
+    if (prereduce) {   // sum layer l's per-tile partial states once per image (not once per workgroup)
+      TRACED(h, s, K_KV_REDUCE, launch_kv_reduce(p.g, w.kvp[l & 1], w.ksp[l & 1], w.kvr, w.ksr, s));
+      p.kv_in = w.kvr; p.ks_in = w.ksr;
+      p.kv_reduced = 1;
+    }
     p.kbuf_in = w.kbuf[l & 1]; p.vt_in = w.vt[l & 1];
     int tail;
     if (l + 1 == OETR_N_ENC) {
@@ -1230,6 +1246,12 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows) {
   if (rows == TM && h->policy != 0)
     return fail(OETR_ERR_UNSUPPORTED, "OETR_DTYPE_F32_SPLIT_QK16 runs 64-token encoder workgroups only");
   h->enc_tile = rows;
+  return OETR_OK;
+}
+
+oetr_status oetr_set_state_prereduce(oetr_handle h, int on) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: NULL handle");
+  h->kv_prereduce = on != 0;
   return OETR_OK;
 }
 

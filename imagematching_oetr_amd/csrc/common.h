@@ -1138,6 +1138,8 @@ struct EncLaunch {
   int tile_rows;         // token rows per workgroup: 32 (TM) or 64 (split mode, k_encoder64);
                          // g.nt / g.tile0 / g.ntiles are in units of this tile
   int b_cross;           // phase-B layer is a cross layer
+  int kv_reduced;        // kv_in / ks_in hold ONE reduced state per image ([2N][8192] / [2N][256], side 1
+                         // first: k_kv_reduce ran between the launches) instead of per-tile partials
   int policy;            // precision policy id (SitePolicy<>): 0 = every site fp32-class
   int dbg;               // ablation flags (OETR_ABLATE builds only)
   long long* tbuf;       // per-phase cycle stamps (OETR_PHASE_TIMING builds only)
@@ -1157,6 +1159,11 @@ struct EncLaunch {
 // has_b: run phase B (finish a layer); tail: 0 = phase A of next encoder layer,
 // 1 = decoder K/V preparation, 2 = nothing.
 hipError_t launch_encoder(const EncLaunch& p, bool has_b, int tail, int mode, hipStream_t s);
+// Sum the per-tile partial linear-attention states of every image (fixed tile order) once,
+// between the launch that wrote them and the launch whose every workgroup would otherwise
+// re-reduce them: g = the ENCODER tile geometry; kvr [2N][8192], ksr [2N][256].
+hipError_t launch_kv_reduce(const Geom& g, const float* kvp, const float* ksp, float* kvr, float* ksr,
+                            hipStream_t s);
 
 struct MhaDev {
   const float *wq_t, *wk_t, *wv_t, *wm_t;  // transposed [in][out]

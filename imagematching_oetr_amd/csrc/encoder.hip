@@ -359,8 +359,9 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     // ================= phase B: finish layer l =================
     const int ss = p.b_cross ? 1 - side : side;
     const int S_len = g.L[ss];
-    const int nts = ABL(p.dbg, ABL_KVREDUCE) ? 1 : g.nt[ss];
-    const int src_slot0 = g.tile0[ss] + n * g.nt[ss];
+    // (kv_reduced: one pre-reduced state per image - k_kv_reduce - instead of the tiles' partials)
+    const int nts = (p.kv_reduced || ABL(p.dbg, ABL_KVREDUCE)) ? 1 : g.nt[ss];
+    const int src_slot0 = p.kv_reduced ? ss * g.N + n : g.tile0[ss] + n * g.nt[ss];
 
     if (!FULL && !ABL(p.dbg, ABL_XLOAD)) load_tile<THREADS>(S0, p.qp + row_base * C, nvalid, tid);  // phi(Q) tile
     // residual x in accumulator layout
@@ -390,6 +391,11 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
                          ((size_t)src_slot0 * NH + NT * wave) * 256 + lane;
       const float* ksp = p.ks_in + (size_t)src_slot0 * C + (tid & (C - 1));
       float ks = 0.f;
+      if (nts == 1) {   // pre-reduced (or a single tile): one state, no redundant clamped loads
+#pragma unroll
+        for (int e = 0; e < 4 * NT; ++e) kvB[e >> 2][e & 3] = kvp[e * 64];
+        ks = ksp[0];
+      } else
       for (int ti0 = 0; ti0 < nts; ti0 += KVR) {
         f32x4 tmp[KVR][4 * NT];
         float kt[KVR];
@@ -734,7 +740,9 @@ constexpr int E2_LNP = E2_Z + RT * NH;
 constexpr int E2_SMEM = E2_LNP + 6 * C;                  // 36096 floats = 141 KB
 
 // phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
-template <int MODE>
+// KDONE: accK already holds phi(K) with the rows past the tile's end zeroed and `ksum` their
+// per-lane sum (phi_k_slice below, issued under the V GEMM's MFMAs).
+template <int MODE, bool KDONE = false>
 __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x16 (&accV)[2],
                                             int S_len, int nvalid, int half, bool two, f32x16& kv,
                                             float& ksum, Range& rg) {
@@ -744,7 +752,7 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
   // it schedules all 32 exps at once and spills.
   const float inv_len = 1.0f / (float)S_len;
   kv = f32x16{0};
-  ksum = 0.f;
+  if constexpr (!KDONE) ksum = 0.f;
   // (laundered: the row-validity tests are otherwise CSE'd with the residual loads' row
   //  clamps at the top of the kernel and 32 values live - spilled - until here)
   int nv2 = nvalid - 4 * half;
@@ -763,9 +771,12 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
           const int r = 8 * s + i;
           const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
           const float x = accK[mt][r];
-          const float kk = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+          float kk = x;
+          if constexpr (!KDONE) {
+            kk = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+            ksum += kk;
+          }
           const float vv = accV[mt][r] * (inv_len * m);
-          ksum += kk;
           if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
         }
         f32x4 ah, al, bh, bl;
@@ -788,9 +799,12 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
         for (int j = 0; j < 4; ++j) {
           const float m = 32 * mt + crow(r0 + j, 0) < nv2 ? 1.0f : 0.0f;
           const float x = accK[mt][r0 + j];
-          k[j] = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+          k[j] = x;
+          if constexpr (!KDONE) {
+            k[j] = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+            ksum += k[j];
+          }
           v[j] = accV[mt][r0 + j] * (inv_len * m);
-          ksum += k[j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
@@ -799,6 +813,20 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
     }
   }
   ksum += __shfl_xor(ksum, 32, 64);
+}
+// One k16 step's share of phi(K) for the 64-row state (two accumulator values, in place),
+// rows past the tile's end zeroed, per-lane sum accumulated: the K half of kv_state_64.
+template <int CI>
+__device__ __forceinline__ void phi_k_slice(f32x16 (&accK)[2], float& ksum, int nv2) {
+  constexpr int mt = CI / 8, r0 = 2 * (CI % 8);
+#pragma unroll
+  for (int r = r0; r < r0 + 2; ++r) {
+    const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
+    const float x = accK[mt][r];
+    const float kk = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+    accK[mt][r] = kk;
+    ksum += kk;
+  }
 }
 __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int lane, int wave,
                                                float* __restrict__ kv_out,
@@ -819,6 +847,7 @@ template <bool HAS_B, int TAIL, int MODE, int POL, int ROWS>
 __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) {
   constexpr int THREADS = 512, TPR = 8, F4 = 8;
   using SP = SitePolicy<POL>;   // arithmetic per GEMM site (two-plane mode only)
+  constexpr bool XEPI = HAS_B && TAIL == 0 && gm_planes(MODE) == 2 && SP::Q == SITE_HI;
   float* R1f = smem + E2_R1;
   float* R2f = smem + E2_R2;
   Range rg;
@@ -872,8 +901,9 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   if (HAS_B) {
     const int ss = p.b_cross ? 1 - side : side;
     const int S_len = g.L[ss];
-    const int nts = g.nt[ss];
-    const int src_slot0 = g.tile0[ss] + n * g.nt[ss];
+    // (kv_reduced: one pre-reduced state per image - k_kv_reduce - instead of the tiles' partials)
+    const int nts = p.kv_reduced ? 1 : g.nt[ss];
+    const int src_slot0 = p.kv_reduced ? ss * g.N + n : g.tile0[ss] + n * g.nt[ss];
 
     // phi(Q) tile -> R2 (f32)
 #pragma unroll
@@ -893,6 +923,11 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
                          ((size_t)src_slot0 * NH + wave) * 256 + lane;
       const float* ksp = p.ks_in + (size_t)src_slot0 * C + (tid & (C - 1));
       float ks = 0.f;
+      if (nts == 1) {   // pre-reduced (or a single tile): one state, no redundant clamped loads
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kvB[e] = kvp[e * 64];
+        ks = ksp[0];
+      } else
       for (int ti0 = 0; ti0 < nts; ti0 += KVR) {
         f32x4 tmp[KVR][4];
         float kt[KVR];
@@ -1067,7 +1102,10 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
                                                                   TAIL == 0 ? p.a.wq : p.d.wk[0],
                                                                   TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], wave, 0);
     }
-    {
+    // (XEPI: the x store is issued under the Q GEMM's MFMAs instead, below - where the Q site runs
+    //  without cross accumulators there are registers for keeping xacc alive that long; with
+    //  them the kernel spills: measured 256 VGPRs + 212 B of scratch)
+    if (!XEPI) {
       // (pointer laundered: otherwise the 32 store addresses are CSE'd with the residual
       //  loads' at the top of the kernel and live - spilled - across every GEMM)
       int l2 = lane;
@@ -1142,15 +1180,32 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // phi(Q) -> HBM, issued under the K GEMM's MFMAs (two accumulator values per k16 step; rows
     // past a ragged tile's end go to the scratch row: an address select, no divergent branch)
     f32x16 accQ[2] = {f32x16{0}, f32x16{0}};
-    ws.template gemm<C, P_T0, true, C, SP::Q, SP::K>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
-                                                     p.a.wk_l, wave, 0);
+    int l2 = lane;  // laundered: no address CSE with the residual loads at the top of the kernel
+    asm volatile("" : "+v"(l2));
+    const int nv2 = nvalid - 4 * (l2 >> 5);
+    {
+      // the residual stream goes back to HBM under the Q GEMM (rows past a ragged tile's end go
+      // to the scratch row: an address select, no divergent branch around the store)
+      float* xs = p.x + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
+      float* xdump = p.dump + wcol + (l2 & 31);
+      auto xepi = [&](auto CI_) {
+        if constexpr (XEPI) {
+          constexpr int CI = decltype(CI_)::value, mt = CI / 8, r0 = 2 * (CI % 8);
+#pragma unroll
+          for (int r = r0; r < r0 + 2; ++r) {
+            const int row = 32 * mt + crow(r, 0);
+            *(row < nv2 ? xs + row * C : xdump) = xacc[mt][r];
+          }
+        }
+      };
+      ws.template gemm_epi<C, P_T0, true, C, SP::Q, SP::K>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
+                                                           p.a.wk_l, wave, 0, xepi);
+    }
     PHASE_STAMP(p, 10);
     f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
     {
-      int l2 = lane;  // laundered like the x store: no address CSE across the kernel
-      asm volatile("" : "+v"(l2));
+      // phi(Q) -> HBM under the K GEMM's MFMAs (two accumulator values per k16 step)
       float* qs = p.qp + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
-      const int nv2 = nvalid - 4 * (l2 >> 5);
       float* qdump = p.dump + wcol + (l2 & 31);
       auto qepi = [&](auto CI_) {
         constexpr int CI = decltype(CI_)::value, mt = CI / 8, r0 = 2 * (CI % 8);
@@ -1158,19 +1213,22 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
         for (int r = r0; r < r0 + 2; ++r) {
           const int row = 32 * mt + crow(r, 0);
           const float x = accQ[mt][r];
-          float* dst = row < nv2 ? qs + row * C : qdump;
-          *dst = fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f));   // == elu(x) + 1
+          *(row < nv2 ? qs + row * C : qdump) = fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f));   // == elu(x) + 1
         }
       };
       ws.template gemm_epi<C, P_T1, true, C, SP::K, SP::V>(P2, p.a.wk, p.a.wk_l, wave, 0, lane, accK, p.a.wv,
                                                            p.a.wv_l, wave, 0, qepi);
     }
-    ws.template gemm<C, P_T2, false, C, SP::V>(P2, p.a.wv, p.a.wv_l, wave, 0, lane, accV, nullptr, nullptr,
-                                               0, 0);
+    // phi(K), its row mask and sum under the V GEMM's MFMAs
+    float ksum = 0.f;
+    {
+      auto kepi = [&](auto CI_) { phi_k_slice<decltype(CI_)::value>(accK, ksum, nv2); };
+      ws.template gemm_epi<C, P_T2, false, C, SP::V, SITE_FULL>(P2, p.a.wv, p.a.wv_l, wave, 0, lane, accV, nullptr,
+                                                                nullptr, 0, 0, kepi);
+    }
     PHASE_STAMP(p, 11);
     f32x16 kv;
-    float ksum;
-    kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
+    kv_state_64<MODE, true>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
   } else if (TAIL == 1) {
@@ -1331,6 +1389,57 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
     else OETR_LAUNCH(false, 2);
   }
 #undef OETR_LAUNCH
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Pre-reduction of the partial linear-attention states, once per image and head, between the
+// launch that wrote them (phase A) and the launch that consumes them (phase B): otherwise
+// EVERY workgroup of an image re-reads and re-sums all of the source image's partials
+// (7 x 33 KB per 64-token workgroup at 400 tokens, 13 x 33 KB per 32-token one - the largest
+// item of its prologue).  Same summation order as the in-kernel loop (tile 0, 1, ...):
+// bit-identical results.  One wave per (image, head).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_kv_reduce(Geom g, const float* __restrict__ kvp,
+                                                  const float* __restrict__ ksp, float* __restrict__ kvr,
+                                                  float* __restrict__ ksr) {
+  const int img = blockIdx.x >> 3, head = blockIdx.x & 7, lane = threadIdx.x;
+  const int side = img >= g.N, n = img - side * g.N;
+  const int nt = g.nt[side];
+  const int slot0 = g.tile0[side] + n * nt;
+  const f32x4* src = reinterpret_cast<const f32x4*>(kvp) + ((size_t)slot0 * NH + head) * 256 + lane;
+  const float* ks = ksp + (size_t)slot0 * C + head * HD + (lane & 31);
+  f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
+                  f32x4{0.f, 0.f, 0.f, 0.f}};
+  float kacc = 0.f;
+  constexpr int U = 8;   // tiles in flight per round trip
+  for (int t0 = 0; t0 < nt; t0 += U) {
+    f32x4 tmp[U][4];
+    float kt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u, nt - 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tmp[u][e] = src[(size_t)t * (NH * 256) + e * 64];
+      kt[u] = ks[(size_t)t * C];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (t0 + u < nt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += tmp[u][e];
+        kacc += kt[u];
+      }
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(kvr) + ((size_t)img * NH + head) * 256 + lane;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dst[e * 64] = acc[e];
+  if (lane < 32) ksr[(size_t)img * C + head * HD + lane] = kacc;
+}
+
+hipError_t launch_kv_reduce(const Geom& g, const float* kvp, const float* ksp, float* kvr, float* ksr,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_kv_reduce, dim3(2 * g.N * NH), dim3(64), 0, s, g, kvp, ksp, kvr, ksr);
   return hipGetLastError();
 }
 

@@ -82,7 +82,8 @@ EXPORTS = (
     'oetr_full_attention_split', 'oetr_set_attention', 'oetr_neck_set_conv_rows',
     'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel',
     'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens',
-    'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async')
+    'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async',
+    'oetr_set_state_prereduce')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -190,6 +191,8 @@ def load_library(path=None):
     lib.oetr_set_encoder_tile.argtypes = [vp, i]
     lib.oetr_set_attention.restype = i
     lib.oetr_set_attention.argtypes = [vp, i]
+    lib.oetr_set_state_prereduce.restype = i
+    lib.oetr_set_state_prereduce.argtypes = [vp, i]
     lib.oetr_neck_create.restype = i
     lib.oetr_neck_create.argtypes = [C.POINTER(_NeckWeights), i, C.POINTER(vp)]
     lib.oetr_neck_destroy.restype = None
@@ -443,6 +446,11 @@ class HotPathEngine:
 
     def _current_ws(self):
         return self._ws.get(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_state_prereduce(self, on):
+        """``oetr_set_state_prereduce``: partial linear-attention states summed once per image in a
+        launch of their own (bit-identical results; measured neutral / slower: default off)."""
+        _check(self.lib, self.lib.oetr_set_state_prereduce(self._h, int(bool(on))), 'oetr_set_state_prereduce')
 
     def query_flags(self, clear=True):
         """Status word of the CURRENT STREAM's workspace (``oetr_query_flags``): synchronises

@@ -199,6 +199,13 @@ oetr_status oetr_read_flags_async(oetr_handle h, void *workspace,
  * concurrent forward calls. */
 oetr_status oetr_set_encoder_tile(oetr_handle h, int rows);
 
+/* 1: reduce each image's per-tile partial linear-attention states (the all-to-all of
+ * LinearAttention, reference src/models/linear_attention.py:45-46) once, in a small launch
+ * between the encoder launches, instead of in every consuming workgroup.  Bit-identical
+ * results (same summation order).  Default 0: measured neutral for overlapped batches and
+ * slower for serial ones on MI355X.  Mutates the handle like the other setters. */
+oetr_status oetr_set_state_prereduce(oetr_handle h, int on);
+
 /* Attention core of the eight encoder layers.  The reference builds
  * QueryTransformer(attention_mode='linear') (src/model.py:82-84; the config knob
  * OETR.NECK.ATTENTION is never read), LINEAR is therefore the default; FULL is

@@ -385,3 +385,20 @@ def test_drop_in_module_forward_dummy(gpu):
         model.tlbr_reg[2].bias.add_(1.0)
     b1n, _ = model.forward_dummy(im1, im2)
     assert not torch.equal(b1n, b1)
+
+
+@pytest.mark.parametrize('tile', [32, 64])
+def test_state_prereduce_is_bit_identical(gpu, tile):
+    """``oetr_set_state_prereduce``: the per-tile partial linear-attention states summed once per
+    image by ``k_kv_reduce`` instead of in every consuming workgroup - same summation order,
+    same bits (self and cross layers, ragged grids)."""
+    from imagematching_oetr_amd import HotPathEngine
+    w = orc.make_hot_weights(2, sharpen=True)
+    f1, f2 = orc.make_features(61, 3, 15, 20).to(gpu), orc.make_features(62, 3, 25, 10).to(gpu)
+    p1, p2 = orc.position_table(15, 20).to(gpu), orc.position_table(25, 10).to(gpu)
+    eng = HotPathEngine(w, device=gpu, enc_tile=tile)
+    a = eng.forward(f1, f2, p1, p2, (480, 640), (800, 320), stages=True)
+    eng.set_state_prereduce(True)
+    b = eng.forward(f1, f2, p1, p2, (480, 640), (800, 320), stages=True)
+    for k in ('memory1', 'memory2', 'hs1', 'hs2', 'box1', 'box2'):
+        assert torch.equal(a[k], b[k]), k
