@@ -15,7 +15,8 @@
 //                                (the reference resizes a second time when the size is
 //                                rounded up to a multiple of size_divisor; with equal
 //                                sizes the cubic weights are exactly (0,1,0,0): a copy)
-// When the gate fails the full images are passed through (evaluation.py:142-170).
+// When the gate fails the full images are passed through (evaluation.py:142-170): copied
+// bit for bit, no resize passes.
 //
 // The sizes are data dependent, so the grids cover the caller's capacity and every
 // thread reads the geometry first.  Bicubic = OpenCV's float path (a = -0.75, pixel
@@ -96,12 +97,17 @@ __global__ void k_crop_geometry(CropLaunch p) {
       g.out_h[i] = (int)ceil((double)g.new_h[i] / p.size_divisor) * p.size_divisor;
     }
   }
-  // (a crop that does not fit the caller's capacity cannot be produced: flagged invalid)
+  // A crop that does not fit the caller's capacity, or a degenerate one (the reference would
+  // raise from cv2.resize there), cannot be produced: valid = -1, sizes zeroed - NOT the same
+  // thing as a failed gate (valid = 0: the images pass through untouched).
+  bool fits = true;
   for (int i = 0; i < 2; ++i)
     if (g.out_w[i] > p.cap_w || g.out_h[i] > p.cap_h || g.new_w[i] > p.cap_w || g.new_h[i] > p.cap_h ||
         g.new_w[i] <= 0 || g.new_h[i] <= 0)
-      valid = false, g.out_w[i] = g.out_h[i] = g.new_w[i] = g.new_h[i] = 0;
-  g.valid = valid ? 1 : 0;
+      fits = false;
+  if (!fits)
+    for (int i = 0; i < 2; ++i) g.out_w[i] = g.out_h[i] = g.new_w[i] = g.new_h[i] = 0;
+  g.valid = !fits ? -1 : (valid ? 1 : 0);
   *p.info = g;
 }
 
@@ -122,6 +128,16 @@ template <int PASS>
 __global__ __launch_bounds__(256) void k_crop_resize(CropLaunch p) {
   const int im = blockIdx.y, c = blockIdx.z;
   const oetr_crop_info& g = *p.info;
+  if (g.valid != 1) {
+    // gate failed: the reference hands data['image0'/'image1'] back untouched
+    // (evaluation.py:142-170) - a plain copy, bit for bit, in the second pass only
+    if (PASS == 2 && g.valid == 0) {
+      const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+      const long npix = (long)p.w[im] * p.h[im];
+      if (idx < npix) p.out[im][(size_t)c * npix + idx] = p.image[im][(size_t)c * npix + idx];
+    }
+    return;
+  }
   int sw, sh, dw, dh, x0, y0, spitch;
   const float* src;
   float* dst;

@@ -935,7 +935,14 @@ class OverlapCrops:
 
     @property
     def valid(self):
-        return bool(self.geometry().valid)
+        """True: crops were made; False: the gate failed and the full images passed through.
+        A degenerate crop / one beyond the buffers' capacity (``oetr_crop_info.valid == -1``,
+        where the reference raises from ``cv2.resize``) raises ``OetrError``."""
+        v = int(self.geometry().valid)
+        if v < 0:
+            raise OetrError('overlap_crop: degenerate crop rectangle or crop larger than the capacity '
+                            '(oetr_crop_info.valid == -1)')
+        return bool(v)
 
     def crop(self, i):
         """[1, C, out_h, out_w] view of image ``i``'s crop (the reference's ``left[None]``)."""

@@ -407,8 +407,10 @@ oetr_status oetr_neck_read_flags_async(oetr_neck_handle h, void *workspace,
  * resize follows OpenCV's published float32 bicubic (a = -0.75) but is
  * parity-UNPINNED: cv2 is not installed where the fixtures were generated. */
 typedef struct {
-  int32_t valid;        /* 1: crops made; 0: gate failed, full images passed through
-                           (evaluation.py:142-170) or a size exceeded the capacity   */
+  int32_t valid;        /* 1: crops made; 0: gate failed, the full images passed through
+                           bit for bit (evaluation.py:142-170); -1: a crop is degenerate
+                           or exceeds the capacity (sizes zeroed, nothing written) - where
+                           the reference would raise from cv2.resize                 */
   int32_t box[2][4];    /* scaled boxes truncated to int, xyxy (utils.py:515-516)      */
   int32_t crop_w[2], crop_h[2]; /* slice sizes (Python slicing clamps at the border) */
   int32_t new_w[2], new_h[2];   /* patch_resize output (utils.py:476-493)            */

@@ -44,8 +44,23 @@ def test_crop_step_matches_reference_goldens(gpu, golden_dir):
                                int(c['size_divisor']), bool(c['pragueparks']))
         assert float((res.crop(0).cpu() - ref['crop0']).abs().max()) <= PIX_TOL
         assert float((res.crop(1).cpu() - ref['crop1']).abs().max()) <= PIX_TOL
+        if not res.valid:      # gate failed: the reference hands the images back untouched - bit for bit
+            assert torch.equal(res.crop(0).cpu(), im0) and torch.equal(res.crop(1).cpu(), im1), ci
         n += 1
     assert n == 8
+
+
+def test_degenerate_crop_is_reported_not_passed_through(gpu):
+    """A box past the image border leaves an empty slice: the reference raises from cv2.resize
+    there; here ``oetr_crop_info.valid == -1`` (distinct from a failed gate) and the Python
+    wrapper raises instead of handing back an empty crop."""
+    im = torch.rand(1, 1, 64, 64, generator=torch.Generator().manual_seed(1)).to(gpu)
+    inside = torch.tensor([[5.0, 5.0, 60.0, 60.0]], device=gpu)
+    outside = torch.tensor([[70.0, 10.0, 100.0, 50.0]], device=gpu)      # x1 beyond the 64-px width
+    res = pkg.overlap_crop(im, im, outside, inside, (1, 1), (1, 1))
+    assert int(res.geometry().valid) == -1
+    with pytest.raises(pkg.OetrError):
+        res.valid
 
 
 def test_crop_geometry_fuzz_is_bit_exact_vs_oracle(gpu):
