@@ -83,7 +83,7 @@ EXPORTS = (
     'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel',
     'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens',
     'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async',
-    'oetr_set_state_prereduce')
+    'oetr_set_state_prereduce', 'oetr_overlap_frame', 'oetr_read_overlap_image')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -228,6 +228,10 @@ def load_library(path=None):
     lib.oetr_overlap_crop.restype = i
     lib.oetr_overlap_crop.argtypes = [vp, vp, i, i, i, i, i, vp, vp, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), i, i, i, vp, vp, vp, sz, vp, vp]
+    lib.oetr_overlap_frame.restype = i
+    lib.oetr_overlap_frame.argtypes = [i, i, i, i] + [C.POINTER(i)] * 4 + [C.POINTER(C.c_double)] * 2
+    lib.oetr_read_overlap_image.restype = i
+    lib.oetr_read_overlap_image.argtypes = [vp, i, i, i, i, i, i, i, i, i, vp, vp, vp, vp]
     if lib.oetr_abi_version() != ABI_VERSION:
         raise RuntimeError(f'{p}: ABI version {lib.oetr_abi_version()} != '
                            f'{ABI_VERSION}')

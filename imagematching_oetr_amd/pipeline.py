@@ -93,6 +93,58 @@ def forward_pairs(model, pairs, max_batch=8):
 
 
 @torch.no_grad()
+def forward_pairs_raw(model, raw_pairs, resize=(640,), grayscale=True, align='disk', max_batch=8):
+    """The reference's per-pair loop from DECODED images to boxes, batched and on the device
+    (``dloc/core/overlap_features.py:158-178``: two ``read_overlap_image`` calls, then
+    ``self.overlap({'image0': overlap_inp0, 'image1': overlap_inp1})``).
+
+    ``raw_pairs``: sequence of ``(image0, image1)``, each a decoded BGR picture ``[H,W,3]``
+    (uint8 or float32, numpy / torch, ANY sizes: the reader maps every picture into the same
+    ``resize[0] x resize[0]`` OETR frame, so one bucket holds them all).  Per chunk of
+    ``max_batch`` pairs: one pinned staging buffer and ONE host-to-device copy for all 2n
+    pictures, the device reader (``reader.read_overlap_images``) writing straight into the
+    ``[n,S,S,3]`` batches, one ``forward_dummy``.  Returns a dict of per-pair results in
+    input order: ``box0`` / ``box1`` ``[len,4]`` device tensors (OETR frame), ``scales0/1``,
+    ``overlap_scales0/1`` (lists of float pairs), ``inp0`` / ``inp1`` (lists of
+    ``[1,1|3,h,w]`` device tensors: the matcher's images) - exactly what
+    ``overlap_crop(inp0[i], inp1[i], box0[i], box1[i], overlap_scales0[i], overlap_scales1[i])``
+    takes, with no host round trip in between."""
+    from .reader import read_overlap_images
+    device = _model_device(model)
+    n = len(raw_pairs)
+    res = dict(box0=torch.zeros(n, 4, device=device), box1=torch.zeros(n, 4, device=device),
+               scales0=[None] * n, scales1=[None] * n, overlap_scales0=[None] * n,
+               overlap_scales1=[None] * n, inp0=[None] * n, inp1=[None] * n)
+    for s in range(0, n, max(1, max_batch)):
+        chunk = list(range(s, min(n, s + max_batch)))
+        m = len(chunk)
+        read = read_overlap_images([raw_pairs[i][0] for i in chunk] + [raw_pairs[i][1] for i in chunk],
+                                   device, resize, grayscale, align)
+        r0, r1 = read[:m], read[m:]
+        if all(r._batch is read[0]._batch for r in read):
+            # one OETR frame for every picture (always, unless resize == [-1]): the reader filled ONE
+            # [2m,S,S,3] batch, image0s first - the two halves ARE forward_dummy's inputs, no copy
+            b0, b1 = model.forward_dummy(read[0]._batch[:m], read[0]._batch[m:])
+            for k, i in enumerate(chunk):
+                res['box0'][i], res['box1'][i] = b0[k], b1[k]
+        else:   # native-size frames: bucket the pairs by shape
+            shapes = [(tuple(a.overlap_inp.shape[1:3]), tuple(b.overlap_inp.shape[1:3])) for a, b in zip(r0, r1)]
+            for _, idx in bucket_by_shape(shapes).items():
+                im0, im1 = torch.cat([r0[k].overlap_inp for k in idx]), torch.cat([r1[k].overlap_inp for k in idx])
+                b0, b1 = model.forward_dummy(im0, im1)
+                for j, k in enumerate(idx):
+                    res['box0'][chunk[k]], res['box1'][chunk[k]] = b0[j], b1[j]
+        for k, i in enumerate(chunk):
+            res['scales0'][i], res['scales1'][i] = r0[k].scales, r1[k].scales
+            res['overlap_scales0'][i], res['overlap_scales1'][i] = r0[k].overlap_scales, r1[k].overlap_scales
+            res['inp0'][i], res['inp1'][i] = r0[k].inp, r1[k].inp
+    flush = getattr(model, 'hip_flush', None)
+    if flush is not None:
+        flush()
+    return res
+
+
+@torch.no_grad()
 def forward_pairs_sharded(model, pairs, max_batch=8, group=None):
     """:func:`forward_pairs` over a process group (one rank per GPU): every rank holds
     the same pair list, computes its shard of every shape bucket and receives the

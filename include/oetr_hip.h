@@ -441,6 +441,33 @@ oetr_status oetr_overlap_crop(const float *image1, const float *image2, int chan
                               int gate_mode, float *tmp, float *out1, float *out2,
                               size_t capacity_floats, oetr_crop_info *info, void *stream);
 
+/* ---- image reader of the overlap pipeline on the device ------------
+ * Replaces read_overlap_image (reference dloc/core/utils/utils.py:271-343) after the
+ * decode: the matcher's frame (sizes rounded up to a multiple of 32 for 'disk', 8 for
+ * 'loftr', process_resize :248-265), the OETR input frame (resize x resize, or the native
+ * size for resize == -1), `scales` / `overlap_scales` as the reference's Python floats, the two
+ * chained cv2.resize (INTER_LINEAR) calls, the grey conversion and the /255.
+ *   oetr_overlap_frame       host arithmetic only (usable without a GPU).
+ *   oetr_read_overlap_image  enqueue-only: image_bgr DEVICE [h][w][3] (uint8 when is_u8, else
+ *                            float32 0..255; cv2.imread's BGR order) -> overlap_out
+ *                            [h_ov][w_ov][3] in [0,1] (one slot of the [N,H,W,3] batch
+ *                            oetr's forward_dummy seam takes) and inp_out [1|3][h_new][w_new]
+ *                            in [0,1] (grey or planar BGR: the matcher's image, what
+ *                            oetr_overlap_crop crops); tmp: h_new*w_new*3 floats of scratch.
+ *                            swap_rb = 1 reverses the channel order first, as the reference
+ *                            does when `align` is empty (utils.py:283-284; its grey
+ *                            conversion still reads the channels as B,G,R afterwards).
+ * Sizes and scales are pinned to the reference (tests/golden/reader.npz); the resize follows
+ * OpenCV's published float32 INTER_LINEAR but is parity-UNPINNED (no cv2 in the build image). */
+typedef enum { OETR_ALIGN_NONE = 0, OETR_ALIGN_DISK = 1, OETR_ALIGN_LOFTR = 2 } oetr_align;
+oetr_status oetr_overlap_frame(int w, int h, int resize, oetr_align align, int *w_new,
+                               int *h_new, int *w_ov, int *h_ov, double scales[2],
+                               double overlap_scales[2]);
+oetr_status oetr_read_overlap_image(const void *image_bgr, int is_u8, int h, int w,
+                                    int h_new, int w_new, int h_ov, int w_ov, int grayscale,
+                                    int swap_rb, float *tmp, float *overlap_out,
+                                    float *inp_out, void *stream);
+
 /* ---- measurement hook (bench.py / profiling only) -------------------------
  * A trace owns a pool of HIP events.  While attached to a handle, every
  * kernel launched by the forward entry points is bracketed by two events

@@ -392,6 +392,64 @@ def gen_crop(out_dir):
     print('crop.npz', len(CROP_CASES), 'cases')
 
 
+# (w, h) of the decoded image, resize, align, grayscale
+READER_CASES = [
+    ((1024, 683), [640], 'disk', True),      # MegaDepth-like: matcher frame 1024x704, OETR frame 640x640
+    ((800, 600), [640], 'loftr', True),
+    ((657, 493), [640], '', False),          # colour, no alignment
+    ((1280, 1280), [-1], 'disk', True),      # native-size OETR frame
+    ((97, 61), [64], 'disk', False),         # small: pixels kept in the fixture
+]
+
+
+def gen_reader(out_dir):
+    """The READER half of the pair front end: the reference's own
+    ``read_overlap_image`` (dloc/core/utils/utils.py:271-343) on seeded synthetic BGR images.
+    cv2 is not installed: ``cv2.imread`` hands back the synthetic array, ``cv2.resize`` /
+    ``cv2.cvtColor`` are the oracle's restatements of OpenCV's float32 INTER_LINEAR / BGR2GRAY -
+    so the PIXELS pin only the plumbing (two chained resizes, /255, layouts), never cv2's
+    numerics; sizes, ``scales`` and ``overlap_scales`` are the reference's own arithmetic."""
+    import importlib
+    from oracle import reader_oracle as rdo
+    cv2 = sys.modules['cv2']
+    images = {}
+    cv2.IMREAD_COLOR, cv2.COLOR_BGR2GRAY, cv2.COLOR_BGR2RGB = 1, 6, 4
+    cv2.imread = lambda path, flag=None: images[path].copy()
+    saved_resize = getattr(cv2, 'resize', None)
+    cv2.resize = lambda img, size, interpolation=None: rdo.bilinear_resize(img, size[0], size[1])
+    cv2.cvtColor = lambda img, code: rdo.bgr_to_gray(img)
+    utils = importlib.import_module('dloc.core.utils.utils')
+    data = {'n_cases': np.int64(len(READER_CASES))}
+    for ci, ((w, h), resize, align, gray) in enumerate(READER_CASES):
+        g = torch.Generator().manual_seed(700 + ci)
+        img = (torch.rand(h, w, 3, generator=g) * 255).to(torch.uint8).numpy()
+        images[f'case{ci}'] = img
+        image, overlap_inp, inp, scales, overlap_scales = utils.read_overlap_image(
+            f'case{ci}', 'cpu', resize, 0, True, grayscale=gray, align=align, overlap=True)
+        tag = f'c{ci}_'
+        data[tag + 'wh'] = np.asarray((w, h))
+        data[tag + 'resize'] = np.asarray(resize)
+        data[tag + 'align'] = np.asarray(align)
+        data[tag + 'grayscale'] = np.int64(gray)
+        data[tag + 'seed'] = np.int64(700 + ci)
+        data[tag + 'scales'] = np.float64(scales)
+        data[tag + 'overlap_scales'] = np.float64(overlap_scales)
+        data[tag + 'overlap_shape'] = np.asarray(overlap_inp.shape)
+        data[tag + 'inp_shape'] = np.asarray(inp.shape)
+        data[tag + 'in_fp'] = fp(torch.from_numpy(img.astype(np.float32)))
+        data[tag + 'overlap_fp'] = fp(overlap_inp)
+        data[tag + 'inp_fp'] = fp(inp)
+        if w * h <= 10000:
+            data[tag + 'overlap_inp'] = overlap_inp.numpy()
+            data[tag + 'inp'] = inp.numpy()
+        print(f'reader case {ci}: {w}x{h} -> inp {tuple(inp.shape)} overlap {tuple(overlap_inp.shape)} '
+              f'scales {scales} overlap_scales {overlap_scales}')
+    if saved_resize is not None:
+        cv2.resize = saved_resize
+    np.savez_compressed(out_dir / 'reader.npz', **data)
+    print('reader.npz', len(READER_CASES), 'cases')
+
+
 @torch.no_grad()
 def gen_train_forward(out_dir, model):
     """Training-side ``OETR.forward(data)`` (src/model.py:255-376) of the REFERENCE model on
@@ -433,6 +491,8 @@ def main():
     install_stubs()
     if args.only == 'crop':
         return gen_crop(out_dir)
+    if args.only == 'reader':
+        return gen_reader(out_dir)
     if args.only == 'fullattn':
         return gen_hot(out_dir, build_reference_model(), FULL_ATTN_CASES, 'fullattn_', True)
     if args.only == 'train':
@@ -440,6 +500,7 @@ def main():
     if args.only == 'hot':
         return gen_hot(out_dir, build_reference_model())
     gen_misc(out_dir)
+    gen_reader(out_dir)
     gen_crop(out_dir)
     gen_attention(out_dir)
     model = build_reference_model()

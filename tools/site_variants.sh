@@ -15,7 +15,7 @@ if [ "$1" = build ]; then
     mkdir -p $VDIR/$name
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DOETR_SITE_${site}=${red} -c $CSRC/encoder.hip -o $VDIR/$name/encoder.o &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $VDIR/$name/liboetr_hip.so $VDIR/$name/encoder.o \
-        $CSRC/api.o $CSRC/decoder.o $CSRC/heads.o $CSRC/attention.o $CSRC/neck.o $CSRC/crop.o ) &
+        $CSRC/api.o $CSRC/decoder.o $CSRC/heads.o $CSRC/attention.o $CSRC/neck.o $CSRC/crop.o $CSRC/reader.o ) &
     n=$((n+1)); if [ $((n % 6)) = 0 ]; then wait; fi
   done; done
   wait
