@@ -740,9 +740,7 @@ constexpr int E2_LNP = E2_Z + RT * NH;
 constexpr int E2_SMEM = E2_LNP + 6 * C;                  // 36096 floats = 141 KB
 
 // phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
-// KDONE: accK already holds phi(K) with the rows past the tile's end zeroed and `ksum` their
-// per-lane sum (phi_k_slice below, issued under the V GEMM's MFMAs).
-template <int MODE, bool KDONE = false>
+template <int MODE>
 __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x16 (&accV)[2],
                                             int S_len, int nvalid, int half, bool two, f32x16& kv,
                                             float& ksum, Range& rg) {
@@ -752,7 +750,7 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
   // it schedules all 32 exps at once and spills.
   const float inv_len = 1.0f / (float)S_len;
   kv = f32x16{0};
-  if constexpr (!KDONE) ksum = 0.f;
+  ksum = 0.f;
   // (laundered: the row-validity tests are otherwise CSE'd with the residual loads' row
   //  clamps at the top of the kernel and 32 values live - spilled - until here)
   int nv2 = nvalid - 4 * half;
@@ -771,11 +769,8 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
           const int r = 8 * s + i;
           const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
           const float x = accK[mt][r];
-          float kk = x;
-          if constexpr (!KDONE) {
-            kk = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
-            ksum += kk;
-          }
+          const float kk = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+          ksum += kk;
           const float vv = accV[mt][r] * (inv_len * m);
           if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
         }
@@ -799,11 +794,8 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
         for (int j = 0; j < 4; ++j) {
           const float m = 32 * mt + crow(r0 + j, 0) < nv2 ? 1.0f : 0.0f;
           const float x = accK[mt][r0 + j];
-          k[j] = x;
-          if constexpr (!KDONE) {
-            k[j] = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
-            ksum += k[j];
-          }
+          k[j] = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+          ksum += k[j];
           v[j] = accV[mt][r0 + j] * (inv_len * m);
         }
 #pragma unroll
@@ -813,20 +805,6 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
     }
   }
   ksum += __shfl_xor(ksum, 32, 64);
-}
-// One k16 step's share of phi(K) for the 64-row state (two accumulator values, in place),
-// rows past the tile's end zeroed, per-lane sum accumulated: the K half of kv_state_64.
-template <int CI>
-__device__ __forceinline__ void phi_k_slice(f32x16 (&accK)[2], float& ksum, int nv2) {
-  constexpr int mt = CI / 8, r0 = 2 * (CI % 8);
-#pragma unroll
-  for (int r = r0; r < r0 + 2; ++r) {
-    const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
-    const float x = accK[mt][r];
-    const float kk = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
-    accK[mt][r] = kk;
-    ksum += kk;
-  }
 }
 __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int lane, int wave,
                                                float* __restrict__ kv_out,
@@ -847,7 +825,6 @@ template <bool HAS_B, int TAIL, int MODE, int POL, int ROWS>
 __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) {
   constexpr int THREADS = 512, TPR = 8, F4 = 8;
   using SP = SitePolicy<POL>;   // arithmetic per GEMM site (two-plane mode only)
-  constexpr bool XEPI = HAS_B && TAIL == 0 && gm_planes(MODE) == 2 && SP::Q == SITE_HI;
   float* R1f = smem + E2_R1;
   float* R2f = smem + E2_R2;
   Range rg;
@@ -1102,10 +1079,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
                                                                   TAIL == 0 ? p.a.wq : p.d.wk[0],
                                                                   TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], wave, 0);
     }
-    // (XEPI: the x store is issued under the Q GEMM's MFMAs instead, below - where the Q site runs
-    //  without cross accumulators there are registers for keeping xacc alive that long; with
-    //  them the kernel spills: measured 256 VGPRs + 212 B of scratch)
-    if (!XEPI) {
+    {
       // (pointer laundered: otherwise the 32 store addresses are CSE'd with the residual
       //  loads' at the top of the kernel and live - spilled - across every GEMM)
       int l2 = lane;
@@ -1183,24 +1157,11 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     int l2 = lane;  // laundered: no address CSE with the residual loads at the top of the kernel
     asm volatile("" : "+v"(l2));
     const int nv2 = nvalid - 4 * (l2 >> 5);
-    {
-      // the residual stream goes back to HBM under the Q GEMM (rows past a ragged tile's end go
-      // to the scratch row: an address select, no divergent branch around the store)
-      float* xs = p.x + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
-      float* xdump = p.dump + wcol + (l2 & 31);
-      auto xepi = [&](auto CI_) {
-        if constexpr (XEPI) {
-          constexpr int CI = decltype(CI_)::value, mt = CI / 8, r0 = 2 * (CI % 8);
-#pragma unroll
-          for (int r = r0; r < r0 + 2; ++r) {
-            const int row = 32 * mt + crow(r, 0);
-            *(row < nv2 ? xs + row * C : xdump) = xacc[mt][r];
-          }
-        }
-      };
-      ws.template gemm_epi<C, P_T0, true, C, SP::Q, SP::K>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
-                                                           p.a.wk_l, wave, 0, xepi);
-    }
+    // (issuing the x store under this GEMM, or phi(K) under the V GEMM below, was measured
+    //  neutral to slightly slower - one-process A/B, 51.6 vs 51.9 us; only the GELU epilogues
+    //  and the phi(Q) store pay for the interleave)
+    ws.template gemm<C, P_T0, true, C, SP::Q, SP::K>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
+                                                     p.a.wk_l, wave, 0);
     PHASE_STAMP(p, 10);
     f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
     {
@@ -1219,16 +1180,12 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       ws.template gemm_epi<C, P_T1, true, C, SP::K, SP::V>(P2, p.a.wk, p.a.wk_l, wave, 0, lane, accK, p.a.wv,
                                                            p.a.wv_l, wave, 0, qepi);
     }
-    // phi(K), its row mask and sum under the V GEMM's MFMAs
-    float ksum = 0.f;
-    {
-      auto kepi = [&](auto CI_) { phi_k_slice<decltype(CI_)::value>(accK, ksum, nv2); };
-      ws.template gemm_epi<C, P_T2, false, C, SP::V, SITE_FULL>(P2, p.a.wv, p.a.wv_l, wave, 0, lane, accV, nullptr,
-                                                                nullptr, 0, 0, kepi);
-    }
+    ws.template gemm<C, P_T2, false, C, SP::V>(P2, p.a.wv, p.a.wv_l, wave, 0, lane, accV, nullptr, nullptr,
+                                               0, 0);
     PHASE_STAMP(p, 11);
     f32x16 kv;
-    kv_state_64<MODE, true>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
+    float ksum;
+    kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
   } else if (TAIL == 1) {
