@@ -204,7 +204,6 @@ bool make_geom(int n, int hf1, int wf1, int hf2, int wf2, Geom* g) {
 // workgroups; oetr_set_encoder_tile overrides.  The heads keep TM.
 int encoder_tile_rows(const oetr_ctx* h, const Geom& g) {
   if (!gm_half(h->mode) || h->attn_full) return TM;
-  if (h->policy != 0) return RT;   // the reduced-site kernels exist in the 64-token shape
   const int want = h->enc_tile;
   if (want == TM || want == 64) return want;
   return g.ntiles > h->num_cus ? 64 : TM;
@@ -1243,8 +1242,6 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_encoder_tile: NULL handle");
   if (rows != 0 && rows != TM && rows != 64)
     return fail(OETR_ERR_BAD_ARG, "oetr_set_encoder_tile: rows must be 0 (auto), 32 or 64");
-  if (rows == TM && h->policy != 0)
-    return fail(OETR_ERR_UNSUPPORTED, "OETR_DTYPE_F32_SPLIT_QK16 runs 64-token encoder workgroups only");
   h->enc_tile = rows;
   return OETR_OK;
 }

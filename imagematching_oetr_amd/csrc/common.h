@@ -68,6 +68,64 @@ enum { GM_F32 = 0, GM_SPLIT = 1, GM_F16 = 2, GM_BF16 = 3 };
 constexpr bool gm_half(int m) { return m != GM_F32; }          // operands are 16-bit planes
 constexpr int gm_planes(int m) { return m == GM_SPLIT ? 2 : 1; }  // planes per operand
 
+// Per-GEMM-site arithmetic of the two-plane (split) mode - the precision policy
+// (DESIGN.md 3.10).  A product a.b with a = ah + al/2^11, b = bh + bl/2^11 keeps
+//   SITE_FULL   ah.bh + (ah.bl + al.bh)/2^11      3 MFMAs, fp32-class
+//   SITE_ACT_HI ah.bh + ah.bl/2^11                2 MFMAs, activations rounded to f16
+//   SITE_W_HI   ah.bh + al.bh/2^11                2 MFMAs, weights rounded to f16
+//   SITE_HI     ah.bh                             1 MFMA,  both rounded to f16 (RNE: the hi
+//                                                 planes ARE round-to-nearest f16 values)
+// Fragments a site does not use are neither fetched (weight lo plane) nor read (activation
+// lo plane).  Ignored by the single-plane modes.
+enum { SITE_FULL = 0, SITE_ACT_HI = 1, SITE_W_HI = 2, SITE_HI = 3 };
+constexpr bool site_w_lo(int s) { return s == SITE_FULL || s == SITE_ACT_HI; }    // uses bl
+constexpr bool site_act_lo(int s) { return s == SITE_FULL || s == SITE_W_HI; }    // uses al
+constexpr int site_mfmas(int s) { return s == SITE_FULL ? 3 : s == SITE_HI ? 1 : 2; }
+// Policies (oetr_dtype -> policy id, api.hip).  The assignment is what survives the north_star
+// bar - boxes within 1e-3 IoU of the fp32 reference on every golden, sharpened heads included -
+// when ONE site at a time, then the combination, is reduced (tools/site_drift.py on the CPU
+// oracle; tests/test_gpu_precision.py + profiles/r3_site_drift.json on the GPU):
+//   Q, K and the decoder's K projection tolerate f16 operands (phi(Q) enters numerator and
+//   normaliser alike, K only through sums over all source tokens); V, merge, both MLP GEMMs and
+//   the attention contractions do not (each alone: 1 - IoU = 3e-3 .. 3e-2).
+// Policy 0 = every site fp32-class.  The OETR_SITE_* macros exist for the per-site drift study
+// (variant builds of the library), not for shipping.
+#ifndef OETR_SITE_Q
+#define OETR_SITE_Q SITE_FULL
+#endif
+#ifndef OETR_SITE_K
+#define OETR_SITE_K SITE_FULL
+#endif
+#ifndef OETR_SITE_V
+#define OETR_SITE_V SITE_FULL
+#endif
+#ifndef OETR_SITE_MERGE
+#define OETR_SITE_MERGE SITE_FULL
+#endif
+#ifndef OETR_SITE_MLP1
+#define OETR_SITE_MLP1 SITE_FULL
+#endif
+#ifndef OETR_SITE_MLP2
+#define OETR_SITE_MLP2 SITE_FULL
+#endif
+#ifndef OETR_SITE_DEC_K
+#define OETR_SITE_DEC_K SITE_FULL
+#endif
+#ifndef OETR_SITE_DEC_V
+#define OETR_SITE_DEC_V SITE_FULL
+#endif
+template <int POL> struct SitePolicy;
+template <> struct SitePolicy<0> {
+  static constexpr int Q = OETR_SITE_Q, K = OETR_SITE_K, V = OETR_SITE_V, MERGE = OETR_SITE_MERGE,
+                       MLP1 = OETR_SITE_MLP1, MLP2 = OETR_SITE_MLP2, DEC_K = OETR_SITE_DEC_K,
+                       DEC_V = OETR_SITE_DEC_V;
+};
+template <> struct SitePolicy<1> {   // OETR_DTYPE_F32_SPLIT_QK16
+  static constexpr int Q = SITE_HI, K = SITE_HI, V = SITE_FULL, MERGE = SITE_FULL, MLP1 = SITE_FULL,
+                       MLP2 = SITE_FULL, DEC_K = SITE_HI, DEC_V = SITE_FULL;
+};
+constexpr int N_POLICIES = 2;
+
 // "f32 via split f16" GEMM mode: a = ah + al/2^11 with ah = f16(a),
 // al = f16((a - ah) * 2^11); a*b ~= ah*bh + (ah*bl + al*bh)/2^11 on
 // v_mfma_f32_32x32x16_f16 (3 MFMAs, 16x the f32 MFMA rate each) with f32
@@ -654,9 +712,10 @@ struct ATile {
   __device__ __forceinline__ ATile(float* base, int ldf_, int ldh_, Range* rg_)
       : f(base), h(reinterpret_cast<_Float16*>(base)),
         l(reinterpret_cast<_Float16*>(base) + TM * ldh_), ldf(ldf_), ldh(ldh_), rg(rg_) {}
-  // 4 consecutive values of one row
+  // 4 consecutive values of one row (LO = false: the consumer site reads the hi plane only)
+  template <bool LO = true>
   __device__ __forceinline__ void put4(int row, int c, const f32x4& v) const {
-    if constexpr (HALF) store_planes4<M>(h + row * ldh, l + row * ldh, c, v, *rg);
+    if constexpr (HALF) store_planes4<M, LO>(h + row * ldh, l + row * ldh, c, v, *rg);
     else *reinterpret_cast<f32x4*>(f + row * ldf + c) = v;
   }
   template <int NT>
@@ -741,12 +800,13 @@ __device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4]
 template <int M, int NT, bool STREAMED = (gm_half(M) && NT == 1)>
 struct WStream {
   static constexpr int adv(int, int) { return 0; }
-  template <int K, int P>
+  template <int K, int P, int SITE = SITE_FULL>
   __device__ __forceinline__ void prime(const f32x4*, const f32x4*, int, int) {}
-  template <int K, int P, int NK, class AT>
+  template <int K, int P, int NK, int SITE = SITE_FULL, int NSITE = SITE_FULL, class AT>
   __device__ __forceinline__ void gemm(const AT& A, const f32x4* W, const f32x4* Wl, int nt0,
                                        int lane, f32x16 (&acc)[NT], const f32x4*, const f32x4*,
                                        int, int dbg) {
+    static_assert(SITE == SITE_FULL, "reduced sites need the streamed one-n-tile-per-wave shape");
     A.template gemm<K, NT>(W, Wl, nt0, lane, acc, dbg);
   }
 };
@@ -763,31 +823,32 @@ struct WStream<M, 1, true> {
 
   static constexpr int adv(int P, int K) { return (P + K / 16 / U) % D; }
 
-  template <int SLOT>
+  template <int SLOT, int SITE>
   __device__ __forceinline__ void fetch(const f32x4* wh, const f32x4* wl, int chunk) {
     if (ABL(dbg, ABL_WLOAD)) return;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ring[SLOT].bh[u] = wh[(chunk * U + u) * 64];
-      if constexpr (TWO) ring[SLOT].bl[u] = wl[(chunk * U + u) * 64];
+      if constexpr (TWO && site_w_lo(SITE)) ring[SLOT].bl[u] = wl[(chunk * U + u) * 64];
     }
   }
-  template <int P, int J>
+  template <int P, int J, int SITE>
   __device__ __forceinline__ void fetch_first(const f32x4* wh, const f32x4* wl) {
     if constexpr (J < PRE) {
-      fetch<(P + J) % D>(wh, wl, J);
-      fetch_first<P, J + 1>(wh, wl);
+      fetch<(P + J) % D, SITE>(wh, wl, J);
+      fetch_first<P, J + 1, SITE>(wh, wl);
     }
   }
-  // Issue the first PRE chunks of a GEMM's weights (K = its reduction length).
-  template <int K, int P>
+  // Issue the first PRE chunks of a GEMM's weights (K = its reduction length, SITE = its
+  // arithmetic: a site that does not use the weights' lo plane does not fetch it).
+  template <int K, int P, int SITE = SITE_FULL>
   __device__ __forceinline__ void prime(const f32x4* W, const f32x4* Wl, int nt0, int lane) {
     const size_t off = (size_t)nt0 * (K / 16) * 64 + lane;
-    fetch_first<P, 0>(W + off, Wl + off);
+    fetch_first<P, 0, SITE>(W + off, Wl + off);
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  template <int K, int P, int NK, int CI>
+  template <int K, int P, int NK, int CI, int SITE, int NSITE>
   __device__ __forceinline__ void step(const _Float16* ah_ptr, const _Float16* al_ptr,
                                        const f32x4* wh, const f32x4* wl, const f32x4* nwh,
                                        const f32x4* nwl, AChunk (&a)[2], f32x16& acc,
@@ -795,13 +856,13 @@ struct WStream<M, 1, true> {
     constexpr int NCH = K / 16 / U;
     if constexpr (CI < NCH) {
       constexpr int PF = CI + PRE;
-      if constexpr (PF < NCH) fetch<(P + PF) % D>(wh, wl, PF);
-      else if constexpr (NK != 0) fetch<(P + PF) % D>(nwh, nwl, PF - NCH);
+      if constexpr (PF < NCH) fetch<(P + PF) % D, SITE>(wh, wl, PF);
+      else if constexpr (NK != 0) fetch<(P + PF) % D, NSITE>(nwh, nwl, PF - NCH);
       if constexpr (CI + 1 < NCH) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           a[(CI + 1) & 1].ah[u] = *reinterpret_cast<const f32x4*>(ah_ptr + ((CI + 1) * U + u) * 16);
-          if constexpr (TWO)
+          if constexpr (TWO && site_act_lo(SITE))
             a[(CI + 1) & 1].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + ((CI + 1) * U + u) * 16);
         }
       }
@@ -810,21 +871,19 @@ struct WStream<M, 1, true> {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         acc = mma16<M>(a[CI & 1].ah[u], b.bh[u], acc);
-        if constexpr (TWO) {
-          cross = mma16<M>(a[CI & 1].ah[u], b.bl[u], cross);
-          cross2 = mma16<M>(a[CI & 1].al[u], b.bh[u], cross2);
-        }
+        if constexpr (TWO && site_w_lo(SITE)) cross = mma16<M>(a[CI & 1].ah[u], b.bl[u], cross);
+        if constexpr (TWO && site_act_lo(SITE)) cross2 = mma16<M>(a[CI & 1].al[u], b.bh[u], cross2);
       }
       __builtin_amdgcn_sched_barrier(0);
-      step<K, P, NK, CI + 1>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross, cross2);
+      step<K, P, NK, CI + 1, SITE, NSITE>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross, cross2);
     }
   }
 
   // acc += A . W^T for this wave's n-tile nt0; chunks 0..PRE-1 of W are already in
   // the ring (prime<K,P> or the previous gemm's NK).  NK != 0: the next GEMM has
-  // reduction length NK and weights (nW, nWl, nnt0); its first chunks are fetched
-  // while this one finishes.
-  template <int K, int P, int NK, class AT>
+  // reduction length NK, weights (nW, nWl, nnt0) and arithmetic NSITE; its first chunks are
+  // fetched while this one finishes.  SITE: this GEMM's arithmetic (SITE_*).
+  template <int K, int P, int NK, int SITE = SITE_FULL, int NSITE = SITE_FULL, class AT>
   __device__ __forceinline__ void gemm(const AT& A, const f32x4* W, const f32x4* Wl, int nt0,
                                        int lane, f32x16 (&acc)[1], const f32x4* nW,
                                        const f32x4* nWl, int nnt0, int) {
@@ -839,12 +898,12 @@ struct WStream<M, 1, true> {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       a[0].ah[u] = *reinterpret_cast<const f32x4*>(ah_ptr + u * 16);
-      if constexpr (TWO) a[0].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + u * 16);
+      if constexpr (TWO && site_act_lo(SITE)) a[0].al[u] = *reinterpret_cast<const f32x4*>(al_ptr + u * 16);
     }
     f32x16 cross = {0}, cross2 = {0};
-    step<K, P, NK, 0>(ah_ptr, al_ptr, W + off, Wl + off, NK ? nW + noff : nullptr,
-                      NK ? nWl + noff : nullptr, a, acc[0], cross, cross2);
-    if constexpr (TWO) {
+    step<K, P, NK, 0, SITE, NSITE>(ah_ptr, al_ptr, W + off, Wl + off, NK ? nW + noff : nullptr,
+                                   NK ? nWl + noff : nullptr, a, acc[0], cross, cross2);
+    if constexpr (TWO && SITE != SITE_HI) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][r] = fmaf(cross[r] + cross2[r], SPLIT_INV, acc[0][r]);
     }
@@ -894,64 +953,6 @@ typedef PlanesT<GM_SPLIT> Planes2;
 #define OETR_RING2_1P 4   // the same for the single-plane modes
 #endif
 struct NoEpi { template <class T> __device__ __forceinline__ void operator()(T) const {} };
-
-// Per-GEMM-site arithmetic of the two-plane (split) mode - the precision policy
-// (DESIGN.md 3.10).  A product a.b with a = ah + al/2^11, b = bh + bl/2^11 keeps
-//   SITE_FULL   ah.bh + (ah.bl + al.bh)/2^11      3 MFMAs, fp32-class
-//   SITE_ACT_HI ah.bh + ah.bl/2^11                2 MFMAs, activations rounded to f16
-//   SITE_W_HI   ah.bh + al.bh/2^11                2 MFMAs, weights rounded to f16
-//   SITE_HI     ah.bh                             1 MFMA,  both rounded to f16 (RNE: the hi
-//                                                 planes ARE round-to-nearest f16 values)
-// Fragments a site does not use are neither fetched (weight lo plane) nor read (activation
-// lo plane).  Ignored by the single-plane modes.
-enum { SITE_FULL = 0, SITE_ACT_HI = 1, SITE_W_HI = 2, SITE_HI = 3 };
-constexpr bool site_w_lo(int s) { return s == SITE_FULL || s == SITE_ACT_HI; }    // uses bl
-constexpr bool site_act_lo(int s) { return s == SITE_FULL || s == SITE_W_HI; }    // uses al
-constexpr int site_mfmas(int s) { return s == SITE_FULL ? 3 : s == SITE_HI ? 1 : 2; }
-// Policies (oetr_dtype -> policy id, api.hip).  The assignment is what survives the north_star
-// bar - boxes within 1e-3 IoU of the fp32 reference on every golden, sharpened heads included -
-// when ONE site at a time, then the combination, is reduced (tools/site_drift.py on the CPU
-// oracle; tests/test_gpu_precision.py + profiles/r3_site_drift.json on the GPU):
-//   Q, K and the decoder's K projection tolerate f16 operands (phi(Q) enters numerator and
-//   normaliser alike, K only through sums over all source tokens); V, merge, both MLP GEMMs and
-//   the attention contractions do not (each alone: 1 - IoU = 3e-3 .. 3e-2).
-// Policy 0 = every site fp32-class.  The OETR_SITE_* macros exist for the per-site drift study
-// (variant builds of the library), not for shipping.
-#ifndef OETR_SITE_Q
-#define OETR_SITE_Q SITE_FULL
-#endif
-#ifndef OETR_SITE_K
-#define OETR_SITE_K SITE_FULL
-#endif
-#ifndef OETR_SITE_V
-#define OETR_SITE_V SITE_FULL
-#endif
-#ifndef OETR_SITE_MERGE
-#define OETR_SITE_MERGE SITE_FULL
-#endif
-#ifndef OETR_SITE_MLP1
-#define OETR_SITE_MLP1 SITE_FULL
-#endif
-#ifndef OETR_SITE_MLP2
-#define OETR_SITE_MLP2 SITE_FULL
-#endif
-#ifndef OETR_SITE_DEC_K
-#define OETR_SITE_DEC_K SITE_FULL
-#endif
-#ifndef OETR_SITE_DEC_V
-#define OETR_SITE_DEC_V SITE_FULL
-#endif
-template <int POL> struct SitePolicy;
-template <> struct SitePolicy<0> {
-  static constexpr int Q = OETR_SITE_Q, K = OETR_SITE_K, V = OETR_SITE_V, MERGE = OETR_SITE_MERGE,
-                       MLP1 = OETR_SITE_MLP1, MLP2 = OETR_SITE_MLP2, DEC_K = OETR_SITE_DEC_K,
-                       DEC_V = OETR_SITE_DEC_V;
-};
-template <> struct SitePolicy<1> {   // OETR_DTYPE_F32_SPLIT_QK16
-  static constexpr int Q = SITE_HI, K = SITE_HI, V = SITE_FULL, MERGE = SITE_FULL, MLP1 = SITE_FULL,
-                       MLP2 = SITE_FULL, DEC_K = SITE_HI, DEC_V = SITE_FULL;
-};
-constexpr int N_POLICIES = 2;
 
 // ROWS: how many of the tile's two 32-row MFMA tiles run.  2 / 1: fixed at compile time - the
 // GEMM steps are branch-free, which is what lets hipcc interleave a step's MFMAs with the

@@ -292,9 +292,11 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
             f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv});
 }
 
-template <bool HAS_B, int TAIL, int MODE, int NW, bool FULL = false>
+template <bool HAS_B, int TAIL, int MODE, int NW, bool FULL = false, int POL = 0>
 __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   constexpr bool SPLIT = gm_half(MODE);  // GEMM operands live in 16-bit LDS planes
+  using SP = SitePolicy<POL>;            // arithmetic per GEMM site (two-plane mode, NW = 8)
+  static_assert(POL == 0 || (gm_planes(MODE) == 2 && NW == 8 && !FULL), "policies: split mode, one n-tile per wave");
   static_assert(!FULL || (gm_f16_range(MODE) && NW == 8), "full attention: f16-based modes, one head per wave");
   using Cfg = EncCfg<NW>;
   constexpr int NT = Cfg::NT, THREADS = Cfg::THREADS, WC = Cfg::WC, TPR = Cfg::TPR, F4 = Cfg::F4;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       }
       if (THREADS == C || tid < C) ksum_s[tid] = ks;
     }
-    ws.template prime<C, P_MERGE>(p.b.wmerge, p.b.wmerge_l, NT * wave, lane);
+    ws.template prime<C, P_MERGE, SP::MERGE>(p.b.wmerge, p.b.wmerge_l, NT * wave, lane);
     __syncthreads();
     PHASE_STAMP(p, 1);
 
@@ -487,8 +489,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     PHASE_STAMP(p, 2);
 
     // x1 = x + message . Wmerge^T
-    ws.template gemm<C, P_MERGE, C>(S1, p.b.wmerge, p.b.wmerge_l, NT * wave, lane, xacc, p.b.w1,
-                                    p.b.w1_l, 2 * NT * wave, p.dbg);
+    ws.template gemm<C, P_MERGE, C, SP::MERGE, SP::MLP1>(S1, p.b.wmerge, p.b.wmerge_l, NT * wave, lane, xacc,
+                                                         p.b.w1, p.b.w1_l, 2 * NT * wave, p.dbg);
     acc_to_lds<NT>(S0, LDA, wcol, lane, xacc);
     __syncthreads();
     PHASE_STAMP(p, 3);
@@ -511,8 +513,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       f32x16 hacc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) hacc[t] = f32x16{0};
-      ws.template gemm<C, P_W1A, C>(S1, p.b.w1, p.b.w1_l, 2 * NT * wave, lane, hacc, p.b.w1,
-                                    p.b.w1_l, 2 * NT * wave + NT, p.dbg);
+      ws.template gemm<C, P_W1A, C, SP::MLP1, SP::MLP1>(S1, p.b.w1, p.b.w1_l, 2 * NT * wave, lane, hacc, p.b.w1,
+                                                        p.b.w1_l, 2 * NT * wave + NT, p.dbg);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -525,8 +527,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       Hh.template put_acc<NT>(2 * wcol, lane, hacc);
 #pragma unroll
       for (int t = 0; t < NT; ++t) hacc[t] = f32x16{0};
-      ws.template gemm<C, P_W1B, FF>(S1, p.b.w1, p.b.w1_l, 2 * NT * wave + NT, lane, hacc, p.b.w2,
-                                     p.b.w2_l, NT * wave, p.dbg);
+      ws.template gemm<C, P_W1B, FF, SP::MLP1, SP::MLP2>(S1, p.b.w1, p.b.w1_l, 2 * NT * wave + NT, lane, hacc,
+                                                         p.b.w2, p.b.w2_l, NT * wave, p.dbg);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     PHASE_STAMP(p, 5);
 
     // x2 = x1 + hidden . W2^T ; write back
-    ws.template gemm<FF, P_W2, (TAIL == 2 ? 0 : C)>(
+    ws.template gemm<FF, P_W2, (TAIL == 2 ? 0 : C), SP::MLP2, (TAIL == 0 ? SP::Q : SP::DEC_K)>(
         Hh, p.b.w2, p.b.w2_l, NT * wave, lane, xacc, TAIL == 0 ? p.a.wq : p.d.wk[0],
         TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], NT * wave, p.dbg);
 #pragma unroll
@@ -562,8 +564,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     } else {
       load_tile<THREADS>(S0, p.x + row_base * C, nvalid, tid);  // first launch: x from HBM
     }
-    if (TAIL == 0) ws.template prime<C, P_T0>(p.a.wq, p.a.wq_l, NT * wave, lane);
-    if (TAIL == 1) ws.template prime<C, P_T0>(p.d.wk[0], p.d.wk_l[0], NT * wave, lane);
+    if (TAIL == 0) ws.template prime<C, P_T0, SP::Q>(p.a.wq, p.a.wq_l, NT * wave, lane);
+    if (TAIL == 1) ws.template prime<C, P_T0, SP::DEC_K>(p.d.wk[0], p.d.wk_l[0], NT * wave, lane);
     __syncthreads();
     if (nchw) {  // token-major copies for the later launches (residual reads, position rows)
       store_tile_tokens<THREADS, TM>(p.x + row_base * C, S0, nvalid, tid);
@@ -594,8 +596,9 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       const f32x4* kb = reinterpret_cast<const f32x4*>(lnp_s + 5 * C) + lpart;
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
-        S1.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * qw[i * TPR] + qb[i * TPR]) + ps[i]);
-        S2.put4(lrow, 4 * (i * TPR + lpart), (xn[i] * kw[i * TPR] + kb[i * TPR]) + ps[i]);
+        S1.template put4<site_act_lo(SP::Q)>(lrow, 4 * (i * TPR + lpart), (xn[i] * qw[i * TPR] + qb[i * TPR]) + ps[i]);
+        S2.template put4<site_act_lo(SP::K) || site_act_lo(SP::V)>(lrow, 4 * (i * TPR + lpart),
+                                                                   (xn[i] * kw[i * TPR] + kb[i * TPR]) + ps[i]);
       }
     }
     __syncthreads();
@@ -605,8 +608,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       f32x16 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
-      ws.template gemm<C, P_T0, C>(S1, p.a.wq, p.a.wq_l, NT * wave, lane, acc, p.a.wk, p.a.wk_l,
-                                   NT * wave, p.dbg);
+      ws.template gemm<C, P_T0, C, SP::Q, SP::K>(S1, p.a.wq, p.a.wq_l, NT * wave, lane, acc, p.a.wk, p.a.wk_l,
+                                                 NT * wave, p.dbg);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -620,10 +623,10 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     f32x16 accK[NT], accV[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { accK[t] = f32x16{0}; accV[t] = f32x16{0}; }
-    ws.template gemm<C, P_T1, C>(S2, p.a.wk, p.a.wk_l, NT * wave, lane, accK, p.a.wv, p.a.wv_l,
-                                 NT * wave, p.dbg);
-    ws.template gemm<C, P_T2, 0>(S2, p.a.wv, p.a.wv_l, NT * wave, lane, accV, nullptr, nullptr, 0,
-                                 p.dbg);
+    ws.template gemm<C, P_T1, C, SP::K, SP::V>(S2, p.a.wk, p.a.wk_l, NT * wave, lane, accK, p.a.wv, p.a.wv_l,
+                                               NT * wave, p.dbg);
+    ws.template gemm<C, P_T2, 0, SP::V>(S2, p.a.wv, p.a.wv_l, NT * wave, lane, accV, nullptr, nullptr, 0,
+                                        p.dbg);
     PHASE_STAMP(p, 9);
     if constexpr (FULL) {
       // K row-major, V transposed ([channel][token], padded to whole tiles: every row of
@@ -649,8 +652,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
         const f32x4 xv = src[i * TPR];
-        S1.put4(lrow, 4 * (i * TPR + lpart), xv + pos[i * TPR]);  // k input: memory + pos
-        if (SPLIT) S2.put4(lrow, 4 * (i * TPR + lpart), xv);      // v input (f32 mode reads S0)
+        S1.template put4<site_act_lo(SP::DEC_K)>(lrow, 4 * (i * TPR + lpart), xv + pos[i * TPR]);  // k input: memory + pos
+        if (SPLIT) S2.template put4<site_act_lo(SP::DEC_V)>(lrow, 4 * (i * TPR + lpart), xv);      // v input (f32 mode reads S0)
       }
     }
     __syncthreads();
@@ -673,10 +676,11 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accK[t][r] = bias_k[dl][t]; accV[t][r] = bias_v[dl][t]; }
-      ws.template gemm<C, PK, C>(S1, p.d.wk[dl], p.d.wk_l[dl], NT * wave, lane, accK, p.d.wv[dl],
-                                 p.d.wv_l[dl], NT * wave, p.dbg);
-      ws.template gemm<C, PV, (dl == 0 ? C : 0)>(Vin, p.d.wv[dl], p.d.wv_l[dl], NT * wave, lane,
-                                                 accV, p.d.wk[1], p.d.wk_l[1], NT * wave, p.dbg);
+      ws.template gemm<C, PK, C, SP::DEC_K, SP::DEC_V>(S1, p.d.wk[dl], p.d.wk_l[dl], NT * wave, lane, accK,
+                                                       p.d.wv[dl], p.d.wv_l[dl], NT * wave, p.dbg);
+      ws.template gemm<C, PV, (dl == 0 ? C : 0), SP::DEC_V, SP::DEC_K>(Vin, p.d.wv[dl], p.d.wv_l[dl], NT * wave,
+                                                                       lane, accV, p.d.wk[1], p.d.wk_l[1],
+                                                                       NT * wave, p.dbg);
       if constexpr (dl == 1) {
         kv_state_store<MODE, NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.dkv1_out,
                                  p.dks1_out, slot, rg);
@@ -1316,8 +1320,26 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
       return hipGetLastError();
     }
   }
-  if (p.policy != 0) return hipErrorInvalidValue;   // policies: 64-token workgroups only (api.hip)
   constexpr int NW = gm_half(MODE) ? OETR_SPLIT_WAVES : OETR_F32_WAVES;
+  if (p.policy != 0) {
+    if constexpr (MODE == GM_SPLIT && NW == 8) {
+      if (p.policy != 1 || p.attn_full) return hipErrorInvalidValue;
+#define OETR_LAUNCHP(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, NW, false, 1>), grid, dim3(64 * NW), 0, s, p)
+      if (has_b) {
+        if (tail == 0) OETR_LAUNCHP(true, 0);
+        else if (tail == 1) OETR_LAUNCHP(true, 1);
+        else OETR_LAUNCHP(true, 2);
+      } else {
+        if (tail == 0) OETR_LAUNCHP(false, 0);
+        else if (tail == 1) OETR_LAUNCHP(false, 1);
+        else OETR_LAUNCHP(false, 2);
+      }
+#undef OETR_LAUNCHP
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (p.attn_full) {
     if constexpr (gm_f16_range(MODE) && NW == 8) {
 #define OETR_LAUNCHF(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, NW, true>), grid, dim3(64 * NW), 0, s, p)

@@ -79,7 +79,7 @@ typedef enum {
  *                            when reduced - phi(Q) enters numerator and normaliser alike, K
  *                            only through sums over all source tokens; V, merge, the MLP and
  *                            the attention contractions themselves do not (per-site table:
- *                            profiles/r3_site_drift.json).  64-token encoder workgroups only.
+ *                            profiles/r3_site_drift.jsonl).  Both encoder workgroup shapes.
  * The reference itself is fp32-only (no autocast anywhere); the two all-rounded 16-bit modes
  * trade parity margin (tests/test_gpu_precision.py records the drift: they MISS the 1e-3 IoU
  * bar) for MFMA rate; QK16 is the reduced mode that meets it. */

@@ -61,7 +61,7 @@ def test_configs3_32_pairs_at_1024(gpu, precision):
     w = orc.make_hot_weights(3, sharpen=True)
     eng = _engine(w, gpu, precision)
     _check_batch(eng, gpu, w, 32, (32, 32), (32, 32), (1024, 1024), (1024, 1024), seed=510, n_oracle=4,
-                 slice_exact=precision != 'f32_split_f16')
+                 slice_exact='@' in precision)
 
 
 def test_configs3_tile_shapes_agree(gpu):
@@ -85,7 +85,7 @@ def test_configs4_mixed_scale_640_vs_1280(gpu, precision):
     w = orc.make_hot_weights(5, sharpen=True)
     eng = _engine(w, gpu, precision)
     _check_batch(eng, gpu, w, 8, (20, 20), (40, 40), (640, 640), (1280, 1280), seed=530, n_oracle=3,
-                 slice_exact=precision != 'f32_split_f16')
+                 slice_exact='@' in precision)
 
 
 def test_configs2_policy_8_pairs_at_640(gpu):

@@ -144,16 +144,18 @@ POLICY = 'f32_split_qk16'
 POLICY_TOL = dict(memory=3e-4, hs=3e-4, tlbr=5e-5, cxy=0.15)   # observed 6e-5 / 6e-5 / 1e-5 / 0.035 px
 
 
+@pytest.mark.parametrize('precision', [POLICY + '@32', POLICY + '@64'])
 @pytest.mark.parametrize('path', HOT, ids=lambda p: p.split('hot_')[-1][:-4])
-def test_precision_policy_meets_the_north_star_iou_bar(path, gpu):
+def test_precision_policy_meets_the_north_star_iou_bar(path, precision, gpu):
     """The north_star bar (IoU >= 1 - 1e-3 vs the REFERENCE's boxes) under the QK16 policy, on
     every golden - 20x20, 32x32, mixed 20x20 vs 40x40 (configs[4]'s shape), ragged grids,
-    plain and sharpened heads - plus bounds on the intermediate tensors.  A plain test."""
-    entry, drift, ious = _golden_drift(path, POLICY, gpu)
-    assert all(v >= 1 - 1e-3 for v in ious), f'{POLICY}: IoU bar missed: {entry}'
+    plain and sharpened heads - in both encoder workgroup shapes, plus bounds on the
+    intermediate tensors.  A plain test."""
+    entry, drift, ious = _golden_drift(path, precision, gpu)
+    assert all(v >= 1 - 1e-3 for v in ious), f'{precision}: IoU bar missed: {entry}'
     for key, v in drift.items():
         if key[:-1] in POLICY_TOL:
-            assert v <= POLICY_TOL[key[:-1]], f'{POLICY} {key}: drift {v:.3e} ({entry})'
+            assert v <= POLICY_TOL[key[:-1]], f'{precision} {key}: drift {v:.3e} ({entry})'
 
 
 def test_precision_policy_full_forward_golden_boxes(gpu, golden_dir):
@@ -169,15 +171,20 @@ def test_precision_policy_full_forward_golden_boxes(gpu, golden_dir):
     assert (iou >= 1 - 1e-3).all(), iou
 
 
-def test_precision_policy_is_a_64_token_mode(gpu):
-    """The reduced-site kernels exist in the 64-token workgroup shape, linear attention."""
+def test_precision_policy_shapes_and_limits(gpu):
+    """Both encoder workgroup shapes run the policy (same sites reduced: boxes agree to the
+    summation-order level); the all-pairs attention mode has no policy build."""
     from imagematching_oetr_amd import HotPathEngine, OetrError
-    w = orc.make_hot_weights(0)
+    w = orc.make_hot_weights(1, sharpen=True)
+    f1, f2 = orc.make_features(11, 2, 20, 20).to(gpu), orc.make_features(111, 2, 20, 20).to(gpu)
+    p = orc.position_table(20, 20).to(gpu)
     eng = _engine(w, gpu, POLICY)
-    with pytest.raises(OetrError):
-        eng.set_encoder_tile(32)
-    eng.set_encoder_tile(64)
-    eng.set_encoder_tile(0)
+    boxes = {}
+    for tile in (32, 64, 0):
+        eng.set_encoder_tile(tile)
+        boxes[tile] = eng.forward(f1, f2, p, p, (640, 640), (640, 640))
+    assert float((boxes[32][0] - boxes[64][0]).abs().max()) <= 5e-2
+    assert torch.equal(boxes[0][0], boxes[32][0])            # auto at 2 pairs: 32-token tiles
     with pytest.raises(OetrError):
         HotPathEngine(w, device=gpu, precision=POLICY, attention='full')
 

@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): bench lines + rocprofv3 kernel stats + PMC passes.
 # usage: tools/profile_round.sh <tag>     outputs under gpurun_out/<tag>/ ; copy the
 # summaries you want judged into profiles/<tag>_*.
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -10,8 +10,14 @@ export TMPDIR=/tmp
 cd $ROOT
 # ---- bench lines (driver-style invocations) --------------------------------
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-timeout 300 python bench.py --steps 20 --warmup 5 --precision bf16 --no-e2e > $OUT/bench_bf16.json 2>> $OUT/bench.err
-timeout 300 python bench.py --steps 20 --warmup 5 --precision f16 --size2 1280 --no-e2e > $OUT/bench_f16_mixed.json 2>> $OUT/bench.err
+# the per-GEMM-site precision policy (the reduced mode inside the IoU bar): configs[2] / configs[4] shares
+timeout 300 python bench.py --steps 20 --warmup 5 --precision f32_split_qk16 --no-e2e > $OUT/bench_qk16.json 2>> $OUT/bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --precision f32_split_qk16 --size2 1280 --no-e2e > $OUT/bench_qk16_mixed.json 2>> $OUT/bench.err
+# the all-rounded single-pass modes (miss the bar: comparison only)
+timeout 300 python bench.py --steps 20 --warmup 5 --precision bf16 --no-e2e --no-cpu-baseline > $OUT/bench_bf16.json 2>> $OUT/bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --precision f16 --size2 1280 --no-e2e --no-cpu-baseline > $OUT/bench_f16_mixed.json 2>> $OUT/bench.err
+# RCCL executed at world size 1 (process group forced)
+OETR_BENCH_FORCE_PG=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-e2e --no-cpu-baseline --no-exact-f32 2>> $OUT/bench.err | grep '^{' > $OUT/bench_rccl_world1.json
 timeout 300 python bench.py --steps 20 --warmup 5 --attention full --no-e2e --no-cpu-baseline > $OUT/bench_attention_full.json 2>> $OUT/bench.err
 OETR_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-e2e --no-exact-f32 2>> $OUT/bench.err | grep '^{' > $OUT/bench_gloo2.json
 for L in 1024 4096; do
@@ -28,6 +34,7 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $SERIAL32 > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace64 -o trace -- $SERIAL64 > $OUT/trace64.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/overlap_trace -o trace -- $BENCH > $OUT/overlap_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_qk16 -o trace -- $BENCH --streams 1 --precision f32_split_qk16 > $OUT/trace_qk16.log 2>&1
 # PMC in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass); default bench = both shapes
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
@@ -44,7 +51,7 @@ FA="python $ROOT/bench.py --kernel full_attention --L 1024 --steps 20 --warmup 3
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/fa_trace -o trace -- $FA > $OUT/fa_trace.log 2>&1
 cd $ROOT
 # summarise on the box; the raw rocpd databases are too big to carry back
-for d in trace trace64 overlap_trace neck_trace fa_trace; do
+for d in trace trace64 trace_qk16 overlap_trace neck_trace fa_trace; do
   db=$(find $OUT/$d -name "*.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_summary.py $db $OUT/${d}_kernel_stats.csv > /dev/null
 done
 for d in pmc_fetch pmc_write pmc_sq pmc_lds neck_pmc_fetch neck_pmc_write neck_pmc_lds; do
