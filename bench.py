@@ -227,7 +227,7 @@ def mangled_encoder(tile, mode_id, policy=0):
     """Substring of the B;A encoder kernel's mangled name in rocprofv3 CSVs."""
     if tile == 64:
         return f'k_encoder64ILb1ELi0ELi{mode_id}ELi{policy}EE'
-    return f'k_encoderILb1ELi0ELi{mode_id}ELi{4 if mode_id == 0 else 8}ELb0EE'
+    return f'k_encoderILb1ELi0ELi{mode_id}ELi{4 if mode_id == 0 else 8}ELb0ELi{policy}EE'
 
 
 def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload, extra_flop=0, grids=None):
