@@ -412,6 +412,11 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(respawn_under_torchrun(args))
 
+    if int(os.environ.get('RANK', 0)) != 0:
+        # only rank 0 reports: keep the other ranks' C-level stdout (RCCL's version banner is
+        # printed through C stdio at exit) away from the one JSON line
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))

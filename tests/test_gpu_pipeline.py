@@ -317,6 +317,49 @@ def test_forward_dummy_to_crop_is_one_hip_graph_with_the_default_guard(gpu):
     assert float((good[0] - e0).abs().max()) <= 5e-2
 
 
+def test_overflow_inside_a_replayed_graph_is_reported(gpu):
+    """A batch captured into a HIP graph cannot be re-run from the host side: its status reads
+    are graph nodes, and ``hip_graph_check()`` after a synchronised replay raises when one of
+    them tripped (never a silent wrong box)."""
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    sd = model.state_dict()
+    sd.update(orc.make_hot_weights(6, sharpen=True))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    g = torch.Generator().manual_seed(13)
+    im = torch.rand(2, 320, 320, 3, generator=g).to(gpu)
+    bb = model.backbone(im)
+    scale = torch.ones(1, device=gpu)
+
+    def step():
+        x = bb * scale
+        return model.boxes_from_backbone(x[:1], x[1:], (320, 320), (320, 320), both=x)
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        step()
+        model.hip_flush()
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        boxes = step()
+    graph.replay()
+    torch.cuda.synchronize()
+    model.hip_graph_check()                      # in range
+    assert torch.isfinite(boxes[0]).all()
+    scale.fill_(1e6)                             # same graph, out-of-range input
+    graph.replay()
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.OetrRangeError):
+        model.hip_graph_check()
+    scale.fill_(1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    model.hip_graph_check()                      # the words are rewritten by every replay
+
+
 def test_training_forward_matches_the_reference_results(gpu, golden_dir):
     """``OETR.forward(data)`` on the HIP stages vs the result dict the
     REFERENCE model's forward produced on CPU for the same seeded weights and batch

@@ -87,3 +87,25 @@ def test_raw_pairs_to_crops_without_a_host_round_trip(gpu):
         for s in (0, 1):
             assert tuple(crops.crop(s).shape) == tuple(ref[f'crop{s}'].shape)
             assert float((crops.crop(s).cpu() - ref[f'crop{s}']).abs().max()) <= 1e-5
+
+
+def test_raw_pairs_native_size_frames_are_bucketed(gpu):
+    """``resize=[-1]`` keeps every picture's own size as its OETR frame (reference
+    utils.py:297-298): pairs are then bucketed by shape, boxes still in input order."""
+    class Stub:   # forward_dummy's contract, boxes that identify the inputs
+        def parameters(self):
+            return iter([torch.zeros(1, device=gpu)])
+
+        def forward_dummy(self, a, b):
+            k = torch.arange(4, dtype=torch.float32, device=a.device)
+            return a.reshape(a.shape[0], -1).mean(1, keepdim=True) + k, b.reshape(b.shape[0], -1).mean(1, keepdim=True) - k
+    g = torch.Generator().manual_seed(8)
+    sizes = [((64, 96), (64, 96)), ((32, 32), (64, 96)), ((64, 96), (64, 96)), ((32, 32), (64, 96))]
+    raw = [((torch.rand(*a, 3, generator=g) * 255).to(torch.uint8), (torch.rand(*b, 3, generator=g) * 255).to(torch.uint8))
+           for a, b in sizes]
+    out = pkg.forward_pairs_raw(Stub(), raw, resize=[-1], grayscale=False, align='', max_batch=8)
+    for i, (a, b) in enumerate(raw):
+        ra, rb = rdo.read_overlap_image(a.numpy(), [-1], False, ''), rdo.read_overlap_image(b.numpy(), [-1], False, '')
+        assert abs(float(out['box0'][i, 0]) - float(ra['overlap_inp'].mean())) <= 1e-5, i
+        assert abs(float(out['box1'][i, 0]) - float(rb['overlap_inp'].mean())) <= 1e-5, i
+        assert tuple(out['inp0'][i].shape) == tuple(ra['inp'].shape) and out['overlap_scales0'][i] == (1.0, 1.0)
