@@ -726,11 +726,14 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 // Here every fragment feeds TWO 32-row MFMA tiles, so the same stream serves 64
 // tokens and the GEMM phases become MFMA/stream balanced.  LDS (160 KB) does not
 // hold the 32-token layout twice, so:
-//   * the residual stream lives in registers only (xacc[2]); LayerNorm input is
-//     staged as an f32 tile in region R1 and normalised IN PLACE into the f16
-//     planes of the same region (one extra barrier, no extra LDS);
-//   * the MLP runs in two hidden halves of 256: MLP1a -> R2, MLP2a (K = 256),
-//     MLP1b -> R2, MLP2b, so the hidden tile needs one region instead of two.
+//   * the residual stream lives in registers only (xacc[2]), in the TRANSPOSED accumulator
+//     layout from the attention apply to MLP2 (merge, MLP1 and MLP2 run with the weights as
+//     the A operand): a lane holds 16 channels of ONE token per row tile, in quads of 4
+//     consecutive channels.  The x tile and phi(Q) arrive as full rows through LDS, LN2 is
+//     computed from the registers (per-lane mean / M2, one 9-KB exchange, Chan's update),
+//     every plane store is 8 bytes, x leaves through an f32 tile in full 1-KB rows;
+//   * the MLP runs in two hidden halves of 256: MLP1a, MLP1b (+ GELU(a) -> R2), MLP2a (K = 256,
+//     + GELU(b) -> R1), MLP2b, so the hidden tile needs one region per half.
 //   R1: f32 [64][260]  or  planes hi|lo [64][264]      (LN staging / GEMM A operand)
 //   R2: f32 [64][260] (phi(Q))  or  planes (kv input, hidden half)
 // The per-wave weight stream (WStream2) is a ring of 6 k16-steps of B fragments
@@ -739,9 +742,10 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 constexpr int E2_R1 = 0;
 constexpr int E2_R2 = R_FLOATS;
 constexpr int E2_KSUM = 2 * R_FLOATS;
-constexpr int E2_Z = E2_KSUM + C;
-constexpr int E2_LNP = E2_Z + RT * NH;
-constexpr int E2_SMEM = E2_LNP + 6 * C;                  // 36096 floats = 141 KB
+constexpr int E2_LNP = E2_KSUM + C;
+constexpr int LNX_LD = 36;                               // (padded: 16 lanes' b128 reads hit 16 bank groups)
+constexpr int E2_LNX = E2_LNP + 6 * C;                   // LayerNorm partial statistics [64 tokens][16][mean, M2]
+constexpr int E2_SMEM = E2_LNX + RT * LNX_LD;            // 37888 floats = 148 KB
 
 // phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
 template <int MODE>
@@ -837,8 +841,8 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   // R2 after phase B (R1 then holds the second hidden half until MLP2b has read it)
   float* Xf = HAS_B ? R2f : R1f;
   float* ksum_s = smem + E2_KSUM;
-  float* z_s = smem + E2_Z;
   float* lnp_s = smem + E2_LNP;
+  float* lnx_s = smem + E2_LNX;
   using WS = WStream2T<MODE, ROWS>;
   WS ws;
   constexpr int P_MERGE = 0;
@@ -876,7 +880,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   const f32x4* pos = reinterpret_cast<const f32x4*>(
                          p.pos + (size_t)(g.prow0[side] + l0 + min(lrow, nvalid - 1)) * C) + lpart;
 
-  f32x16 xacc[2];  // residual stream of this wave's 32 columns, both row tiles (C layout)
+  f32x16 xacc[2];  // residual stream of this wave's 32 channels, both row tiles (transposed C layout)
   PHASE_STAMP(p, 0);
 
   if (HAS_B) {
@@ -886,7 +890,9 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     const int nts = p.kv_reduced ? 1 : g.nt[ss];
     const int src_slot0 = p.kv_reduced ? ss * g.N + n : g.tile0[ss] + n * g.nt[ss];
 
-    // phi(Q) tile -> R2 (f32)
+    // ---- round 3: the residual stream lives in the TRANSPOSED accumulator layout (lane = token,
+    //      register quads = 4 consecutive channels), merge / MLP2 run transposed like MLP1 ----
+    // phi(Q) tile -> R2 (f32): full 1-KB rows, 16 bytes per lane
 #pragma unroll
     for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {
       const int idx = tid + THREADS * i;
@@ -894,7 +900,8 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       *reinterpret_cast<f32x4*>(R2f + r * LDA + 4 * c4) =
           reinterpret_cast<const f32x4*>(p.qp + (row_base + min(r, nvalid - 1)) * C)[c4];
     }
-    // reduce the source image's partial KV states (fixed order) into B-operand order
+    // reduce the source image's partial KV states (fixed order): the registers are this head's
+    // state in MFMA fragment order (A operand of the transposed apply)
     f32x4 kvB[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) kvB[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -929,91 +936,132 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       }
       if (tid < C) ksum_s[tid] = ks;
     }
-    // residual x in accumulator layout (after the reduction: its 112 in-flight registers are free)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = min(32 * mt + crow(r, half), nvalid - 1);
-        xacc[mt][r] = p.x[(row_base + row) * C + wcol + col];
-      }
     ws.template prime<C, P_MERGE, SP::MERGE>(p.b.wmerge, p.b.wmerge_l, wave, 0, lane);
+    // residual x of token (32 mt + col), channels wcol + 8 g + 4 half + 0..3: straight into the
+    // merge GEMM's accumulators, issued LAST (the loads return in order - nothing waits on these
+    // before the merge GEMM, the state reduction and the apply run under them)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float* xr = p.x + (row_base + min(32 * mt + col, nvalid - 1)) * C + wcol + 4 * half;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 8 * g4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xacc[mt][4 * g4 + i] = v[i];
+      }
+    }
     __syncthreads();
     PHASE_STAMP(p, 1);
 
-    {  // Z[row][h] = 1 / (phi(Q)[row,h,:] . Ksum[h,:] + eps): 64 rows x 8 heads = 512 threads
-      const int r = tid >> 3, h = tid & 7;
-      const f32x4* qrow = reinterpret_cast<const f32x4*>(R2f + r * LDA + h * HD);
-      const f32x4* kk = reinterpret_cast<const f32x4*>(ksum_s + h * HD);
-      float dot = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 a = qrow[i], b = kk[i];
-        dot += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-      }
-      z_s[r * NH + h] = 1.0f / (dot + ATTN_EPS);
-    }
-    __syncthreads();
-
-    // message = (phi(Q) . KV) * Z * S for head = wave -> R1 planes
-    f32x4 kvBh[2], kvBl[2];  // f16-based modes: the reduced state as split B fragments
-    if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) split8(kvB[2 * s2], kvB[2 * s2 + 1], kvBh[s2], kvBl[s2], rg);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if (mt == 1 && !ws.two()) break;  // ragged tile: rows 32.. are never stored
-      float zr[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) zr[r] = z_s[(32 * mt + crow(r, half)) * NH + wave];
-      f32x16 macc = {0};
+    // message^T[v][t] = sum_d KV^T[v][d] phi(Q)^T[d][t], and the normaliser's dot product
+    // phi(Q)[t,:] . Ksum as one more row product of the same B fragments (every accumulator row
+    // of `zacc` is that dot): Z needs no LDS pass of its own.  Lane = token t, registers = v.
+    {
+      f32x4 kvh[2], kvl[2], ksh[2], ksl[2];
+      const float inv_S = 1.0f / (float)S_len;
+      (void)inv_S;
       if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
-        f32x16 c1 = {0};
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const float* qrow = R2f + (32 * mt + col) * LDA + wave * HD + 4 * half + 16 * s2;
-          f32x4 ah, al;
-          split8(*reinterpret_cast<const f32x4*>(qrow), *reinterpret_cast<const f32x4*>(qrow + 8),
-                 ah, al, rg);
-          mma16_split3(ah, al, kvBh[s2], kvBl[s2], macc, c1);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) macc[r] = fmaf(c1[r], SPLIT_INV, macc[r]);
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(R2f + (32 * mt + col) * LDA + wave * HD +
-                                                          4 * half + ks * 8);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            macc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], kvB[ks][j], macc, 0, 0, 0);
+          split8(kvB[2 * s2], kvB[2 * s2 + 1], kvh[s2], kvl[s2], rg);
+          // (Ksum / S - the mean of phi(K), inside the f16 range whenever phi(K) is - in the
+          //  k-slot order of the fragments)
+          const float* kr = ksum_s + wave * HD + 4 * half + 16 * s2;
+          split8(*reinterpret_cast<const f32x4*>(kr) * inv_S, *reinterpret_cast<const f32x4*>(kr + 8) * inv_S,
+                 ksh[s2], ksl[s2], rg);
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) macc[r] = macc[r] * zr[r] * (float)S_len;
-      P1.put_acc(mt, wcol, lane, macc);
+      for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !ws.two()) break;  // ragged tile: rows 32.. are never stored
+        f32x16 macc = {0}, zacc = {0};
+        if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
+          f32x16 c1 = {0}, cz = {0};
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const float* qrow = R2f + (32 * mt + col) * LDA + wave * HD + 4 * half + 16 * s2;
+            f32x4 qh, ql;
+            split8(*reinterpret_cast<const f32x4*>(qrow), *reinterpret_cast<const f32x4*>(qrow + 8), qh, ql, rg);
+            mma16_split3(kvh[s2], kvl[s2], qh, ql, macc, c1);
+            mma16_split3(ksh[s2], ksl[s2], qh, ql, zacc, cz);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) macc[r] = fmaf(c1[r], SPLIT_INV, macc[r]);
+          zacc[0] = fmaf(cz[0], SPLIT_INV, zacc[0]);
+        } else {
+#pragma unroll
+          for (int ks4 = 0; ks4 < 4; ++ks4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(R2f + (32 * mt + col) * LDA + wave * HD + 4 * half + ks4 * 8);
+            const f32x4 kk = *reinterpret_cast<const f32x4*>(ksum_s + wave * HD + 4 * half + ks4 * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              macc = __builtin_amdgcn_mfma_f32_32x32x2f32(kvB[ks4][j], q[j], macc, 0, 0, 0);
+              zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[j], q[j], zacc, 0, 0, 0);
+            }
+          }
+        }
+        const float zdot = gm_f16_range(MODE) && OETR_SPLIT_APPLY ? zacc[0] * (float)S_len : zacc[0];
+        const float zs = (float)S_len / (zdot + ATTN_EPS);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          P1.put4(32 * mt + col, wcol + 8 * g4 + 4 * half,
+                  f32x4{macc[4 * g4] * zs, macc[4 * g4 + 1] * zs, macc[4 * g4 + 2] * zs, macc[4 * g4 + 3] * zs});
+      }
     }
     __syncthreads();
     PHASE_STAMP(p, 2);
 
-    // x1 = x + message . Wmerge^T
-    ws.template gemm<C, P_MERGE, true, C, SP::MERGE, SP::MLP1>(P1, p.b.wmerge, p.b.wmerge_l, wave, 0, lane,
-                                                               xacc, p.b.w1, p.b.w1_l, wave, 0);
-    __syncthreads();  // every wave is done reading the message planes
+    // x1 = x + message . Wmerge^T   (transposed product)
+    ws.template gemm<C, P_MERGE, true, C, SP::MERGE, SP::MLP1, true>(P1, p.b.wmerge, p.b.wmerge_l, wave, 0, lane,
+                                                                     xacc, p.b.w1, p.b.w1_l, wave, 0);
     PHASE_STAMP(p, 3);
+    // LN2(x1) from the registers: per lane the statistics of its 16 channels of a token (mean,
+    // M2), the 16 partials of a token (8 waves x 2 half-waves) combined after ONE exchange
+    // through LDS (Chan's parallel update: as accurate as the two-pass form)
+    {
+      float pm[2], pq[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-      acc_to_lds<1>(R1f + mt * 32 * LDA, LDA, wcol, lane, *reinterpret_cast<f32x16(*)[1]>(&xacc[mt]));
-    __syncthreads();
-    {  // LN2(x1), in place: f32 rows -> registers | barrier | f16 planes
-      f32x4 xn[F4];
-      ln_rows<TPR, F4>(R1f, tid, xn, 0);
-      __syncthreads();
-      const f32x4* gw = reinterpret_cast<const f32x4*>(lnp_s) + lpart;
-      const f32x4* gb = reinterpret_cast<const f32x4*>(lnp_s + C) + lpart;
+      for (int mt = 0; mt < 2; ++mt) {
+        float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < F4; ++i) P1.put4(lrow, 4 * (i * TPR + lpart), xn[i] * gw[i * TPR] + gb[i * TPR]);
+        for (int r = 0; r < 16; ++r) sum += xacc[mt][r];
+        pm[mt] = sum * (1.0f / 16.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = xacc[mt][r] - pm[mt]; q = fmaf(d, d, q); }
+        pq[mt] = q;
+        *reinterpret_cast<f32x2*>(lnx_s + (32 * mt + col) * LNX_LD + 2 * (2 * wave + half)) = f32x2{pm[mt], pq[mt]};
+      }
+      __syncthreads();   // partials visible; every wave is done reading the message planes
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !ws.two()) break;
+        const f32x4* pp = reinterpret_cast<const f32x4*>(lnx_s + (32 * mt + col) * LNX_LD);
+        f32x4 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = pp[i];   // (mean, M2) x 16 partials
+        float msum = 0.f, qsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { msum += t[i][0] + t[i][2]; qsum += t[i][1] + t[i][3]; }
+        const float mean = msum * (1.0f / 16.0f);
+        float dev = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d0 = t[i][0] - mean, d1 = t[i][2] - mean;
+          dev = fmaf(d0, d0, dev);
+          dev = fmaf(d1, d1, dev);
+        }
+        const float rstd = 1.0f / sqrtf((qsum + 16.0f * dev) * (1.0f / C) + LN_EPS);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int c0 = wcol + 8 * g4 + 4 * half;
+          const f32x4 gw = *reinterpret_cast<const f32x4*>(lnp_s + c0), gb = *reinterpret_cast<const f32x4*>(lnp_s + C + c0);
+          f32x4 y;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = (xacc[mt][4 * g4 + i] - mean) * rstd * gw[i] + gb[i];
+          P1.put4(32 * mt + col, c0, y);
+        }
+      }
     }
     __syncthreads();
 
@@ -1023,6 +1071,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // (R1 = the LN2 planes, free once every wave has finished MLP1b: the first barrier)
     {
       constexpr int SNEXT = TAIL == 0 ? SP::Q : SP::DEC_K;   // first GEMM of the tail
+      constexpr bool XTR = true;                            // residual stream in the transposed layout
       f32x16 haccA[2] = {f32x16{0}, f32x16{0}}, haccB[2] = {f32x16{0}, f32x16{0}};
 #if OETR_MLP1_TR
       // MLP1 runs TRANSPOSED (WStream2T: TR): a lane then holds, per register quad, FOUR
@@ -1074,38 +1123,34 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       __syncthreads();   // hidden half a complete; every wave is done reading the LN2 planes
       PHASE_STAMP(p, 5);
       auto epiB = gelu_to(P1, haccB);
-      ws.template gemm_epi<FF, P_2A, true, FF, SP::MLP2, SP::MLP2>(P2, p.b.w2, p.b.w2_l, wave, 0, lane, xacc,
-                                                                   p.b.w2, p.b.w2_l, wave, 16, epiB);
+      ws.template gemm_epi<FF, P_2A, true, FF, SP::MLP2, SP::MLP2, XTR>(P2, p.b.w2, p.b.w2_l, wave, 0, lane, xacc,
+                                                                        p.b.w2, p.b.w2_l, wave, 16, epiB);
       __syncthreads();   // hidden half b complete
       PHASE_STAMP(p, 6);
       PHASE_STAMP(p, 7);
-      ws.template gemm<FF, P_2B, (TAIL != 2), C, SP::MLP2, SNEXT>(P1, p.b.w2, p.b.w2_l, wave, 16, lane, xacc,
-                                                                  TAIL == 0 ? p.a.wq : p.d.wk[0],
-                                                                  TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], wave, 0);
+      ws.template gemm<FF, P_2B, (TAIL != 2), C, SP::MLP2, SNEXT, XTR>(P1, p.b.w2, p.b.w2_l, wave, 16, lane, xacc,
+                                                                       TAIL == 0 ? p.a.wq : p.d.wk[0],
+                                                                       TAIL == 0 ? p.a.wq_l : p.d.wk_l[0], wave, 0);
     }
-    {
-      // (pointer laundered: otherwise the 32 store addresses are CSE'd with the residual
-      //  loads' at the top of the kernel and live - spilled - across every GEMM)
-      int l2 = lane;
-      asm volatile("" : "+v"(l2));
-      float* xs = p.x + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
-      const int nv2 = nvalid - 4 * (l2 >> 5);
+    // x1 tile -> the f32 staging region (one 16-byte LDS store per register quad), then HBM in
+    // full 1-KB rows.  (The region's planes were last read by a GEMM every wave finished before
+    // a barrier above: R2 by MLP2a; R1 holds the second hidden half, which MLP2b reads.)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * mt + crow(r, 0);   // compile-time constant
-          if (row < nv2) xs[row * C] = xacc[mt][r];
-        }
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<f32x4*>(Xf + (32 * mt + col) * LDA + wcol + 8 * g4 + 4 * half) =
+            f32x4{xacc[mt][4 * g4], xacc[mt][4 * g4 + 1], xacc[mt][4 * g4 + 2], xacc[mt][4 * g4 + 3]};
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {
+      const int idx = tid + THREADS * i;
+      const int r = idx >> 6, c4 = idx & 63;
+      if (r < nvalid)
+        reinterpret_cast<f32x4*>(p.x + (row_base + r) * C)[c4] = *reinterpret_cast<const f32x4*>(Xf + r * LDA + 4 * c4);
     }
     PHASE_STAMP(p, 8);
     if (TAIL == 2) { range_report<MODE>(rg, p.flags); return; }
-    // (the staging region's planes were last read by a GEMM every wave finished before a barrier
-    //  above: R2 by MLP2a; R1 holds the second hidden half, which MLP2b reads)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-      acc_to_lds<1>(Xf + mt * 32 * LDA, LDA, wcol, lane, *reinterpret_cast<f32x16(*)[1]>(&xacc[mt]));
-    __syncthreads();
   } else {
     if (nchw) {  // first launch, reference layout: transpose on the way in (R2 is free until phase A writes P2)
       load_tile_nchw<THREADS, RT>(R1f, p.feat_nchw[side] + (size_t)n * C * L + l0, L, nvalid, tid);
