@@ -240,7 +240,7 @@ __device__ __forceinline__ float erf_f32(float x) {
 // Exact-erf GELU (torch nn.GELU default): 0.5 v (1 + erf(v / sqrt 2)).
 //
 // GELU needs erf only to ABSOLUTE accuracy (it is added to 1), so one formula serves
-// every v:  gelu(v) = max(v, 0) - 0.5 |v| erfc(|v| / sqrt 2),  erfc = 2^(w Q(w)),
+// every v:  gelu(v) = max(v, 0) - |v| (0.5 erfc(|v| / sqrt 2)),  0.5 erfc = 2^(w Q(w) - 1),
 // w = min(|v|, 5.5), Q = degree-9 fit of log2(erfc(w / sqrt 2)) / w on [0, 5.5]
 // (tools/fit_erf.py: max abs error 2.4e-7 over |v| <= 12, 1.2e-7 for |v| < 2, every
 // operation rounded to fp32 - tighter than the two-branch erf_f32 form it replaces,
@@ -263,8 +263,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
   float q = GELU_Q[9];
 #pragma unroll
   for (int i = 8; i >= 0; --i) q = fmaf(q, w, GELU_Q[i]);
-  const float e = __builtin_amdgcn_exp2f(w * q);
-  return fmaf(-0.5f * ax, e, fmaxf(x, 0.f));
+  const float e = __builtin_amdgcn_exp2f(fmaf(w, q, -1.0f));   // 0.5 erfc: the 0.5 rides in the exponent
+  return fmaf(-ax, e, fmaxf(x, 0.f));                            // (-|x| is a source modifier, not an instruction)
 #endif
 }
 
@@ -312,11 +312,11 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
   f32x2 q = splat2(GELU_Q[9]);
 #pragma unroll
   for (int i = 8; i >= 0; --i) q = __builtin_elementwise_fma(q, w, splat2(GELU_Q[i]));
-  const f32x2 u = w * q;
+  const f32x2 u = __builtin_elementwise_fma(w, q, splat2(-1.0f));
   f32x2 g;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
-    g[i] = fmaf(-0.5f * ax[i], __builtin_amdgcn_exp2f(u[i]), fmaxf(v[i], 0.f));
+    g[i] = fmaf(-fabsf(v[i]), __builtin_amdgcn_exp2f(u[i]), fmaxf(v[i], 0.f));
   return g;
 #endif
 }
@@ -339,12 +339,13 @@ __device__ __forceinline__ f32x4 gelu_erf4(const f32x4& v) {
     q0 = __builtin_elementwise_fma(q0, w0, splat2(GELU_Q[i]));
     q1 = __builtin_elementwise_fma(q1, w1, splat2(GELU_Q[i]));
   }
-  const f32x2 u0 = w0 * q0, u1 = w1 * q1;
+  const f32x2 u0 = __builtin_elementwise_fma(w0, q0, splat2(-1.0f));
+  const f32x2 u1 = __builtin_elementwise_fma(w1, q1, splat2(-1.0f));
   f32x4 g;
-  g[0] = fmaf(-0.5f * a0[0], __builtin_amdgcn_exp2f(u0[0]), fmaxf(v[0], 0.f));
-  g[2] = fmaf(-0.5f * a1[0], __builtin_amdgcn_exp2f(u1[0]), fmaxf(v[2], 0.f));
-  g[1] = fmaf(-0.5f * a0[1], __builtin_amdgcn_exp2f(u0[1]), fmaxf(v[1], 0.f));
-  g[3] = fmaf(-0.5f * a1[1], __builtin_amdgcn_exp2f(u1[1]), fmaxf(v[3], 0.f));
+  g[0] = fmaf(-fabsf(v[0]), __builtin_amdgcn_exp2f(u0[0]), fmaxf(v[0], 0.f));
+  g[2] = fmaf(-fabsf(v[2]), __builtin_amdgcn_exp2f(u1[0]), fmaxf(v[2], 0.f));
+  g[1] = fmaf(-fabsf(v[1]), __builtin_amdgcn_exp2f(u0[1]), fmaxf(v[1], 0.f));
+  g[3] = fmaf(-fabsf(v[3]), __builtin_amdgcn_exp2f(u1[1]), fmaxf(v[3], 0.f));
   return g;
 #endif
 }
@@ -437,10 +438,13 @@ __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
   // tests: fp32-class vs fp64), formed as a * 2^11 - hi * 2^11: both products and their
   // difference are exact (a - hi is representable), and the f16 operand goes straight into
   // v_fma_mix_f32 - 6 VALU per pair instead of 8 (no v_cvt_f32_f16).
-  hi = __builtin_convertvector(f32x2{a, b}, f16x2);
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f ab = v2f{a, b};
+  hi = __builtin_convertvector(ab, f16x2);
+  const v2f sc = ab * v2f{SPLIT_SCALE, SPLIT_SCALE};   // (one v_pk_mul_f32)
   lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(
-                                     __builtin_fmaf((float)hi[0], -SPLIT_SCALE, a * SPLIT_SCALE),
-                                     __builtin_fmaf((float)hi[1], -SPLIT_SCALE, b * SPLIT_SCALE)));
+                                     __builtin_fmaf((float)hi[0], -SPLIT_SCALE, sc[0]),
+                                     __builtin_fmaf((float)hi[1], -SPLIT_SCALE, sc[1])));
 }
 // Range guard of the f16-based modes (GM_SPLIT, GM_F16): every activation that is converted
 // into a GEMM operand leaves its f16 bit pattern in a running maximum (Range, two VALU per
