@@ -241,18 +241,19 @@ __device__ __forceinline__ float erf_f32(float x) {
 //
 // GELU needs erf only to ABSOLUTE accuracy (it is added to 1), so one formula serves
 // every v:  gelu(v) = max(v, 0) - |v| (0.5 erfc(|v| / sqrt 2)),  0.5 erfc = 2^(w Q(w) - 1),
-// w = min(|v|, 5.5), Q = degree-9 fit of log2(erfc(w / sqrt 2)) / w on [0, 5.5]
-// (tools/fit_erf.py: max abs error 2.4e-7 over |v| <= 12, 1.2e-7 for |v| < 2, every
-// operation rounded to fp32 - tighter than the two-branch erf_f32 form it replaces,
-// 6.8e-7, at half the instructions: no small-|x| branch, no select, no copysign).
+// w = min(|v|, 5.5), Q = degree-5 polynomial for log2(erfc(w / sqrt 2)) / w on [0, 5.5], fitted
+// minimax on the GELU error itself (weight 0.5 w^2 erfc ln2 = d gelu / d Q: the exponent needs
+// accuracy only where |v| erfc is not small) - tools/fit_erf.py: max abs error 3.1e-7 over
+// |v| <= 12 (half an ulp of the result at |v| ~ 4 is 2.4e-7), 1.6e-7 for |v| < 2, every operation
+// rounded to fp32.  Round 2's uniform degree-9 fit of Q measured 2.4e-7 / 1.2e-7 with four more
+// FMAs per value; the two-branch erf_f32 form before it 6.8e-7.
 #ifndef OETR_GELU_TWO_BRANCH
 #define OETR_GELU_TWO_BRANCH 0
 #endif
 constexpr float GELU_T = 5.5f;
-constexpr float GELU_Q[10] = {-1.151104268e+00f, -4.592180034e-01f, -5.245695910e-02f,
-                              6.978375917e-03f,  -3.027199248e-05f, -2.638561890e-04f,
-                              7.173310719e-05f,  -1.016200793e-05f, 7.862152819e-07f,
-                              -2.615616390e-08f};
+constexpr int GELU_DEG = 5;
+constexpr float GELU_Q[GELU_DEG + 1] = {-1.151147082e+00f, -4.589156863e-01f, -5.323818670e-02f,
+                                        7.977462822e-03f,  -7.398742635e-04f, 2.992419385e-05f};
 __device__ __forceinline__ float gelu_erf(float x) {
 #ifdef OETR_OCML_ERF
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -260,9 +261,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_f32(x * 0.70710678118654752440f));
 #else
   const float ax = fabsf(x), w = fminf(ax, GELU_T);
-  float q = GELU_Q[9];
+  float q = GELU_Q[GELU_DEG];
 #pragma unroll
-  for (int i = 8; i >= 0; --i) q = fmaf(q, w, GELU_Q[i]);
+  for (int i = GELU_DEG - 1; i >= 0; --i) q = fmaf(q, w, GELU_Q[i]);
   const float e = __builtin_amdgcn_exp2f(fmaf(w, q, -1.0f));   // 0.5 erfc: the 0.5 rides in the exponent
   return fmaf(-ax, e, fmaxf(x, 0.f));                            // (-|x| is a source modifier, not an instruction)
 #endif
@@ -309,9 +310,9 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
 #else
   const f32x2 ax = __builtin_elementwise_abs(v);
   const f32x2 w = f32x2{fminf(ax[0], GELU_T), fminf(ax[1], GELU_T)};
-  f32x2 q = splat2(GELU_Q[9]);
+  f32x2 q = splat2(GELU_Q[GELU_DEG]);
 #pragma unroll
-  for (int i = 8; i >= 0; --i) q = __builtin_elementwise_fma(q, w, splat2(GELU_Q[i]));
+  for (int i = GELU_DEG - 1; i >= 0; --i) q = __builtin_elementwise_fma(q, w, splat2(GELU_Q[i]));
   const f32x2 u = __builtin_elementwise_fma(w, q, splat2(-1.0f));
   f32x2 g;
 #pragma unroll
@@ -333,9 +334,9 @@ __device__ __forceinline__ f32x4 gelu_erf4(const f32x4& v) {
   const f32x2 a0 = __builtin_elementwise_abs(v0), a1 = __builtin_elementwise_abs(v1);
   const f32x2 w0 = f32x2{fminf(a0[0], GELU_T), fminf(a0[1], GELU_T)};
   const f32x2 w1 = f32x2{fminf(a1[0], GELU_T), fminf(a1[1], GELU_T)};
-  f32x2 q0 = splat2(GELU_Q[9]), q1 = splat2(GELU_Q[9]);
+  f32x2 q0 = splat2(GELU_Q[GELU_DEG]), q1 = splat2(GELU_Q[GELU_DEG]);
 #pragma unroll
-  for (int i = 8; i >= 0; --i) {
+  for (int i = GELU_DEG - 1; i >= 0; --i) {
     q0 = __builtin_elementwise_fma(q0, w0, splat2(GELU_Q[i]));
     q1 = __builtin_elementwise_fma(q1, w1, splat2(GELU_Q[i]));
   }

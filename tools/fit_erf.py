@@ -83,8 +83,9 @@ print('R =', ', '.join('%.9ef' % c for c in R))
 # ---------------------------------------------------------------------------
 # Single-formula GELU (csrc/common.h: gelu_erf, round 2).  GELU adds erf to 1, so only
 # ABSOLUTE erf accuracy matters and the small-|x| branch above is unnecessary:
-#   gelu(v) = max(v, 0) - 0.5 |v| erfc(|v| / sqrt 2),   erfc(w / sqrt 2) = 2^(w Q(w)),
-#   w = min(|v|, T),  Q = degree-9 fit of log2(erfc(w / sqrt 2)) / w on [0, T], T = 5.5
+#   gelu(v) = max(v, 0) - |v| 2^(w Q(w) - 1),   erfc(w / sqrt 2) = 2^(w Q(w)),
+#   w = min(|v|, T),  Q ~ log2(erfc(w / sqrt 2)) / w on [0, T], T = 5.5
+# Round 3: degree 5, minimax on the GELU error (round 2: degree 9, uniform in Q).
 T = 5.5
 S2 = np.sqrt(2.0)
 
@@ -95,13 +96,37 @@ def qfun(w):
     return np.where(w < 1e-9, -2 / np.sqrt(np.pi) / np.log(2) / S2, r)
 
 
-Q = fit(qfun, 0.0, T, 9, n=6000)
-v = np.concatenate([np.linspace(-12, 12, 4000001), np.linspace(-1e-2, 1e-2, 200001)]).astype(f32)
-w = np.minimum(np.abs(v), f32(T)).astype(f32)
-e = np.exp2((w * horner32(Q, w)).astype(f32)).astype(f32)
-g = (np.maximum(v, f32(0)) - (f32(0.5) * np.abs(v) * e).astype(f32)).astype(f32)
-g_ref = 0.5 * v.astype(np.float64) * (1 + special.erf(v.astype(np.float64) / S2))
-err = np.abs(g.astype(np.float64) - g_ref)
-print('single-formula gelu: max abs err %.3e at v=%.3f; |v|<2: %.3e' % (err.max(), v[err.argmax()],
-                                                                      err[np.abs(v) < 2].max()))
+def fit_gelu_weighted(deg, iters=200, n=8000):
+    """Minimax fit of Q on [0, T] with the weight d gelu / d Q = 0.5 w^2 erfc(w/sqrt 2) ln 2
+    (Lawson's iteratively reweighted least squares): the error that matters is the GELU's."""
+    x = np.cos(np.pi * (np.arange(n) + 0.5) / n) * T / 2 + T / 2
+    y = qfun(x)
+    wgt = 0.5 * x * x * special.erfc(x / S2) * np.log(2) + 1e-13
+    A = np.vander(x / T, deg + 1, increasing=True)
+    lw = np.ones_like(x)
+    for _ in range(iters):
+        sw = np.sqrt(lw) * wgt
+        c, *_ = np.linalg.lstsq(A * sw[:, None], y * sw, rcond=None)
+        r = np.abs((A @ c - y) * wgt)
+        lw = lw * (r + 1e-30)
+        lw /= lw.sum()
+    return c / (T ** np.arange(deg + 1))
+
+
+def gelu_err(Q):
+    v = np.concatenate([np.linspace(-12, 12, 4000001), np.linspace(-1e-2, 1e-2, 200001)]).astype(f32)
+    w = np.minimum(np.abs(v), f32(T)).astype(f32)
+    e = np.exp2((w * horner32(Q, w) - f32(1)).astype(f32)).astype(f32)        # 0.5 erfc
+    g = (np.maximum(v, f32(0)) - (np.abs(v) * e).astype(f32)).astype(f32)
+    g_ref = 0.5 * v.astype(np.float64) * (1 + special.erf(v.astype(np.float64) / S2))
+    err = np.abs(g.astype(np.float64) - g_ref)
+    return err.max(), v[err.argmax()], err[np.abs(v) < 2].max()
+
+
+Q9 = fit(qfun, 0.0, T, 9, n=6000)                      # round 2: uniform fit of Q, degree 9
+print('uniform degree-9 Q:   gelu max abs err %.3e at v=%.3f; |v|<2: %.3e' % gelu_err(Q9))
+for deg in (4, 5, 6):
+    Qd = fit_gelu_weighted(deg)
+    print('weighted degree-%d Q: gelu max abs err %.3e at v=%.3f; |v|<2: %.3e' % ((deg,) + gelu_err(Qd)))
+Q = fit_gelu_weighted(5)                               # csrc/common.h: GELU_Q
 print('Q =', ', '.join('%.9ef' % c for c in Q))
