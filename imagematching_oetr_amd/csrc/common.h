@@ -974,6 +974,11 @@ struct WStream2T {
   struct AStep { f32x4 ah[2], al[2]; };
   BStep ring[D];
   bool two_rt = true;
+  // lane as the LAST, 32-bit index of every fragment address: the slab pointers stay uniform
+  // (the wave index is a scalar), so the loads take an SGPR base + lane offset + immediate and
+  // the per-step address arithmetic is SALU work
+  unsigned ln = 0;
+  __device__ __forceinline__ void set_lane(int lane) { ln = (unsigned)lane; }
   __device__ __forceinline__ bool two() const { return ROWS == 2 || (ROWS == 0 && two_rt); }
   __device__ __forceinline__ void set_rows(int nvalid) {
     if constexpr (ROWS == 0) two_rt = __builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0) != 0;
@@ -982,8 +987,8 @@ struct WStream2T {
 
   template <int SLOT, int SITE>
   __device__ __forceinline__ void fetch(const f32x4* wh, const f32x4* wl, int step) {
-    ring[SLOT].bh = wh[step * 64];
-    if constexpr (TWO && site_w_lo(SITE)) ring[SLOT].bl = wl[step * 64];
+    ring[SLOT].bh = wh[step * 64 + ln];
+    if constexpr (TWO && site_w_lo(SITE)) ring[SLOT].bl = wl[step * 64 + ln];
   }
   template <int P, int J, int SITE>
   __device__ __forceinline__ void fetch_first(const f32x4* wh, const f32x4* wl) {
@@ -996,7 +1001,8 @@ struct WStream2T {
   // packed with KTOT/16 steps per n-tile.
   template <int KTOT, int P, int SITE = SITE_FULL>
   __device__ __forceinline__ void prime(const f32x4* W, const f32x4* Wl, int nt0, int ks0, int lane) {
-    const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64 + lane;
+    const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64;
+    (void)lane;
     fetch_first<P, 0, SITE>(W + off, Wl + off);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1071,8 +1077,8 @@ struct WStream2T {
   __device__ __forceinline__ void gemm_epi(const PlanesT<M>& A, const f32x4* W, const f32x4* Wl, int nt0,
                                            int ks0, int lane, f32x16 (&acc)[2], const f32x4* nW,
                                            const f32x4* nWl, int nnt0, int nks0, EPI& epi) {
-    const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64 + lane;
-    const size_t noff = ((size_t)nnt0 * (NKTOT / 16) + nks0) * 64 + lane;
+    const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64;
+    const size_t noff = ((size_t)nnt0 * (NKTOT / 16) + nks0) * 64;
     const int a_off = (lane & 31) * LDAH + 8 * (lane >> 5);
     const _Float16* ah_ptr = A.h + a_off;
     const _Float16* al_ptr = A.l + a_off;

@@ -73,7 +73,8 @@ __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __rest
   static_assert(16 % WStream2T<MODE>::D == 0, "tap loop below assumes a ring phase of 0 after every GEMM");
   constexpr int THREADS = 512, TPR = THREADS / RT, F4 = 64 / TPR;
   const Geom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
   const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
   const int tile = item / CONVP_SPLIT, tap0 = (item - tile * CONVP_SPLIT) * CONVP_TAPS;
   const int logical = xcd_remap(tile, g.N * (nt0 + nt1));
@@ -98,6 +99,7 @@ __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __rest
   }
   WStream2T<MODE> ws;
   ws.set_rows(nvalid);
+  ws.set_lane(lane);
   constexpr size_t TAP_UNITS = (size_t)C * C / 8;
   ws.template prime<C, 0>(p.w.conv_w + tap0 * TAP_UNITS, p.w.conv_w_l + tap0 * TAP_UNITS, wave, 0, lane);
   __syncthreads();

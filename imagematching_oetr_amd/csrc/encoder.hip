@@ -851,7 +851,10 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   constexpr int P_T1 = WS::adv(P_T0), P_T2 = WS::adv(P_T1), P_T3 = WS::adv(P_T2);
 
   const Geom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  // (the wave index as a SCALAR: everything derived from it - weight slab pointers, row indices
+  //  of the row-per-wave copies - is then SALU work and the loads use SGPR bases)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
   const int wcol = 32 * wave;
   const int lrow = tid / TPR, lpart = tid % TPR;
 
@@ -868,6 +871,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
   const bool nchw = !HAS_B && p.feat_nchw[0] != nullptr;   // first launch on NCHW inputs (launch-uniform)
   ws.set_rows(nvalid);
+  ws.set_lane(lane);
 
   for (int i = tid; i < 6 * C; i += THREADS) {
     const int which = i >> 8, c = i & (C - 1);
