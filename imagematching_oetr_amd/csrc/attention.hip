@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_full_attention(const float* __restrict_
                                                         const float* __restrict__ k,
                                                         const float* __restrict__ v, int n_img,
                                                         int L, int S, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5;
   const int col = lane & 31;
   const int qtiles = (L + 31) / 32;
   const long wid = (long)blockIdx.x * 4 + wave;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_full_attention_split(const float* __res
                                                               uint32_t* flags) {
   __shared__ __attribute__((aligned(16))) _Float16 Kh[32 * FA_PITCH], Kl[32 * FA_PITCH];
   __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * FA_PITCH], Vl[32 * FA_PITCH];  // [d][slot]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, col = lane & 31;
   const int qchunks = (L + 127) / 128;
   const int qc = blockIdx.x % qchunks, nh = blockIdx.x / qchunks, n = nh / NH, h = nh % NH;
   const int q0 = qc * 128 + wave * 32;

@@ -377,11 +377,11 @@ struct GemmRegs {
 
 template <int NT, int U>
 __device__ __forceinline__ void gemm_fetch(GemmRegs<NT, U>& r, const float* a_ptr,
-                                           const f32x4* const (&w_ptr)[NT], int chunk) {
+                                           const f32x4* const (&w_ptr)[NT], int chunk, unsigned ln) {
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) r.b[u][t] = w_ptr[t][(chunk * U + u) * 64];
+    for (int t = 0; t < NT; ++t) r.b[u][t] = w_ptr[t][(chunk * U + u) * 64 + ln];
 #pragma unroll
   for (int u = 0; u < U; ++u)
     r.a[u] = *reinterpret_cast<const f32x4*>(a_ptr + (chunk * U + u) * 8);
@@ -414,16 +414,16 @@ __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda
   const float* a_ptr = A + (lane & 31) * lda + 4 * (lane >> 5);
   const f32x4* w_ptr[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) w_ptr[t] = Wp + (size_t)(nt0 + t) * KS * 64 + lane;
+  for (int t = 0; t < NT; ++t) w_ptr[t] = Wp + (size_t)(nt0 + t) * KS * 64;   // (uniform when nt0 is: lane comes last)
 
   GemmRegs<NT, U> r0, r1;
-  gemm_fetch<NT, U>(r0, a_ptr, w_ptr, 0);
+  gemm_fetch<NT, U>(r0, a_ptr, w_ptr, 0, (unsigned)lane);
   for (int c = 0; c < NCH; c += 2) {
-    gemm_fetch<NT, U>(r1, a_ptr, w_ptr, c + 1);
+    gemm_fetch<NT, U>(r1, a_ptr, w_ptr, c + 1, (unsigned)lane);
     __builtin_amdgcn_sched_barrier(0);
     gemm_mma<NT, U>(r0, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if (c + 2 < NCH) gemm_fetch<NT, U>(r0, a_ptr, w_ptr, c + 2);
+    if (c + 2 < NCH) gemm_fetch<NT, U>(r0, a_ptr, w_ptr, c + 2, (unsigned)lane);
     __builtin_amdgcn_sched_barrier(0);
     gemm_mma<NT, U>(r1, acc);
     __builtin_amdgcn_sched_barrier(0);
@@ -582,8 +582,8 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
   const f32x4* wl_ptr[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    wh_ptr[t] = Whi + (size_t)(nt0 + t) * KS * 64 + lane;
-    wl_ptr[t] = Wlo + (size_t)(nt0 + t) * KS * 64 + lane;
+    wh_ptr[t] = Whi + (size_t)(nt0 + t) * KS * 64;   // (uniform when nt0 is: lane comes last)
+    wl_ptr[t] = Wlo + (size_t)(nt0 + t) * KS * 64;
   }
   // two cross accumulators per tile: three independent MFMA chains per k-step
   // (a single one makes every other MFMA wait on its predecessor's result)
@@ -593,13 +593,14 @@ __device__ __forceinline__ void gemm_rows32_h(const _Float16* __restrict__ Ahi,
     for (int t = 0; t < NT; ++t) { cross[t] = f32x16{0}; cross2[t] = f32x16{0}; }
   }
 
+  const unsigned ln = (unsigned)lane;
   auto fetch = [&](GemmRegsH<M, NT, U>& r, int chunk) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        r.bh[u][t] = wh_ptr[t][(chunk * U + u) * 64];
-        if constexpr (TWO) r.bl[u][t] = wl_ptr[t][(chunk * U + u) * 64];
+        r.bh[u][t] = wh_ptr[t][(chunk * U + u) * 64 + ln];
+        if constexpr (TWO) r.bl[u][t] = wl_ptr[t][(chunk * U + u) * 64 + ln];
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -805,6 +806,7 @@ __device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4]
 template <int M, int NT, bool STREAMED = (gm_half(M) && NT == 1)>
 struct WStream {
   static constexpr int adv(int, int) { return 0; }
+  __device__ __forceinline__ void set_lane(int) {}
   template <int K, int P, int SITE = SITE_FULL>
   __device__ __forceinline__ void prime(const f32x4*, const f32x4*, int, int) {}
   template <int K, int P, int NK, int SITE = SITE_FULL, int NSITE = SITE_FULL, class AT>
@@ -825,6 +827,10 @@ struct WStream<M, 1, true> {
   struct AChunk { f32x4 ah[U], al[TWO ? U : 1]; };
   BChunk ring[D];
   int dbg = 0;  // ablation flags (OETR_ABLATE builds only)
+  // lane as the LAST, 32-bit index of every fragment address (see WStream2T::ln): with a scalar
+  // wave index the slab pointers are uniform and the loads take SGPR base + lane offset
+  unsigned ln = 0;
+  __device__ __forceinline__ void set_lane(int lane) { ln = (unsigned)lane; }
 
   static constexpr int adv(int P, int K) { return (P + K / 16 / U) % D; }
 
@@ -833,8 +839,8 @@ struct WStream<M, 1, true> {
     if (ABL(dbg, ABL_WLOAD)) return;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      ring[SLOT].bh[u] = wh[(chunk * U + u) * 64];
-      if constexpr (TWO && site_w_lo(SITE)) ring[SLOT].bl[u] = wl[(chunk * U + u) * 64];
+      ring[SLOT].bh[u] = wh[(chunk * U + u) * 64 + ln];
+      if constexpr (TWO && site_w_lo(SITE)) ring[SLOT].bl[u] = wl[(chunk * U + u) * 64 + ln];
     }
   }
   template <int P, int J, int SITE>
@@ -848,7 +854,8 @@ struct WStream<M, 1, true> {
   // arithmetic: a site that does not use the weights' lo plane does not fetch it).
   template <int K, int P, int SITE = SITE_FULL>
   __device__ __forceinline__ void prime(const f32x4* W, const f32x4* Wl, int nt0, int lane) {
-    const size_t off = (size_t)nt0 * (K / 16) * 64 + lane;
+    const size_t off = (size_t)nt0 * (K / 16) * 64;
+    (void)lane;
     fetch_first<P, 0, SITE>(W + off, Wl + off);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -894,8 +901,8 @@ struct WStream<M, 1, true> {
                                        const f32x4* nWl, int nnt0, int) {
     if (ABL(dbg, ABL_GEMM)) return;
     static_assert(PRE * U * 16 <= K && (NK == 0 || PRE * U * 16 <= NK), "ring deeper than a GEMM");
-    const size_t off = (size_t)nt0 * (K / 16) * 64 + lane;
-    const size_t noff = (size_t)nnt0 * ((NK ? NK : 16) / 16) * 64 + lane;
+    const size_t off = (size_t)nt0 * (K / 16) * 64;
+    const size_t noff = (size_t)nnt0 * ((NK ? NK : 16) / 16) * 64;
     const int a_off = (lane & 31) * A.ldh + 8 * (lane >> 5);
     const _Float16* ah_ptr = A.h + a_off;
     const _Float16* al_ptr = A.l + a_off;

@@ -13,7 +13,7 @@ __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restri
   constexpr int NW = 8, NT = 1, THREADS = 64 * NW, WC = 32 * NT;
   constexpr int TPR = THREADS / TM, F4 = 64 / TPR;
   const Geom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
   const int col = lane & 31;
   const int logical = xcd_remap(tile, g.ntiles);
   const int per = g.nt[0] + g.nt[1];

@@ -325,9 +325,10 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   constexpr int P_T3 = WS::adv(P_T2, C);
 
   const Geom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  const int col = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar)
+  const int half = lane >> 5, col = lane & 31;
   const int wcol = WC * wave;               // first of this wave's output columns
+  ws.set_lane(lane);
   const int lrow = tid / TPR, lpart = tid % TPR;  // (row, float4 slot) in row-wise phases
 
   // ---- tile identity (pair-major logical order: n, side, tile) ----

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
   constexpr int TPR = THREADS / TM, F4 = 64 / TPR;  // threads / float4s per row when staging
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
   const Geom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
   const int col = lane & 31;
 
   const int logical = xcd_remap(blockIdx.x, g.ntiles);
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
   __shared__ float gmean_s[GN_GROUPS], grstd_s[GN_GROUPS];
   __shared__ float red_s[FIN_THREADS / 64];
   const Geom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int img = blockIdx.x;
   const int side = img >= g.N, n = side ? img - g.N : img;
   const int L = g.L[side], wf = g.wf[side], nts = g.nt[side];
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_size_reg(HeadsDev w, const float* __res
   for (int k = 0; k < C; ++k) a += w.tlbr0_t[k * C + tid] * h_s[k];
   hid_s[tid] = fmaxf(a, 0.f);
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;  // wave j -> output j
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave j -> output j
   const f32x4 wv = reinterpret_cast<const f32x4*>(w.tlbr2_w + wave * C)[lane];
   const f32x4 hv = reinterpret_cast<const f32x4*>(hid_s)[lane];
   float d = wave_sum((wv[0] * hv[0] + wv[1] * hv[1]) + (wv[2] * hv[2] + wv[3] * hv[3]));

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512) void k_neck_proj(NeckProjLaunch p) {
   float* S0 = smem + NP_S0_OFF;
   float* par = smem + NP_PAR_OFF;
   const NeckGeom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31;
   const int tpi = (g.HW + TM - 1) / TM;
   const int img = blockIdx.x / tpi, p0 = (blockIdx.x - img * tpi) * TM;
   const int nvalid = min(TM, g.HW - p0);
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512) void k_neck_proj(NeckProjLaunch p) {
   }
   using WS = WStream<GM_SPLIT, 1>;
   WS ws;
+  ws.set_lane(lane);
   constexpr int P0 = 0, P1 = WS::adv(P0, 512);
   const float* src = p.bb + (size_t)img * BBC * g.HW + p0 + min(tid & 31, nvalid - 1);
   proj_stage(A, src, g.HW, tid);
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   __shared__ int2 rowinfo[MT];
   const NeckGeom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar)
+  const int half = lane >> 5, col = lane & 31;
+  const unsigned ln = lane;   // last, 32-bit index of the weight-fragment addresses (SGPR base + lane offset)
   const int nt = wave & 3, rh = wave >> 2;  // this wave: n-tile nt, rows [HALF_ROWS*rh, +HALF_ROWS)
 
   // ---- which output tile / conv / K slice ----
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   const int rem = it - cd.item0;
   const int split = rem / cd.nhalf, nh = rem - split * cd.nhalf;
   const int ksmask = (1 << cd.log2ks) - 1;
-  const size_t wbase = ((size_t)(split * cd.nhalf + nh) * 4 + nt) * (NC_STAGES * 4) * 64 + lane;
+  const size_t wbase = ((size_t)(split * cd.nhalf + nh) * 4 + nt) * (NC_STAGES * 4) * 64;
   const f32x4* wh = cd.wh + wbase;
   const f32x4* wl = cd.wl + wbase;
 
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
   for (int t = 0; t < RTW; ++t) { acc[t] = f32x16{0}; cross[t] = f32x16{0}; }
   ConvB bf[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) { bf[kk].h = wh[kk * 64]; bf[kk].l = wl[kk * 64]; }
+  for (int kk = 0; kk < 4; ++kk) { bf[kk].h = wh[kk * 64 + ln]; bf[kk].l = wl[kk * 64 + ln]; }
 
   stage_load(0, 0); stage_write(0, 0);
   stage_load(0, 1); stage_write(0, 1);
@@ -297,8 +300,8 @@ __global__ __launch_bounds__(512) void k_neck_conv(NeckConvLaunch p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       if (more && !(NECK_ABL & 2)) {  // the same k16 step of the next stage into the slot just consumed
-        bf[kk].h = wh[((s + 1) * 4 + kk) * 64];
-        bf[kk].l = wl[((s + 1) * 4 + kk) * 64];
+        bf[kk].h = wh[((s + 1) * 4 + kk) * 64 + ln];
+        bf[kk].l = wl[((s + 1) * 4 + kk) * 64 + ln];
       }
       __builtin_amdgcn_sched_barrier(0);
       if (kk == 1 && more) {
@@ -365,7 +368,9 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   __shared__ int2 ent[SH::NE_MAX];
   const NeckGeom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar)
+  const int half = lane >> 5, col = lane & 31;
+  const unsigned ln = lane;   // last, 32-bit index of the weight-fragment addresses (SGPR base + lane offset)
   const int nt = wave & 3, rh = wave >> 2;
 
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
   const int nky = NECK_PIX >> cd.log2ks;       // kernel rows in a 16-pixel slice: 4 / 2 / 1
   const int groups = taps >> 1;                // 4-step groups per stage: 1 / 2 / 4
   const int nstg = nky * 16;                   // stages: (ky in slice, x parity, 32-channel chunk)
-  const size_t wbase = ((size_t)(split * cd.nhalf + nh) * 4 + nt) * (NC_STAGES * 4) * 64 + lane;
+  const size_t wbase = ((size_t)(split * cd.nhalf + nh) * 4 + nt) * (NC_STAGES * 4) * 64;
   const f32x4* wh = cd.wh_rw + wbase;
   const f32x4* wl = cd.wl_rw + wbase;
 
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
     constexpr int RING = (NW == 4 && GR >= 2 && NECK_RING8) ? 8 : 4;
     ConvB bf[RING];
 #pragma unroll
-    for (int kk = 0; kk < RING; ++kk) { bf[kk].h = wh[kk * 64]; bf[kk].l = wl[kk * 64]; }
+    for (int kk = 0; kk < RING; ++kk) { bf[kk].h = wh[kk * 64 + ln]; bf[kk].l = wl[kk * 64 + ln]; }
     int gstep = RING;                               // next k16 step to fetch into the ring
     for (int s = 0; s < nstg; ++s) {
       const int cur = s & 1;
@@ -525,8 +530,8 @@ __global__ __launch_bounds__(64 * NW) void k_neck_conv_rw(NeckConvLaunch p) {
         }
         const int gi = min(gstep, NC_STAGES * 4 - 1);   // refill the ring slot just consumed
         if (!(NECK_ABL & 2)) {
-          bf[kk].h = wh[(size_t)gi * 64];
-          bf[kk].l = wl[(size_t)gi * 64];
+          bf[kk].h = wh[(size_t)gi * 64 + ln];
+          bf[kk].l = wl[(size_t)gi * 64 + ln];
         }
         ++gstep;
         __builtin_amdgcn_sched_barrier(0);
@@ -602,11 +607,12 @@ __global__ __launch_bounds__(512) void k_neck_out(NeckOutLaunch p) {
   const ATile<GM_SPLIT> A(smem, LDH, LDHH, &rg);
   float* S0 = smem + NP_S0_OFF;
   const NeckGeom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), col = lane & 31;
   const int r0 = blockIdx.x * TM;
 
   using WS = WStream<GM_SPLIT, 1>;
   WS ws;
+  ws.set_lane(lane);
   f32x16 acc[1];
   {
     const float b = p.bias2[32 * wave + col];
