@@ -175,7 +175,7 @@ long long* g_tbuf = nullptr;
 
 struct Workspace {
   float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
-      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *dump, *kvr, *ksr;
+      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *kvr, *ksr;
   uint32_t* flags;   // the workspace's status word (first 256 bytes: shape-independent position)
   size_t bytes;
 };
@@ -227,7 +227,9 @@ Workspace carve(const Geom& g, void* base, bool attn_full = false) {
   const size_t rows = g.rows, nt = g.ntiles;
   w.flags = reinterpret_cast<uint32_t*>(take(OETR_WORKSPACE_STATUS_BYTES / sizeof(float)));
   w.x = take(rows * C);
-  w.qp = take(rows * C);
+  // phi(Q): token-major for the 32-row kernel; the 64-row kernel keeps it TILE-major
+  // ([tile][64][256], every image's last tile padded - its stores need no row predicate)
+  w.qp = take((rows + (size_t)2 * g.N * 64) * C);
   w.pos = take((size_t)(g.L[0] + g.L[1]) * C);
   for (int i = 0; i < 2; ++i) { w.kvp[i] = take(nt * KV_FLOATS); w.ksp[i] = take(nt * C); }
   w.att0 = take(nt * C); w.z0 = take(nt * NH);
@@ -239,7 +241,6 @@ Workspace carve(const Geom& g, void* base, bool attn_full = false) {
   w.cxy = take((size_t)2 * g.N * 2);
   w.tlbr = take((size_t)2 * g.N * 4);
   w.convp = take((size_t)9 * rows * C);  // P_tap = W_tap . memory (forward path)
-  w.dump = take(C);                      // write-only scratch row (EncLaunch::dump)
   w.kvr = take((size_t)2 * g.N * KV_FLOATS);   // one reduced linear-attention state per image
   w.ksr = take((size_t)2 * g.N * C);           //   (k_kv_reduce, between the encoder launches)
   for (int i = 0; i < 2; ++i) {           // attention == full: K rows and V^T, per layer parity
@@ -342,7 +343,6 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   }
 #endif
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
-  p.dump = w.dump;
   p.flags = w.flags;
   p.attn_full = h->attn_full;
   p.policy = h->policy;

@@ -1127,7 +1127,8 @@ struct DecKVDev {
 struct EncLaunch {
   Geom g;
   float* x;              // [rows][256] token-major activations (in/out, in place)
-  float* qp;             // [rows][256] phi(Q) of the layer being finished / next
+  float* qp;             // phi(Q) of the layer being finished / next: [rows][256] token-major (32-row
+                         // kernel) or [tiles][64][256] tile-major (64-row kernel)
   const float* pos;      // [L0+L1][256] token-major position table
   const float* kv_in;    // partial KV states of the layer being finished
   const float* ks_in;    //   [ntiles][8192] / [ntiles][256]
@@ -1171,8 +1172,6 @@ struct EncLaunch {
   const float* feat_nchw[2];
   const float* pos_nchw[2];
   float* pos_out;        // = pos, writable (the token-major table the n == 0 tiles fill in)
-  float* dump;           // [256] write-only scratch row: where stores of rows past a ragged tile's end
-                         // go (an address select instead of a divergent branch around the store)
 };
 
 // has_b: run phase B (finish a layer); tail: 0 = phase A of next encoder layer,

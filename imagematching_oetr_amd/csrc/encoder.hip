@@ -818,13 +818,13 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
 __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int lane, int wave,
                                                float* __restrict__ kv_out,
                                                float* __restrict__ ks_out, int slot) {
-  f32x4* dst = reinterpret_cast<f32x4*>(kv_out) + ((size_t)slot * NH + wave) * 4 * 64 + lane;
+  f32x4* dst = reinterpret_cast<f32x4*>(kv_out) + ((size_t)slot * NH + wave) * 4 * 64;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     f32x4 o = {kv[4 * q], kv[4 * q + 1], kv[4 * q + 2], kv[4 * q + 3]};
-    dst[q * 64] = o;
+    dst[q * 64 + (unsigned)lane] = o;
   }
-  if (lane < 32) ks_out[(size_t)slot * C + wave * HD + lane] = ksum;
+  if (lane < 32) (ks_out + (size_t)slot * C + wave * HD)[(unsigned)lane] = ksum;
 }
 
 // Body of k_encoder64 for one workgroup.  ROWS (WStream2T): 2 = both 32-row MFMA tiles hold valid
@@ -870,6 +870,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   const int nvalid = min(RT, L - l0);
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
+  const size_t qrow_base = (size_t)slot * RT;   // this tile's rows of the TILE-major phi(Q) buffer
   const bool nchw = !HAS_B && p.feat_nchw[0] != nullptr;   // first launch on NCHW inputs (launch-uniform)
   ws.set_rows(nvalid);
   ws.set_lane(lane);
@@ -897,13 +898,13 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
 
     // ---- round 3: the residual stream lives in the TRANSPOSED accumulator layout (lane = token,
     //      register quads = 4 consecutive channels), merge / MLP2 run transposed like MLP1 ----
-    // phi(Q) tile -> R2 (f32): full 1-KB rows, 16 bytes per lane
+    // phi(Q) tile -> R2 (f32): a wave copies rows wave, wave + 8, ...: full 1-KB rows, 16 bytes
+    // per lane, the row address a scalar
 #pragma unroll
-    for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {
-      const int idx = tid + THREADS * i;
-      const int r = idx >> 6, c4 = idx & 63;
-      *reinterpret_cast<f32x4*>(R2f + r * LDA + 4 * c4) =
-          reinterpret_cast<const f32x4*>(p.qp + (row_base + min(r, nvalid - 1)) * C)[c4];
+    for (int i = 0; i < RT / 8; ++i) {
+      const int r = wave + 8 * i;
+      *reinterpret_cast<f32x4*>(R2f + r * LDA + 4 * lane) =
+          reinterpret_cast<const f32x4*>(p.qp + (qrow_base + min(r, nvalid - 1)) * C)[(unsigned)lane];
     }
     // reduce the source image's partial KV states (fixed order): the registers are this head's
     // state in MFMA fragment order (A operand of the transposed apply)
@@ -912,14 +913,14 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     for (int q = 0; q < 4; ++q) kvB[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
       constexpr int KVR = 7;
-      const f32x4* kvp = reinterpret_cast<const f32x4*>(p.kv_in) +
-                         ((size_t)src_slot0 * NH + wave) * 256 + lane;
-      const float* ksp = p.ks_in + (size_t)src_slot0 * C + (tid & (C - 1));
+      const unsigned ln = lane, kl = tid & (C - 1);
+      const f32x4* kvp = reinterpret_cast<const f32x4*>(p.kv_in) + ((size_t)src_slot0 * NH + wave) * 256;
+      const float* ksp = p.ks_in + (size_t)src_slot0 * C;
       float ks = 0.f;
       if (nts == 1) {   // pre-reduced (or a single tile): one state, no redundant clamped loads
 #pragma unroll
-        for (int e = 0; e < 4; ++e) kvB[e] = kvp[e * 64];
-        ks = ksp[0];
+        for (int e = 0; e < 4; ++e) kvB[e] = kvp[e * 64 + ln];
+        ks = ksp[kl];
       } else
       for (int ti0 = 0; ti0 < nts; ti0 += KVR) {
         f32x4 tmp[KVR][4];
@@ -928,8 +929,8 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
         for (int u = 0; u < KVR; ++u) {
           const int ti = min(ti0 + u, nts - 1);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tmp[u][e] = kvp[(size_t)ti * (NH * 256) + e * 64];
-          kt[u] = ksp[(size_t)ti * C];
+          for (int e = 0; e < 4; ++e) tmp[u][e] = kvp[(size_t)ti * (NH * 256) + e * 64 + ln];
+          kt[u] = ksp[(size_t)ti * C + kl];
         }
 #pragma unroll
         for (int u = 0; u < KVR; ++u)
@@ -1148,11 +1149,11 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
             f32x4{xacc[mt][4 * g4], xacc[mt][4 * g4 + 1], xacc[mt][4 * g4 + 2], xacc[mt][4 * g4 + 3]};
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {
-      const int idx = tid + THREADS * i;
-      const int r = idx >> 6, c4 = idx & 63;
+    for (int i = 0; i < RT / 8; ++i) {
+      const int r = wave + 8 * i;   // (scalar: a wave-uniform branch, an SGPR row address)
       if (r < nvalid)
-        reinterpret_cast<f32x4*>(p.x + (row_base + r) * C)[c4] = *reinterpret_cast<const f32x4*>(Xf + r * LDA + 4 * c4);
+        reinterpret_cast<f32x4*>(p.x + (row_base + r) * C)[(unsigned)lane] =
+            *reinterpret_cast<const f32x4*>(Xf + r * LDA + 4 * lane);
     }
     PHASE_STAMP(p, 8);
     if (TAIL == 2) { range_report<MODE>(rg, p.flags); return; }
@@ -1205,12 +1206,10 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     }
     __syncthreads();
     PHASE_STAMP(p, 9);
-    // phi(Q) -> HBM, issued under the K GEMM's MFMAs (two accumulator values per k16 step; rows
-    // past a ragged tile's end go to the scratch row: an address select, no divergent branch)
+    // phi(Q) -> HBM, issued under the K GEMM's MFMAs (two accumulator values per k16 step).  The
+    // phi(Q) buffer is TILE-major ([slot][64][256], rows past an image's end are padding), so
+    // every store is unconditional: an SGPR row address, one per-lane offset, no select
     f32x16 accQ[2] = {f32x16{0}, f32x16{0}};
-    int l2 = lane;  // laundered: no address CSE with the residual loads at the top of the kernel
-    asm volatile("" : "+v"(l2));
-    const int nv2 = nvalid - 4 * (l2 >> 5);
     // (issuing the x store under this GEMM, or phi(K) under the V GEMM below, was measured
     //  neutral to slightly slower - one-process A/B, 51.6 vs 51.9 us; only the GELU epilogues
     //  and the phi(Q) store pay for the interleave)
@@ -1220,15 +1219,16 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
     {
       // phi(Q) -> HBM under the K GEMM's MFMAs (two accumulator values per k16 step)
-      float* qs = p.qp + (row_base + 4 * (l2 >> 5)) * C + wcol + (l2 & 31);
-      float* qdump = p.dump + wcol + (l2 & 31);
+      float* qs = p.qp + qrow_base * C + wcol;                  // (scalar)
+      const unsigned qoff = 4 * half * C + col;                 // row crow(r, half) = crow(r, 0) + 4 half
+      const bool two = ws.two();
       auto qepi = [&](auto CI_) {
         constexpr int CI = decltype(CI_)::value, mt = CI / 8, r0 = 2 * (CI % 8);
+        if (mt == 1 && !two) return;   // (rows 32.. of a one-row-tile workgroup are never read)
 #pragma unroll
         for (int r = r0; r < r0 + 2; ++r) {
-          const int row = 32 * mt + crow(r, 0);
           const float x = accQ[mt][r];
-          *(row < nv2 ? qs + row * C : qdump) = fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f));   // == elu(x) + 1
+          (qs + (32 * mt + crow(r, 0)) * C)[qoff] = fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f));   // == elu(x) + 1
         }
       };
       ws.template gemm_epi<C, P_T1, true, C, SP::K, SP::V>(P2, p.a.wk, p.a.wk_l, wave, 0, lane, accK, p.a.wv,
