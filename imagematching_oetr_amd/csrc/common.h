@@ -35,6 +35,12 @@ constexpr int MAX_TOKENS = 10000;  // NECK.MAX_SHAPE 100x100 (reference default.
 // phases up to n under real conditions (launch, loads and barriers included).
 #if defined(OETR_ABLATE)
 #define PHASE_STAMP(p, idx) do { if (((p).dbg >> 16) == (idx) + 1) return; } while (0)
+#elif defined(OETR_PHASE_TIMING) && OETR_PHASE_TIMING == 2   // per WAVE, workgroups 0..15 (tools/wave_skew64.py)
+#define PHASE_STAMP(p, idx)                                                              \
+  do {                                                                                   \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 16 && (p).tbuf)                          \
+      (p).tbuf[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #elif defined(OETR_PHASE_TIMING)
 #define PHASE_STAMP(p, idx)                                                              \
   do {                                                                                   \
@@ -177,10 +183,16 @@ __device__ __forceinline__ float exp_neg(float x) {
   const float e = __builtin_amdgcn_exp2f(t);
   return fmaf(e, r * 0.69314718055994531f, e);
 }
-// phi(x) = elu(x) + 1.  torch evaluates expm1(x) + 1 for x <= 0, which is
-// exp(x) to within one rounding of the final add (<= 6e-8 absolute).
+// phi(x) = elu(x) + 1 = x + 1 (x > 0) | e^x (x <= 0).  torch evaluates expm1(x) + 1 for
+// x <= 0, which is exp(x) to within one rounding of the final add (<= 6e-8 absolute).
+// Branch-free as a MEDIAN: e^x >= x + 1 everywhere, and 1 lies between them on the other side
+// (x > 0: 1 < x + 1 < e^x;  x < 0: x + 1 < e^x < 1), so phi(x) = med3(x + 1, e^x, 1) - add, mul,
+// v_exp_f32, v_med3_f32 (round 2: max + min + the compensated exp_neg + add = 9; an overflowed
+// e^x = inf for large x is never the median).  e^x = exp2(x log2 e) with the product rounded
+// once: relative error <= |x| 4e-8 + one ulp of v_exp_f32, i.e. <= 8e-8 absolute since
+// |x| e^x <= 1/e - the size of torch's own final rounding.
 __device__ __forceinline__ float elu1(float x) {
-  return x > 0.f ? x + 1.0f : exp_neg(x);
+  return __builtin_amdgcn_fmed3f(x + 1.0f, __builtin_amdgcn_exp2f(x * 1.4426950408889634f), 1.0f);
 }
 
 // DPP lane exchange inside a row of 16 lanes (no LDS traffic, unlike
@@ -463,12 +475,25 @@ struct Range {
   // value the format cannot hold arrives as inf (0x7c00; NaN is larger) and the ordering of
   // f16 magnitudes is the ordering of their bit patterns.  (Round 2 kept a wave-uniform mask
   // in SGPRs - v_max + v_cmp + s_or per pair and ~450 SGPR spills per kernel.)
+  //
+  // Round 3: where the fp32 SOURCE values are at hand (cvt_planes2 - every conversion of the
+  // encoder / heads / neck GEMM operands) the guard is one v_max3_f32 per pair on |a|, |b|
+  // (source modifiers) instead of two instructions on the converted bits: a value rounds to
+  // f16 inf exactly when |x| >= 65520.  NaN SOURCES are not seen by this form (max drops
+  // them); a NaN can only arise downstream of an inf, which is seen - or come in with the
+  // caller's features, in which case the boxes are NaN and no precision helps.
   uint32_t mx = 0;
+  float fm = 0.f;
+  __device__ __forceinline__ void see2(float a, float b) {
+    fm = __builtin_fmaxf(__builtin_fmaxf(fm, __builtin_fabsf(a)), __builtin_fabsf(b));
+  }
   __device__ __forceinline__ void see_hi(uint32_t hi_pair) {
     mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, mx),
                                                                 __builtin_bit_cast(u16x2, hi_pair & 0x7fff7fffu)));
   }
-  __device__ __forceinline__ bool bad() const { return (mx & 0xffffu) >= 0x7c00u || (mx >> 16) >= 0x7c00u; }
+  __device__ __forceinline__ bool bad() const {
+    return (mx & 0xffffu) >= 0x7c00u || (mx >> 16) >= 0x7c00u || !(fm < 65520.0f);
+  }
 };
 template <int M>
 __device__ __forceinline__ void range_report(const Range& rg, uint32_t* flags) {
@@ -493,7 +518,7 @@ __device__ __forceinline__ void cvt_planes2(float a, float b, uint32_t& hi, uint
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
     lo = 0;
   }
-  if constexpr (gm_f16_range(M)) rg.see_hi(hi);
+  if constexpr (gm_f16_range(M)) rg.see2(a, b);
 }
 // One 32x32x16 MFMA on raw 16-byte fragments in the mode's element type.
 template <int M>
@@ -800,6 +825,17 @@ __device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4]
 #ifndef OETR_RING1
 #define OETR_RING1 6    // ring depth of the single-plane (f16 / bf16) weight stream
 #endif
+// gfx950: a vector-memory STORE can retire - decrement vmcnt - before an OLDER load has
+// returned, so the in-order allowance hipcc computes for `s_waitcnt vmcnt(N)` (N = every younger
+// operation, stores included) can be met while the load is still in flight.  Measured: with
+// phi(Q) / x / conv-P stores issued between a weight fragment's fetch and its use, MFMAs of the
+// short-step workgroups (one row tile, single-plane modes) read fragments whose lanes had not
+// all arrived - results that depended on timing (tools/determinism_check.py: up to 36 of 60
+// forwards differing; 0 of 180 with the waits below, at no cost).  Every step of the weight
+// streams therefore waits with an allowance that counts the younger LOADS only.
+#ifndef OETR_VMCNT_LOADS
+#define OETR_VMCNT_LOADS 1
+#endif
 #ifndef OETR_WS_U
 #define OETR_WS_U 1     // k16 steps per chunk
 #endif
@@ -879,6 +915,17 @@ struct WStream<M, 1, true> {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#if OETR_VMCNT_LOADS
+      {
+        // loads-only allowance (see WStream2T::step): stores issued since this chunk's fetch
+        // - phi(Q) after the Q GEMM, x after MLP2 - are not counted
+        constexpr int L_THIS = (TWO && site_w_lo(SITE)) ? 2 : 1, L_NEXT = (TWO && site_w_lo(NSITE)) ? 2 : 1;
+        constexpr int IN_THIS = (CI + PRE < NCH ? PRE : NCH - 1 - CI);
+        constexpr int younger = U * (IN_THIS * L_THIS + (NK != 0 ? (PRE - IN_THIS) * L_NEXT : 0));
+        __builtin_amdgcn_s_waitcnt((younger & 0xF) | ((younger >> 4) << 14) | 0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       const BChunk& b = ring[(P + CI) % D];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1046,6 +1093,19 @@ struct WStream2T {
       __builtin_amdgcn_sched_barrier(0);
       const BStep& b = ring[(P + CI) % D];
       const AStep& ac = a[CI & 1];
+#if OETR_VMCNT_LOADS
+      {
+        // this step's fragments are in the registers once at most `younger` vector-memory
+        // operations are outstanding, counting only the LOADS issued after them (the PRE steps
+        // fetched since): global STORES issued in between (phi(Q) under the K GEMM, x before
+        // phase A, conv-P's tap stores) must not be part of the allowance
+        constexpr int L_THIS = (TWO && site_w_lo(SITE)) ? 2 : 1, L_NEXT = (TWO && site_w_lo(NSITE)) ? 2 : 1;
+        constexpr int IN_THIS = (CI + PRE < NS ? PRE : NS - 1 - CI);      // later steps of this GEMM in flight
+        constexpr int younger = IN_THIS * L_THIS + (HAS_NEXT ? (PRE - IN_THIS) * L_NEXT : 0);
+        __builtin_amdgcn_s_waitcnt((younger & 0xF) | ((younger >> 4) << 14) | 0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       epi(std::integral_constant<int, CI>{});
       auto mm = [](const f32x4& act, const f32x4& wgt, const f32x16& c) {
         if constexpr (TR) return mma16<M>(wgt, act, c);

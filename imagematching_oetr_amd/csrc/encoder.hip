@@ -102,7 +102,7 @@ __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& ac
         const int r = 8 * s + i;
         const float m = crow(r, half) < nvalid ? 1.0f : 0.0f;
         const float x = accK[r];
-        const float kk = (skip_phi ? x : fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+        const float kk = (skip_phi ? x : elu1(x)) * m;
         const float vv = accV[r] * (inv_len * m);
         ksum += kk;
         if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
@@ -123,7 +123,7 @@ __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& ac
       for (int j = 0; j < 4; ++j) {
         const float m = crow(r0 + j, half) < nvalid ? 1.0f : 0.0f;
         const float x = accK[r0 + j];
-        k[j] = (skip_phi ? x : fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+        k[j] = (skip_phi ? x : elu1(x)) * m;
         v[j] = accV[r0 + j] * (inv_len * m);
         ksum += k[j];
       }
@@ -753,10 +753,10 @@ template <int MODE>
 __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x16 (&accV)[2],
                                             int S_len, int nvalid, int half, bool two, f32x16& kv,
                                             float& ksum, Range& rg) {
-  // Branch-free phi (max(x,0) + exp(min(x,0)) == elu(x)+1 bit for bit: exp_neg(0) == 1) on
-  // scalars, a few at a time: as a select hipcc branches per element (and, on the
-  // accumulator tuples, copies whole 16-register tuples around the branch); unfenced,
-  // it schedules all 32 exps at once and spills.
+  // Branch-free phi (common.h: elu1, a median) on scalars, a few at a time: unfenced, hipcc
+  // schedules all 32 exps at once and spills.  A row tile whose 32 rows are all valid (every
+  // tile of an image but its last) takes the path without the row masks - a workgroup-uniform
+  // branch per row tile.
   const float inv_len = 1.0f / (float)S_len;
   kv = f32x16{0};
   ksum = 0.f;
@@ -767,20 +767,25 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
   if constexpr (gm_f16_range(MODE) && OETR_SPLIT_STATE) {
     // 64-token contraction as 4 k16 steps of the fp32-class split (see kv_state_32)
     f32x16 c1 = {0};
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if (mt == 1 && !two) break;  // no valid row in the second row tile
+    auto row_tile = [&](auto MT_, auto MASKED_) {
+      constexpr int mt = decltype(MT_)::value;
+      constexpr bool MASKED = decltype(MASKED_)::value;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         f32x4 k0, k1, v0, v1;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int r = 8 * s + i;
-          const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
           const float x = accK[mt][r];
-          const float kk = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+          float kk = elu1(x), vv;
+          if constexpr (MASKED) {
+            const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
+            kk *= m;
+            vv = accV[mt][r] * (inv_len * m);
+          } else {
+            vv = accV[mt][r] * inv_len;
+          }
           ksum += kk;
-          const float vv = accV[mt][r] * (inv_len * m);
           if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
         }
         f32x4 ah, al, bh, bl;
@@ -789,6 +794,14 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
         mma16_split3(ah, al, bh, bl, kv, c1);
         __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (nvalid >= 32) row_tile(I0{}, std::false_type{});
+    else row_tile(I0{}, std::true_type{});
+    if (two) {   // (else: no valid row in the second row tile)
+      if (nvalid >= 64) row_tile(I1{}, std::false_type{});
+      else row_tile(I1{}, std::true_type{});
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
@@ -803,7 +816,7 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
         for (int j = 0; j < 4; ++j) {
           const float m = 32 * mt + crow(r0 + j, 0) < nv2 ? 1.0f : 0.0f;
           const float x = accK[mt][r0 + j];
-          k[j] = (fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f))) * m;
+          k[j] = (elu1(x)) * m;
           ksum += k[j];
           v[j] = accV[mt][r0 + j] * (inv_len * m);
         }
@@ -1228,7 +1241,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
 #pragma unroll
         for (int r = r0; r < r0 + 2; ++r) {
           const float x = accQ[mt][r];
-          (qs + (32 * mt + crow(r, 0)) * C)[qoff] = fmaxf(x, 0.f) + exp_neg(fminf(x, 0.f));   // == elu(x) + 1
+          (qs + (32 * mt + crow(r, 0)) * C)[qoff] = elu1(x);
         }
       };
       ws.template gemm_epi<C, P_T1, true, C, SP::K, SP::V>(P2, p.a.wk, p.a.wk_l, wave, 0, lane, accK, p.a.wv,

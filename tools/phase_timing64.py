@@ -12,8 +12,8 @@ model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
 n = 8
 f1 = (torch.rand(n, 256, 20, 20) - 0.5).to(dev); f2 = (torch.rand(n, 256, 20, 20) - 0.5).to(dev)
 pos = model.pos_encoding(f1.cpu()).contiguous().to(dev)
-NAMES = ['loads+kvreduce', 'Z+attn-apply', 'merge GEMM', 'stage+LN2', 'MLP1a+GELU', 'MLP2a', 'MLP1b+GELU', 'MLP2b+store+stage',
-         'LN-A', 'Q GEMM+phi+store', 'K,V GEMMs', 'KV state']
+NAMES = ['loads+kvreduce', 'attn-apply (+Z)', 'merge GEMM', 'LN2 (registers)', 'MLP1a, MLP1b+GELU(a)', 'MLP2a+GELU(b)', '-', 'MLP2b+stage+x store',
+         'LN-A', 'Q GEMM', 'K GEMM+phi(Q) store, V GEMM', 'KV state']
 prec = sys.argv[1] if len(sys.argv) > 1 else 'f32_split_f16'
 eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision=prec, enc_tile=64)
 lib = eng.lib
