@@ -443,6 +443,9 @@ __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda
 }
 
 // ---- 16-bit-plane GEMM core (GM_SPLIT / GM_F16 / GM_BF16) -----------------
+#ifndef OETR_SPLIT_MIXLO
+#define OETR_SPLIT_MIXLO 1
+#endif
 // hi/lo halves of two floats: (hi0,hi1) and (lo0,lo1) packed as f16x2.
 __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
   // hi = RNE f16 (v_cvt_pk_f16_f32): the hi plane alone is the f16 rounding of the value
@@ -455,9 +458,21 @@ __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
   const v2f ab = v2f{a, b};
   hi = __builtin_convertvector(ab, f16x2);
   const v2f sc = ab * v2f{SPLIT_SCALE, SPLIT_SCALE};   // (one v_pk_mul_f32)
+#if OETR_SPLIT_MIXLO
+  // (a - hi) 2^11 straight into the f16 halves: v_fma_mixlo_f16 / v_fma_mixhi_f16 (fma in fp32,
+  // result rounded to nearest f16) - no separate pack instruction
+  // (inline asm: hipcc selects two v_fma_mixlo_f16 and a pack for the plain expression)
+  const uint32_t hb = __builtin_bit_cast(uint32_t, hi);
+  const float ns = -SPLIT_SCALE;
+  uint32_t lb;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "s"(ns), "v"(sc[0]));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "s"(ns), "v"(sc[1]));
+  lo = __builtin_bit_cast(f16x2, lb);
+#else
   lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(
                                      __builtin_fmaf((float)hi[0], -SPLIT_SCALE, sc[0]),
                                      __builtin_fmaf((float)hi[1], -SPLIT_SCALE, sc[1])));
+#endif
 }
 // Range guard of the f16-based modes (GM_SPLIT, GM_F16): every activation that is converted
 // into a GEMM operand leaves its f16 bit pattern in a running maximum (Range, two VALU per
