@@ -443,9 +443,6 @@ __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda
 }
 
 // ---- 16-bit-plane GEMM core (GM_SPLIT / GM_F16 / GM_BF16) -----------------
-#ifndef OETR_SPLIT_MIXLO
-#define OETR_SPLIT_MIXLO 1
-#endif
 // hi/lo halves of two floats: (hi0,hi1) and (lo0,lo1) packed as f16x2.
 __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
   // hi = RNE f16 (v_cvt_pk_f16_f32): the hi plane alone is the f16 rounding of the value
@@ -454,25 +451,17 @@ __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
   // tests: fp32-class vs fp64), formed as a * 2^11 - hi * 2^11: both products and their
   // difference are exact (a - hi is representable), and the f16 operand goes straight into
   // v_fma_mix_f32 - 6 VALU per pair instead of 8 (no v_cvt_f32_f16).
+  // (An inline-asm v_fma_mixlo_f16 / v_fma_mixhi_f16 pair - no pack instruction - was tried and
+  //  removed: same speed in a one-process A/B, and hipcc pads no hazards around asm: a
+  //  v_fma_mixhi_f16 result consumed by an MFMA one issue slot later gave timing-dependent
+  //  linear-attention states, 116 of 46 944 forwards.)
   typedef float v2f __attribute__((ext_vector_type(2)));
   const v2f ab = v2f{a, b};
   hi = __builtin_convertvector(ab, f16x2);
   const v2f sc = ab * v2f{SPLIT_SCALE, SPLIT_SCALE};   // (one v_pk_mul_f32)
-#if OETR_SPLIT_MIXLO
-  // (a - hi) 2^11 straight into the f16 halves: v_fma_mixlo_f16 / v_fma_mixhi_f16 (fma in fp32,
-  // result rounded to nearest f16) - no separate pack instruction
-  // (inline asm: hipcc selects two v_fma_mixlo_f16 and a pack for the plain expression)
-  const uint32_t hb = __builtin_bit_cast(uint32_t, hi);
-  const float ns = -SPLIT_SCALE;
-  uint32_t lb;
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "s"(ns), "v"(sc[0]));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "s"(ns), "v"(sc[1]));
-  lo = __builtin_bit_cast(f16x2, lb);
-#else
   lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(
                                      __builtin_fmaf((float)hi[0], -SPLIT_SCALE, sc[0]),
                                      __builtin_fmaf((float)hi[1], -SPLIT_SCALE, sc[1])));
-#endif
 }
 // Range guard of the f16-based modes (GM_SPLIT, GM_F16): every activation that is converted
 // into a GEMM operand leaves its f16 bit pattern in a running maximum (Range, two VALU per
@@ -562,11 +551,34 @@ __device__ __forceinline__ void split8(const f32x4& a0, const f32x4& a1, f32x4& 
 // main += ah.bh ; cross += ah.bl + al.bh   (one k16 step of a split product; ONE cross
 // accumulator: these blocks are 2-4 steps long and short of registers, the dependent
 // cross MFMAs cost a few stalled cycles)
+//
+// The operands of these MFMAs come straight out of VALU conversions (split2), not from LDS or a
+// load.  Left to hipcc's scheduler the conversions of `al` sit between the MFMAs, an operand
+// register is written one or two issue slots before the MFMA that reads it and rewritten right
+// after - legal by hipcc's hazard tables and by tools/mfma_hazard_probe.hip (every VALU
+// producer needs ONE wait state before the MFMA, overwriting a source right after it is safe,
+// with or without a sibling MFMA stream) - and yet this is where the timing-dependent results
+// of round 3 came from (encoder.hip: OETR_SPLIT_STATE; 230 -> 0-1 of 20 000 forwards with the
+// fences below under the vmcnt(0) amplifier, tools/hunt_multi.sh; the mechanism was not
+// isolated).  So: every operand is complete OETR_SPLIT3_PAD + 1 wait states before the first
+// MFMA and the three MFMAs issue back to back.  0.7 us per encoder launch.
+#ifndef OETR_SPLIT3_PAD
+#define OETR_SPLIT3_PAD 7
+#endif
+#define OETR_STR2(x) #x
+#define OETR_STR(x) OETR_STR2(x)
+template <bool FENCE = true>
 __device__ __forceinline__ void mma16_split3(const f32x4& ah, const f32x4& al, const f32x4& bh,
                                              const f32x4& bl, f32x16& main, f32x16& cross) {
+  if constexpr (FENCE) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop " OETR_STR(OETR_SPLIT3_PAD));
+    __builtin_amdgcn_sched_barrier(0);
+  }
   cross = mma16<GM_SPLIT>(ah, bl, cross);
   main = mma16<GM_SPLIT>(ah, bh, main);
   cross = mma16<GM_SPLIT>(al, bh, cross);
+  if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 }
 
 // Store 4 consecutive floats of a row as 4 16-bit values per plane (8-byte stores).
@@ -840,16 +852,15 @@ __device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4]
 #ifndef OETR_RING1
 #define OETR_RING1 6    // ring depth of the single-plane (f16 / bf16) weight stream
 #endif
-// gfx950: a vector-memory STORE can retire - decrement vmcnt - before an OLDER load has
-// returned, so the in-order allowance hipcc computes for `s_waitcnt vmcnt(N)` (N = every younger
-// operation, stores included) can be met while the load is still in flight.  Measured: with
-// phi(Q) / x / conv-P stores issued between a weight fragment's fetch and its use, MFMAs of the
-// short-step workgroups (one row tile, single-plane modes) read fragments whose lanes had not
-// all arrived - results that depended on timing (tools/determinism_check.py: up to 36 of 60
-// forwards differing; 0 of 180 with the waits below, at no cost).  Every step of the weight
-// streams therefore waits with an allowance that counts the younger LOADS only.
+// Optional explicit waits before every step of the weight streams (a constexpr of the ring
+// position):  1 = an allowance that counts the younger LOADS only,  2 = vmcnt(0).  Default 0:
+// hipcc's own s_waitcnt placement.  (Round 3 first blamed its timing-dependent results on
+// stores retiring before older loads and shipped variant 1; the cause was elsewhere -
+// encoder.hip: OETR_SPLIT_STATE - and with that fixed the plain build shows 0 differing of
+// 129 000 forwards.  Variant 2 slows the short-step workgroups down and is the AMPLIFIER the
+// determinism hunts use: tools/hunt_multi.sh.)
 #ifndef OETR_VMCNT_LOADS
-#define OETR_VMCNT_LOADS 1
+#define OETR_VMCNT_LOADS 0
 #endif
 #ifndef OETR_WS_U
 #define OETR_WS_U 1     // k16 steps per chunk
@@ -932,11 +943,10 @@ struct WStream<M, 1, true> {
       __builtin_amdgcn_sched_barrier(0);
 #if OETR_VMCNT_LOADS
       {
-        // loads-only allowance (see WStream2T::step): stores issued since this chunk's fetch
-        // - phi(Q) after the Q GEMM, x after MLP2 - are not counted
+        // (OETR_VMCNT_LOADS: see above)
         constexpr int L_THIS = (TWO && site_w_lo(SITE)) ? 2 : 1, L_NEXT = (TWO && site_w_lo(NSITE)) ? 2 : 1;
         constexpr int IN_THIS = (CI + PRE < NCH ? PRE : NCH - 1 - CI);
-        constexpr int younger = U * (IN_THIS * L_THIS + (NK != 0 ? (PRE - IN_THIS) * L_NEXT : 0));
+        constexpr int younger = OETR_VMCNT_LOADS == 2 ? 0 : U * (IN_THIS * L_THIS + (NK != 0 ? (PRE - IN_THIS) * L_NEXT : 0));
         __builtin_amdgcn_s_waitcnt((younger & 0xF) | ((younger >> 4) << 14) | 0x0F70);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1112,11 +1122,10 @@ struct WStream2T {
       {
         // this step's fragments are in the registers once at most `younger` vector-memory
         // operations are outstanding, counting only the LOADS issued after them (the PRE steps
-        // fetched since): global STORES issued in between (phi(Q) under the K GEMM, x before
-        // phase A, conv-P's tap stores) must not be part of the allowance
+        // fetched since)
         constexpr int L_THIS = (TWO && site_w_lo(SITE)) ? 2 : 1, L_NEXT = (TWO && site_w_lo(NSITE)) ? 2 : 1;
         constexpr int IN_THIS = (CI + PRE < NS ? PRE : NS - 1 - CI);      // later steps of this GEMM in flight
-        constexpr int younger = IN_THIS * L_THIS + (HAS_NEXT ? (PRE - IN_THIS) * L_NEXT : 0);
+        constexpr int younger = OETR_VMCNT_LOADS == 2 ? 0 : IN_THIS * L_THIS + (HAS_NEXT ? (PRE - IN_THIS) * L_NEXT : 0);
         __builtin_amdgcn_s_waitcnt((younger & 0xF) | ((younger >> 4) << 14) | 0x0F70);
         __builtin_amdgcn_sched_barrier(0);
       }

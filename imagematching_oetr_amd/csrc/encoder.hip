@@ -28,11 +28,21 @@
 
 #include "common.h"
 
-// fp32-class split f16 MFMAs (instead of f32 MFMAs at 1/16 of the rate) for the two small
-// attention blocks of the f16-based modes: the per-tile KV state phi(K)^T V and the
-// attention apply phi(Q).KV (A/B: tools/variants)
+// The two small attention blocks of the f16-based modes - the per-tile KV state phi(K)^T V and
+// the attention apply phi(Q).KV - take their MFMA operands straight from VALU conversions.
+//  * APPLY runs as fp32-class split f16 MFMAs (common.h: mma16_split3, fenced).
+//  * STATE runs on f32 MFMAs (v_mfma_f32_32x32x2_f32, exact products).  The split form
+//    (OETR_SPLIT_STATE=1, round 2's default) is 1.8 us per launch faster in the 64-row kernel
+//    (2.2 us SLOWER in the 32-row one) and gave timing-dependent states: with the two waves of a
+//    SIMD in different phases - a ragged last tile behind cold weight loads - one head's state
+//    came out with the columns 16..31 of its B operand (V) wrong, 2-800 of 25 000 forwards
+//    depending on mode and box (tools/determinism_hunt.py).  No failure in 120 000
+//    forwards with the state on f32 MFMAs, 77 000 of them under the vmcnt(0) amplifier.
 #ifndef OETR_SPLIT_STATE
-#define OETR_SPLIT_STATE 1
+#define OETR_SPLIT_STATE 0
+#endif
+#ifndef OETR_APPLY_FENCE
+#define OETR_APPLY_FENCE 1
 #endif
 #ifndef OETR_SPLIT_APPLY
 #define OETR_SPLIT_APPLY 1
@@ -373,7 +383,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(crow(r, half), nvalid - 1);
-        xacc[t][r] = ABL(p.dbg, ABL_XLOAD) ? 0.5f : p.x[(row_base + row) * C + wcol + 32 * t + col];
+        // (uniform base + 32-bit per-lane offset: an SGPR-base load, no 64-bit VALU address)
+        xacc[t][r] = ABL(p.dbg, ABL_XLOAD) ? 0.5f : (p.x + row_base * C + wcol + 32 * t)[(unsigned)(row * C + col)];
       }
     if constexpr (FULL) {
       full_attention_tile<MODE>(p, n, ss, row_base, nvalid, lane, wave, S1, rg);
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
             split8(*reinterpret_cast<const f32x4*>(qrow), *reinterpret_cast<const f32x4*>(qrow + 8),
                    ah, al, rg);
             split8(kvB[t][2 * s2], kvB[t][2 * s2 + 1], bh, bl, rg);
-            mma16_split3(ah, al, bh, bl, macc[t], c1);
+            mma16_split3<OETR_APPLY_FENCE != 0>(ah, al, bh, bl, macc[t], c1);
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) macc[t][r] = fmaf(c1[r], SPLIT_INV, macc[t][r]);
@@ -553,7 +564,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = crow(r, half);
-        if (row < nvalid && !ABL(p.dbg, ABL_STORE)) p.x[(row_base + row) * C + wcol + 32 * t + col] = xacc[t][r];
+        if (row < nvalid && !ABL(p.dbg, ABL_STORE)) (p.x + row_base * C + wcol + 32 * t)[(unsigned)(row * C + col)] = xacc[t][r];
       }
     if (TAIL != 2) acc_to_lds<NT>(S0, LDA, wcol, lane, xacc);
     __syncthreads();  // also: every wave is done reading Hh before S2 (alias) is written
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
           if (row < nvalid && !ABL(p.dbg, ABL_STORE))
-            p.qp[(row_base + row) * C + wcol + 32 * t + col] = (FULL || ABL(p.dbg, ABL_ELU)) ? acc[t][r] : elu1(acc[t][r]);
+            (p.qp + row_base * C + wcol + 32 * t)[(unsigned)(row * C + col)] = (FULL || ABL(p.dbg, ABL_ELU)) ? acc[t][r] : elu1(acc[t][r]);
         }
     }
     PHASE_STAMP(p, 8);
@@ -1001,8 +1012,8 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
             const float* qrow = R2f + (32 * mt + col) * LDA + wave * HD + 4 * half + 16 * s2;
             f32x4 qh, ql;
             split8(*reinterpret_cast<const f32x4*>(qrow), *reinterpret_cast<const f32x4*>(qrow + 8), qh, ql, rg);
-            mma16_split3(kvh[s2], kvl[s2], qh, ql, macc, c1);
-            mma16_split3(ksh[s2], ksl[s2], qh, ql, zacc, cz);
+            mma16_split3<OETR_APPLY_FENCE != 0>(kvh[s2], kvl[s2], qh, ql, macc, c1);
+            mma16_split3<OETR_APPLY_FENCE != 0>(ksh[s2], ksl[s2], qh, ql, zacc, cz);
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) macc[r] = fmaf(c1[r], SPLIT_INV, macc[r]);
