@@ -302,6 +302,30 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
             f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv});
 }
 
+// LayerNorm affines -> LDS, six rows of 256 [ln2 w, b | lnq w, b | lnkv w, b].  Every source
+// pointer is a compile-time choice per 256-thread group: with a run-time row index hipcc built
+// a pointer table in scratch and fetched through it with dependent flat loads - three
+// serialized round trips (scratch -> flat -> LDS) at the top of every launch.
+template <int THREADS, bool HAS_B, int TAIL>
+__device__ __forceinline__ void stage_ln_params(float* lnp_s, const EncLaunch& p, int tid) {
+  static_assert(THREADS == 256 || THREADS == 512, "one or two 256-thread groups");
+  const int c = tid & (C - 1);
+  if constexpr (THREADS == 512) {
+    const bool hi = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;   // waves 4..7: the bias rows
+    if (HAS_B) lnp_s[tid] = (hi ? p.b.ln2_b : p.b.ln2_w)[c];
+    if (TAIL == 0) {
+      lnp_s[2 * C + tid] = (hi ? p.a.lnq_b : p.a.lnq_w)[c];
+      lnp_s[4 * C + tid] = (hi ? p.a.lnkv_b : p.a.lnkv_w)[c];
+    }
+  } else {
+    if (HAS_B) { lnp_s[c] = p.b.ln2_w[c]; lnp_s[C + c] = p.b.ln2_b[c]; }
+    if (TAIL == 0) {
+      lnp_s[2 * C + c] = p.a.lnq_w[c]; lnp_s[3 * C + c] = p.a.lnq_b[c];
+      lnp_s[4 * C + c] = p.a.lnkv_w[c]; lnp_s[5 * C + c] = p.a.lnkv_b[c];
+    }
+  }
+}
+
 template <bool HAS_B, int TAIL, int MODE, int NW, bool FULL = false, int POL = 0>
 __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   constexpr bool SPLIT = gm_half(MODE);  // GEMM operands live in 16-bit LDS planes
@@ -357,13 +381,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 
   // LayerNorm affines -> LDS once (the row-wise phases then issue no global loads
   // that would queue behind the weight stream's run-ahead fetches)
-  for (int i = tid; i < 6 * C; i += THREADS) {
-    const int which = i >> 8, c = i & (C - 1);
-    const float* src = which == 0 ? p.b.ln2_w : which == 1 ? p.b.ln2_b : which == 2 ? p.a.lnq_w
-                     : which == 3 ? p.a.lnq_b : which == 4 ? p.a.lnkv_w : p.a.lnkv_b;
-    const bool used = which < 2 ? HAS_B : TAIL == 0;
-    if (used) lnp_s[i] = src[c];
-  }
+  stage_ln_params<THREADS, HAS_B, TAIL>(lnp_s, p, tid);
 
   f32x16 xacc[NT];  // residual stream of this wave's columns (C layout)
   PHASE_STAMP(p, 0);
@@ -899,13 +917,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   ws.set_rows(nvalid);
   ws.set_lane(lane);
 
-  for (int i = tid; i < 6 * C; i += THREADS) {
-    const int which = i >> 8, c = i & (C - 1);
-    const float* src = which == 0 ? p.b.ln2_w : which == 1 ? p.b.ln2_b : which == 2 ? p.a.lnq_w
-                     : which == 3 ? p.a.lnq_b : which == 4 ? p.a.lnkv_w : p.a.lnkv_b;
-    const bool used = which < 2 ? HAS_B : TAIL == 0;
-    if (used) lnp_s[i] = src[c];
-  }
+  stage_ln_params<THREADS, HAS_B, TAIL>(lnp_s, p, tid);
   // position rows of this tile for the tail (issued early: nothing waits on them yet)
   const f32x4* pos = reinterpret_cast<const f32x4*>(
                          p.pos + (size_t)(g.prow0[side] + l0 + min(lrow, nvalid - 1)) * C) + lpart;

@@ -45,6 +45,51 @@
         "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",   \
         "v230", "v231", "v232", "v233", "v234", "v235", "v236")
 
+// The mma16_split3 pattern: c += A.B1 ; m += A.B2 ; (VALU writes A2) ; c += A2.B2 - the third MFMA
+// depends on the first through its accumulator - then EVERY source register is overwritten with
+// 2.0 in the slots right after (the next iteration's conversions, as hipcc schedules them).
+// c must end at 32 * iters, m at 16 * iters.  GAP: wait states between the third MFMA and the
+// overwrites.
+#define TRIPLE(GAP)                                                                               \
+  asm volatile(                                                                                   \
+      "s_mov_b32 s40, %[iters]\n"                                                                 \
+      "v_mov_b32 v208, 0\n v_mov_b32 v209, 0\n v_mov_b32 v210, 0\n v_mov_b32 v211, 0\n"           \
+      "v_mov_b32 v212, 0\n v_mov_b32 v213, 0\n v_mov_b32 v214, 0\n v_mov_b32 v215, 0\n"           \
+      "v_mov_b32 v216, 0\n v_mov_b32 v217, 0\n v_mov_b32 v218, 0\n v_mov_b32 v219, 0\n"           \
+      "v_mov_b32 v220, 0\n v_mov_b32 v221, 0\n v_mov_b32 v222, 0\n v_mov_b32 v223, 0\n"           \
+      "v_mov_b32 v224, 0\n v_mov_b32 v225, 0\n v_mov_b32 v226, 0\n v_mov_b32 v227, 0\n"           \
+      "v_mov_b32 v228, 0\n v_mov_b32 v229, 0\n v_mov_b32 v230, 0\n v_mov_b32 v231, 0\n"           \
+      "v_mov_b32 v232, 0\n v_mov_b32 v233, 0\n v_mov_b32 v234, 0\n v_mov_b32 v235, 0\n"           \
+      "v_mov_b32 v236, 0\n v_mov_b32 v237, 0\n v_mov_b32 v238, 0\n v_mov_b32 v239, 0\n"           \
+      "v_mov_b32 v180, 1.0\n"                                                                     \
+      "v_mov_b32 v204, %[one]\n v_mov_b32 v205, %[one]\n v_mov_b32 v206, %[one]\n v_mov_b32 v207, %[one]\n" \
+      "s_nop 15\n"                                                                                \
+      "1:\n"                                                                                      \
+      "v_cvt_pk_f16_f32 v200, v180, v180\n v_cvt_pk_f16_f32 v201, v180, v180\n v_cvt_pk_f16_f32 v202, v180, v180\n v_cvt_pk_f16_f32 v203, v180, v180\n" \
+      "v_cvt_pkrtz_f16_f32 v196, v180, v180\n v_cvt_pkrtz_f16_f32 v197, v180, v180\n v_cvt_pkrtz_f16_f32 v198, v180, v180\n v_cvt_pkrtz_f16_f32 v199, v180, v180\n" \
+      "s_nop 0\n"                                                                                 \
+      "v_mfma_f32_32x32x16_f16 v[208:223], v[204:207], v[200:203], v[208:223]\n"                  \
+      "v_cvt_pk_f16_f32 v192, v180, v180\n v_cvt_pk_f16_f32 v193, v180, v180\n"                   \
+      "v_mfma_f32_32x32x16_f16 v[224:239], v[204:207], v[196:199], v[224:239]\n"                  \
+      "v_cvt_pk_f16_f32 v194, v180, v180\n v_cvt_pk_f16_f32 v195, v180, v180\n"                   \
+      "v_mov_b32 v200, %[two]\n v_mov_b32 v201, %[two]\n"                                         \
+      "s_nop 0\n"                                                                                 \
+      "v_mfma_f32_32x32x16_f16 v[208:223], v[192:195], v[196:199], v[208:223]\n"                  \
+      GAP                                                                                         \
+      "v_mov_b32 v196, %[two]\n v_mov_b32 v197, %[two]\n v_mov_b32 v198, %[two]\n v_mov_b32 v199, %[two]\n" \
+      "v_mov_b32 v192, %[two]\n v_mov_b32 v193, %[two]\n v_mov_b32 v194, %[two]\n v_mov_b32 v195, %[two]\n" \
+      "v_mov_b32 v202, %[two]\n v_mov_b32 v203, %[two]\n"                                         \
+      "s_sub_u32 s40, s40, 1\n s_cmp_lg_u32 s40, 0\n s_cbranch_scc1 1b\n"                          \
+      "s_nop 15\n s_nop 15\n"                                                                     \
+      "v_mov_b32 %[o0], v208\n v_mov_b32 %[o1], v223\n v_mov_b32 %[o2], v224\n v_mov_b32 %[o3], v239\n" \
+      : [o0] "=v"(o[0]), [o1] "=v"(o[1]), [o2] "=v"(o[2]), [o3] "=v"(o[3])                         \
+      : [iters] "s"(iters), [one] "s"(one), [two] "s"(two)                                        \
+      : "s40", "scc", "v180", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", \
+        "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210",  \
+        "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",   \
+        "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236",   \
+        "v237", "v238", "v239")
+
 #define AGGRESSOR()                                                                               \
   asm volatile(                                                                                   \
       "s_mov_b32 s40, %[iters]\n"                                                                 \
@@ -80,6 +125,22 @@
     }                                                                                             \
   }
 
+#define KERNEL3(NAME, GAP)                                                                        \
+  __global__ __launch_bounds__(512) void NAME(float* out, int iters_, int aggr) {                 \
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                            \
+    const int iters = __builtin_amdgcn_readfirstlane(wave < 4 ? iters_ : 3 * iters_);             \
+    const unsigned one = 0x3c003c00u, two = 0x40004000u;                                          \
+    float o[4] = {0.f, 0.f, 0.f, 0.f};                                                            \
+    if (wave < 4) {                                                                               \
+      TRIPLE(GAP);                                                                                \
+      float* dst = out + ((size_t)blockIdx.x * 4 + wave) * 256 + (threadIdx.x & 63) * 4;          \
+      dst[0] = o[0] * 0.5f; dst[1] = o[1] * 0.5f; dst[2] = o[2]; dst[3] = o[3];                   \
+    } else if (aggr) {                                                                            \
+      AGGRESSOR();                                                                                \
+      if (o[0] == 12345.f) out[0] = o[0];                                                         \
+    }                                                                                             \
+  }
+
 #define N0 ""
 #define N1 "s_nop 0\n"
 #define N2 "s_nop 1\n"
@@ -98,6 +159,10 @@ FAMILY(mix, PROD_MIX)
 KERNEL(k_war0, PROD_MOV, N64, N0)
 KERNEL(k_war1, PROD_MOV, N64, N1)
 
+KERNEL3(k_triple0, N0)
+KERNEL3(k_triple1, N1)
+KERNEL3(k_triple8, N8)
+
 typedef void (*kern_t)(float*, int, int);
 struct Case { const char* name; kern_t k; };
 
@@ -110,7 +175,9 @@ int main() {
                    {T " 3 states", k_##P##3}, {T " 4 states", k_##P##4}
   Case cases[] = {ROWS(mov, "v_mov_b32"), ROWS(cvtpk, "v_cvt_pk_f16_f32"), ROWS(pkrtz, "v_cvt_pkrtz_f16_f32"),
                   ROWS(pkmul, "v_pk_mul_f32"), ROWS(mix, "v_fma_mixlo/hi_f16"),
-                  {"MFMA -> v_mov_b32 of its B operand, 0 states", k_war0}, {"MFMA -> v_mov_b32 1 state", k_war1}};
+                  {"MFMA -> v_mov_b32 of its B operand, 0 states", k_war0}, {"MFMA -> v_mov_b32 1 state", k_war1},
+                  {"split3 triple, sources rewritten 0 states after", k_triple0}, {"split3 triple, 1 state", k_triple1},
+                  {"split3 triple, 8 states", k_triple8}};
   for (int aggr = 0; aggr < 2; ++aggr)
     for (auto& c : cases) {
       long bad = 0, quarter[4] = {0, 0, 0, 0};
