@@ -27,12 +27,15 @@ def model():
     return pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
 
 
-@pytest.mark.parametrize('precision,tile,rounds', [('f32_split_f16', 64, 400), ('f32_split_qk16', 64, 300),
-                                                    ('f16', 64, 400), ('bf16', 64, 150),
-                                                    ('f32_split_f16', 32, 300), ('f16', 32, 150), ('f32', 32, 40)])
-def test_forward_is_a_function_of_its_inputs(model, precision, tile, rounds):
+@pytest.mark.parametrize('precision,tile,rounds,attention',
+                         [('f32_split_f16', 64, 400, 'linear'), ('f32_split_qk16', 64, 300, 'linear'),
+                          ('f16', 64, 400, 'linear'), ('bf16', 64, 150, 'linear'),
+                          ('f32_split_f16', 32, 300, 'linear'), ('f16', 32, 150, 'linear'), ('f32', 32, 40, 'linear'),
+                          ('f32_split_f16', 32, 100, 'full')])   # (the all-pairs mode's MFMA triples are fenced too)
+def test_forward_is_a_function_of_its_inputs(model, precision, tile, rounds, attention):
     dev = torch.device('cuda', 0)
-    eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision=precision, enc_tile=tile)
+    eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision=precision, enc_tile=tile,
+                            attention=attention)
     gen = torch.Generator().manual_seed(1)
     cases = []
     for n, h1, w1, h2, w2 in SHAPES:
@@ -55,3 +58,19 @@ def test_forward_is_a_function_of_its_inputs(model, precision, tile, rounds):
             if bad:
                 differing.append((rnd, SHAPES[ci], bad, float((out['box1'] - refs[ci]['box1']).abs().max())))
     assert not differing, f'{len(differing)} of {runs} forwards differ from the first of their shape: {differing[:5]}'
+
+
+def test_neck_is_a_function_of_its_inputs():
+    """The same for the HIP neck: three map sizes interleaved."""
+    from oracle import oetr_oracle as orc
+    dev = torch.device('cuda', 0)
+    neck = pkg.NeckEngine(orc.make_neck_weights(8), device=dev)
+    maps = [orc.make_backbone_features(72, 1, 6, 10).to(dev), orc.make_backbone_features(73, 8, 40, 40).to(dev),
+            orc.make_backbone_features(74, 3, 26, 34).to(dev)]
+    refs = [neck.forward(m).clone() for m in maps]
+    differing = []
+    for rnd in range(60):
+        for i, m in enumerate(maps):
+            if not torch.equal(neck.forward(m), refs[i]):
+                differing.append((rnd, i))
+    assert not differing, f'{len(differing)} of 180 neck forwards differ: {differing[:5]}'
