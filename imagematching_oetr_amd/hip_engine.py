@@ -434,6 +434,8 @@ class HotPathEngine:
         if attention != 'linear':
             _check(self.lib, self.lib.oetr_set_attention(self._h, self.ATTENTIONS[attention]),
                    'oetr_set_attention')
+        if os.environ.get('OETR_STATE_PREREDUCE'):      # tuning knob for A/B runs (bench.py, tools/)
+            self.set_state_prereduce(int(os.environ['OETR_STATE_PREREDUCE']))
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -451,10 +453,12 @@ class HotPathEngine:
     def _current_ws(self):
         return self._ws.get(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def set_state_prereduce(self, on):
-        """``oetr_set_state_prereduce``: partial linear-attention states summed once per image in a
-        launch of their own (bit-identical results; measured neutral / slower: default off)."""
-        _check(self.lib, self.lib.oetr_set_state_prereduce(self._h, int(bool(on))), 'oetr_set_state_prereduce')
+    def set_state_prereduce(self, mode):
+        """``oetr_set_state_prereduce``: partial linear-attention states summed once per image
+        instead of in every consuming workgroup - 0 off, 1 in a launch of their own, 2 inside
+        the producing launch by the last workgroup of the image to finish (bit-identical
+        results in every setting)."""
+        _check(self.lib, self.lib.oetr_set_state_prereduce(self._h, int(mode)), 'oetr_set_state_prereduce')
 
     def query_flags(self, clear=True):
         """Status word of the CURRENT STREAM's workspace (``oetr_query_flags``): synchronises

@@ -199,11 +199,13 @@ oetr_status oetr_read_flags_async(oetr_handle h, void *workspace,
  * concurrent forward calls. */
 oetr_status oetr_set_encoder_tile(oetr_handle h, int rows);
 
-/* 1: reduce each image's per-tile partial linear-attention states (the all-to-all of
- * LinearAttention, reference src/models/linear_attention.py:45-46) once, in a small launch
- * between the encoder launches, instead of in every consuming workgroup.  Bit-identical
- * results (same summation order).  Default 0: measured neutral for overlapped batches and
- * slower for serial ones on MI355X.  Mutates the handle like the other setters. */
+/* Reduce each image's per-tile partial linear-attention states (the all-to-all of
+ * LinearAttention, reference src/models/linear_attention.py:45-46) ONCE instead of in every
+ * consuming workgroup.  0: off.  1: in a small launch between the encoder launches (measured
+ * neutral for overlapped batches, slower for serial ones on MI355X).  2: inside the launch that
+ * writes the partials, by the last workgroup of an image to finish (agent-scope release / ticket
+ * / acquire; arrival counters in the workspace, zeroed per call).  Bit-identical results in every
+ * setting (same summation order).  Mutates the handle like the other setters. */
 oetr_status oetr_set_state_prereduce(oetr_handle h, int on);
 
 /* Attention core of the eight encoder layers.  The reference builds
