@@ -1277,8 +1277,8 @@ oetr_status oetr_set_attention(oetr_handle h, oetr_attention mode) {
     return fail(OETR_ERR_BAD_ARG, "oetr_set_attention: unknown mode");
   if (mode == OETR_ATTENTION_FULL && h->policy != 0)
     return fail(OETR_ERR_UNSUPPORTED, "attention 'full' is not built for OETR_DTYPE_F32_SPLIT_QK16");
-  if (mode == OETR_ATTENTION_FULL && !gm_f16_range(h->mode))
-    return fail(OETR_ERR_UNSUPPORTED, "attention 'full' is built for OETR_DTYPE_F32_SPLIT_F16 and OETR_DTYPE_F16");
+  if (mode == OETR_ATTENTION_FULL && !gm_f16_range(h->mode) && h->mode != GM_F32)
+    return fail(OETR_ERR_UNSUPPORTED, "attention 'full' is built for OETR_DTYPE_F32_SPLIT_F16, OETR_DTYPE_F16 and OETR_DTYPE_F32");
   h->attn_full = mode == OETR_ATTENTION_FULL;
   return OETR_OK;
 }

@@ -232,6 +232,66 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
   const float* vr = p.vt_in + p.vt_off[ss] + ((size_t)n * C + head * HD + col) * p.lpad[ss] + 4 * half;
   constexpr float NEG = -1.0e30f;   // finite "minus infinity": exp_neg(NEG - m) == 0, no NaN
   const float temp = 0.17677669529663687f;   // 1 / sqrt(32)
+  if constexpr (MODE == GM_F32) {
+    // Exact-fp32 products (v_mfma_f32_32x32x2_f32; the build an f16-based handle falls back to
+    // when an operand leaves the f16 range).  Same register geometry as below: S^T rows = keys
+    // (crow(r, half)), columns = queries; the k-slot of step j is channel 16 half + j for
+    // S^T = K Q^T and key crow(j, half) for O^T = V^T P - so P feeds the second product from
+    // the accumulator registers as it stands.
+    f32x4 qf[4];
+    {
+      const float* qp = p.qp + (row_base + min(col, nvalid - 1)) * C + head * HD + 16 * half;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qf[i] = *reinterpret_cast<const f32x4*>(qp + 4 * i);
+    }
+    const float* kb32 = p.kbuf_in + ((size_t)g.row0[ss] + (size_t)n * S) * C + head * HD + 16 * half;
+    auto load32 = [&](int k0, f32x4 (&kk)[4], f32x4 (&vv)[4]) {
+      const float* kr = kb32 + (size_t)min(k0 + col, S - 1) * C;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kk[i] = *reinterpret_cast<const f32x4*>(kr + 4 * i);
+        vv[i] = *reinterpret_cast<const f32x4*>(vr + k0 + 8 * i);   // keys k0 + 8 i + 4 half + 0..3 = crow(4 i + .., half)
+      }
+    };
+    f32x16 o = {0};
+    float m_run = NEG, l_run = 0.f;
+    f32x4 kk[4], vv[4];
+    load32(0, kk, vv);
+    for (int k0 = 0; k0 < S; k0 += 32) {
+      f32x4 kc[4], vc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { kc[i] = kk[i]; vc[i] = vv[i]; }
+      if (k0 + 32 < S) load32(k0 + 32, kk, vv);
+      f32x16 st = {0};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[j >> 2][j & 3], qf[j >> 2][j & 3], st, 0, 0, 0);
+      float mt = NEG;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = (k0 + crow(r, half) < S) ? st[r] * temp : NEG;
+        mt = fmaxf(mt, st[r]);
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = exp_neg(fminf(m_run - m_new, 0.f));
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = exp_neg(fminf(st[r] - m_new, 0.f)); ps += st[r]; }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[j >> 2][j & 3], st[j], o, 0, 0, 0);
+    }
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      S1.put4(col, head * HD + 8 * g4 + 4 * half,
+              f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv});
+    return;
+  } else {
   f32x4 qh[2], ql[2];
   {
     const float* qp = p.qp + (row_base + min(col, nvalid - 1)) * C + head * HD + 8 * half;
@@ -300,6 +360,7 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
   for (int g4 = 0; g4 < 4; ++g4)   // registers 4*g4.. = d rows 8*g4 + 4*half + 0..3 of query `col`
     S1.put4(col, head * HD + 8 * g4 + 4 * half,
             f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv});
+  }   // f16-based modes
 }
 
 // ---------------------------------------------------------------------------
@@ -399,7 +460,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
   constexpr bool SPLIT = gm_half(MODE);  // GEMM operands live in 16-bit LDS planes
   using SP = SitePolicy<POL>;            // arithmetic per GEMM site (two-plane mode, NW = 8)
   static_assert(POL == 0 || (gm_planes(MODE) == 2 && NW == 8 && !FULL), "policies: split mode, one n-tile per wave");
-  static_assert(!FULL || (gm_f16_range(MODE) && NW == 8), "full attention: f16-based modes, one head per wave");
+  static_assert(!FULL || ((gm_f16_range(MODE) || MODE == GM_F32) && NW == 8),
+                "full attention: f16-based modes or exact fp32, one head per wave");
   using Cfg = EncCfg<NW>;
   constexpr int NT = Cfg::NT, THREADS = Cfg::THREADS, WC = Cfg::WC, TPR = Cfg::TPR, F4 = Cfg::F4;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
@@ -1499,8 +1561,9 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
     }
   }
   if (p.attn_full) {
-    if constexpr (gm_f16_range(MODE) && NW == 8) {
-#define OETR_LAUNCHF(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, NW, true>), grid, dim3(64 * NW), 0, s, p)
+    // (the exact-fp32 build runs 8 waves here too: one head per wave in the attention core)
+    if constexpr ((gm_f16_range(MODE) && NW == 8) || MODE == GM_F32) {
+#define OETR_LAUNCHF(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, 8, true>), grid, dim3(64 * 8), 0, s, p)
       if (has_b) {
         if (tail == 0) OETR_LAUNCHF(true, 0);
         else if (tail == 1) OETR_LAUNCHF(true, 1);

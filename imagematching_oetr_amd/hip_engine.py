@@ -360,8 +360,8 @@ class HotPathEngine:
         ``enc_tile``: token rows per encoder workgroup, None = auto, 32 or 64
         (``oetr_set_encoder_tile``).  ``attention``: 'linear' (what the reference
         builds, ``src/model.py:82-84``) or 'full' = ``EncoderLayer(attention='full')``
-        (``transformer.py:86-89``): all-pairs softmax attention, f16-based precisions
-        only."""
+        (``transformer.py:86-89``): all-pairs softmax attention, precisions 'f32_split_f16',
+        'f16' and 'f32' (the exact build an overflowing batch is re-run on)."""
         self.lib = load_library()
         if precision not in self.PRECISIONS:
             raise ValueError(f'precision must be one of {sorted(self.PRECISIONS)}')

@@ -252,12 +252,9 @@ class OETR(nn.Module):
         main = self.engine()
         if self.hip_precision == 'f32':
             return main
-        if self.hip_attention != 'linear':
-            raise OetrRangeError("a GEMM operand reached |x| >= 65504 and attention='full' has no "
-                                 'exact-fp32 build to fall back to')
         if self._engine_f32 is None:
             self._engine_f32 = HotPathEngine(self.hot_path_state(), device=main.device,
-                                             precision='f32')
+                                             precision='f32', attention=self.hip_attention)
         return self._engine_f32
 
     def neck_engine(self):

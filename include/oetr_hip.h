@@ -216,7 +216,8 @@ oetr_status oetr_set_state_prereduce(oetr_handle h, int on);
  * src/models/linear_attention.py:53-87) - the all-pairs HW x HW correlation, computed
  * flash style on the f16 matrix pipe (fp32-class operand split), never materialised.
  * Same weights, same state dict.  FULL exists for the f16-based dtypes
- * (F32_SPLIT_F16, F16), uses 32-token workgroups and a larger workspace (query
+ * (F32_SPLIT_F16, F16) and for F32 (exact fp32 MFMA products: the build an out-of-range
+ * batch is re-run on), uses 32-token workgroups and a larger workspace (query
  * oetr_workspace_bytes after the call).  Mutates the handle like the other setters. */
 typedef enum { OETR_ATTENTION_LINEAR = 0, OETR_ATTENTION_FULL = 1 } oetr_attention;
 oetr_status oetr_set_attention(oetr_handle h, oetr_attention mode);

@@ -42,7 +42,7 @@ def test_oracle_full_attention_matches_reference(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('precision', ['f32_split_f16', 'f16'])
+@pytest.mark.parametrize('precision', ['f32_split_f16', 'f16', 'f32'])
 @pytest.mark.parametrize('path', CASES, ids=lambda p: p.split('fullattn_')[-1][:-4])
 def test_hip_full_attention_mode_vs_reference_golden(path, precision, gpu):
     from imagematching_oetr_amd import HotPathEngine
@@ -53,7 +53,7 @@ def test_hip_full_attention_mode_vs_reference_golden(path, precision, gpu):
     dev = [t.to(gpu) for t in (f1, f2, p1, p2)]
     out = eng.forward(*dev, im1, im2, stages=True)
     assert eng.query_flags() == 0
-    if precision == 'f32_split_f16':          # fp32-class: the fp32 tolerances of the parity suite
+    if precision in ('f32_split_f16', 'f32'):  # fp32-class / exact fp32: the fp32 tolerances of the parity suite
         for s in ('1', '2'):
             step = int(g[f'memory{s}_step'])
             assert maxerr(out['memory' + s][:, ::step], g['memory' + s]) <= TOL['memory']
@@ -79,19 +79,43 @@ def test_hip_full_attention_mode_vs_reference_golden(path, precision, gpu):
 def test_full_attention_mode_contract(gpu):
     from imagematching_oetr_amd import HotPathEngine, OetrError
     w = orc.make_hot_weights(0)
-    for prec in ('f32', 'bf16'):
+    for prec in ('bf16', 'f32_split_qk16'):
         with pytest.raises(OetrError, match='full'):
             HotPathEngine(w, device=gpu, precision=prec, attention='full')
     with pytest.raises(ValueError):
         HotPathEngine(w, device=gpu, attention='sparse')
     # single token per image, ragged tiles, 1600 keys
-    eng = HotPathEngine(w, device=gpu, attention='full')
-    for g1, g2 in (((1, 1), (1, 1)), ((1, 7), (33, 1)), ((5, 5), (40, 40))):
-        f1, f2 = orc.make_features(31, 2, *g1), orc.make_features(32, 2, *g2)
-        p1, p2 = orc.position_table(*g1), orc.position_table(*g2)
-        im1, im2 = (g1[0] * 32, g1[1] * 32), (g2[0] * 32, g2[1] * 32)
-        out = eng.forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p2.to(gpu), im1, im2, stages=True)
-        ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True, attention=orc.full_attention)
-        assert maxerr(out['memory1'], ref['memory1']) <= TOL['memory'], (g1, g2)
-        assert maxerr(out['memory2'], ref['memory2']) <= TOL['memory'], (g1, g2)
-        assert maxerr(out['box1'], ref['box1']) <= TOL['box']
+    for prec in ('f32_split_f16', 'f32'):
+      eng = HotPathEngine(w, device=gpu, attention='full', precision=prec)
+      for g1, g2 in (((1, 1), (1, 1)), ((1, 7), (33, 1)), ((5, 5), (40, 40))):
+          f1, f2 = orc.make_features(31, 2, *g1), orc.make_features(32, 2, *g2)
+          p1, p2 = orc.position_table(*g1), orc.position_table(*g2)
+          im1, im2 = (g1[0] * 32, g1[1] * 32), (g2[0] * 32, g2[1] * 32)
+          out = eng.forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p2.to(gpu), im1, im2, stages=True)
+          ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True, attention=orc.full_attention)
+          assert maxerr(out['memory1'], ref['memory1']) <= TOL['memory'], (g1, g2)
+          assert maxerr(out['memory2'], ref['memory2']) <= TOL['memory'], (g1, g2)
+          assert maxerr(out['box1'], ref['box1']) <= TOL['box']
+
+
+@pytest.mark.gpu
+def test_module_reruns_an_overflowing_full_attention_batch_in_exact_fp32(gpu):
+    """``attention='full'`` has an exact-fp32 build too (``OETR_DTYPE_F32``): an out-of-range batch
+    is answered with ITS boxes, as in the linear mode (reference ``transformer.py:86-89`` is fp32)."""
+    import imagematching_oetr_amd as pkg
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    w = orc.make_hot_weights(5, sharpen=True)
+    sd = model.state_dict(); sd.update(w); model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    model.hip_attention = 'full'
+    model.invalidate_engine()
+    f1, f2 = orc.make_features(41, 2, 8, 10) * 4.0e5, orc.make_features(42, 2, 10, 8)
+    p1, p2 = orc.position_table(8, 10), orc.position_table(10, 8)
+    dev = [t.to(gpu) for t in (f1, f2, p1, p2)]
+    b1, b2 = model.boxes_from_features(*dev, (256, 320), (320, 256))
+    model.hip_flush()
+    exact = pkg.HotPathEngine(w, device=gpu, precision='f32', attention='full')
+    e1, e2 = exact.forward(*dev, (256, 320), (320, 256))
+    assert torch.equal(b1, e1) and torch.equal(b2, e2) and torch.isfinite(b1).all()
+    assert model._engine_f32 is not None and model._engine_f32.attention == 'full'

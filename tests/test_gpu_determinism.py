@@ -31,7 +31,8 @@ def model():
                          [('f32_split_f16', 64, 400, 'linear'), ('f32_split_qk16', 64, 300, 'linear'),
                           ('f16', 64, 400, 'linear'), ('bf16', 64, 150, 'linear'),
                           ('f32_split_f16', 32, 300, 'linear'), ('f16', 32, 150, 'linear'), ('f32', 32, 40, 'linear'),
-                          ('f32_split_f16', 32, 100, 'full')])   # (the all-pairs mode's MFMA triples are fenced too)
+                          ('f32_split_f16', 32, 100, 'full'),     # (the all-pairs mode's MFMA triples are fenced too)
+                          ('f32', 32, 20, 'full')])
 def test_forward_is_a_function_of_its_inputs(model, precision, tile, rounds, attention):
     dev = torch.device('cuda', 0)
     eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision=precision, enc_tile=tile,
