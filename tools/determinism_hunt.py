@@ -18,7 +18,7 @@ tile = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 60.0
 if len(sys.argv) > 4:
     hip_engine._lib = hip_engine.load_library(str(REPO / 'tools' / 'variants' / sys.argv[4] / 'liboetr_hip.so'))
-eng = pkg.HotPathEngine(w, device=dev, precision=prec, enc_tile=tile)
+eng = pkg.HotPathEngine(w, device=dev, precision=prec, enc_tile=tile, attention=os.environ.get('HUNT_ATTENTION', 'linear'))
 if os.environ.get('HUNT_PREREDUCE'): eng.set_state_prereduce(int(os.environ['HUNT_PREREDUCE']))
 shapes = [(2, 20, 20, 20, 20), (8, 20, 20, 20, 20), (2, 10, 10, 6, 20), (3, 25, 25, 25, 25), (1, 32, 32, 32, 32)]
 if os.environ.get('HUNT_SHAPES'):
