@@ -3,7 +3,7 @@
 // SIMD keeps the matrix pipe busy?   Build: hipcc --offload-arch=gfx950 -O2 -o /tmp/probe tools/mfma_hazard_probe.hip
 //
 // One workgroup of 8 waves per CU: waves 0-3 (one per SIMD) are the victims, waves 4-7 share
-// their SIMDs and (AGGR = 1) issue MFMAs back to back.  A victim repeats
+// their SIMDs and issue MFMAs back to back (1), 1-KB global loads (2) or both (3).  A victim repeats
 //     B <- 1.0 (4 x v_mov)   s_nop PRE   D += ones x B (one MFMA)   s_nop POST   B <- 2.0 (4 x v_mov)
 // so D must end at exactly 16 * iters in every lane; any read of a 2.0 (an operand not yet
 // written, or already overwritten) shows as a larger value in that lane.
@@ -109,8 +109,34 @@
         "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", \
         "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163")
 
+// Sibling waves that keep the VECTOR-MEMORY return path busy instead (2), or both pipes (3): a
+// stream of 1-KB global_load_dwordx4 (L2-resident buffer) landing in the sibling wave's VGPRs
+// while the victim's MFMA fetches operands a VALU instruction has just written.
+#define AGGRESSOR_LD(MFMAS)                                                                       \
+  asm volatile(                                                                                   \
+      "s_mov_b32 s40, %[iters]\n"                                                                 \
+      "v_mov_b32 v91, %[voff]\n"                                                                  \
+      "1:\n"                                                                                      \
+      "global_load_dwordx4 v[100:103], v91, %[base]\n"                                            \
+      "global_load_dwordx4 v[104:107], v91, %[base] offset:1024\n"                                \
+      "global_load_dwordx4 v[108:111], v91, %[base] offset:2048\n"                                \
+      "global_load_dwordx4 v[112:115], v91, %[base] offset:3072\n"                                \
+      MFMAS                                                                                       \
+      "v_add_u32 v91, 0x2000, v91\n v_and_b32 v91, 0x3fffff, v91\n"                               \
+      "s_waitcnt vmcnt(2)\n"                                                                      \
+      "s_sub_u32 s40, s40, 1\n s_cmp_lg_u32 s40, 0\n s_cbranch_scc1 1b\n"                          \
+      "s_waitcnt vmcnt(0)\n s_nop 15\n v_mov_b32 %[o0], v100\n"                                   \
+      : [o0] "=v"(o[0])                                                                           \
+      : [iters] "s"(iters), [voff] "v"((threadIdx.x & 63) * 16), [base] "s"(lbuf)                 \
+      : "s40", "scc", "memory", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101",  \
+        "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", \
+        "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", \
+        "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", \
+        "v141", "v142", "v143", "v144", "v145", "v146", "v147")
+#define LD_MFMAS "v_mfma_f32_32x32x16_f16 v[116:131], v[92:95], v[96:99], v[116:131]\n v_mfma_f32_32x32x16_f16 v[132:147], v[92:95], v[96:99], v[132:147]\n"
+
 #define KERNEL(NAME, PROD, PRE, POST)                                                                  \
-  __global__ __launch_bounds__(512) void NAME(float* out, int iters_, int aggr) {                 \
+  __global__ __launch_bounds__(512) void NAME(float* out, int iters_, int aggr, const float* lbuf) {                 \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                            \
     const int iters = __builtin_amdgcn_readfirstlane(wave < 4 ? iters_ : 2 * iters_);             \
     const unsigned one = 0x3c003c00u, two = 0x40004000u;                                          \
@@ -120,13 +146,13 @@
       float* dst = out + ((size_t)blockIdx.x * 4 + wave) * 256 + (threadIdx.x & 63) * 4;          \
       dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];                                 \
     } else if (aggr) {                                                                            \
-      AGGRESSOR();                                                                                \
+      if (aggr == 1) { AGGRESSOR(); } else if (aggr == 2) { AGGRESSOR_LD(""); } else { AGGRESSOR_LD(LD_MFMAS); }  \
       if (o[0] == 12345.f) out[0] = o[0];                                                         \
     }                                                                                             \
   }
 
 #define KERNEL3(NAME, GAP)                                                                        \
-  __global__ __launch_bounds__(512) void NAME(float* out, int iters_, int aggr) {                 \
+  __global__ __launch_bounds__(512) void NAME(float* out, int iters_, int aggr, const float* lbuf) {                 \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                            \
     const int iters = __builtin_amdgcn_readfirstlane(wave < 4 ? iters_ : 3 * iters_);             \
     const unsigned one = 0x3c003c00u, two = 0x40004000u;                                          \
@@ -136,7 +162,7 @@
       float* dst = out + ((size_t)blockIdx.x * 4 + wave) * 256 + (threadIdx.x & 63) * 4;          \
       dst[0] = o[0] * 0.5f; dst[1] = o[1] * 0.5f; dst[2] = o[2]; dst[3] = o[3];                   \
     } else if (aggr) {                                                                            \
-      AGGRESSOR();                                                                                \
+      if (aggr == 1) { AGGRESSOR(); } else if (aggr == 2) { AGGRESSOR_LD(""); } else { AGGRESSOR_LD(LD_MFMAS); }  \
       if (o[0] == 12345.f) out[0] = o[0];                                                         \
     }                                                                                             \
   }
@@ -163,7 +189,7 @@ KERNEL3(k_triple0, N0)
 KERNEL3(k_triple1, N1)
 KERNEL3(k_triple8, N8)
 
-typedef void (*kern_t)(float*, int, int);
+typedef void (*kern_t)(float*, int, int, const float*);
 struct Case { const char* name; kern_t k; };
 
 int main() {
@@ -171,6 +197,9 @@ int main() {
   float* d;
   hipMalloc(&d, (size_t)blocks * 4 * 256 * sizeof(float));
   std::vector<float> h((size_t)blocks * 4 * 256);
+  float* lbuf;
+  hipMalloc(&lbuf, (size_t)8 << 20);
+  hipMemset(lbuf, 0, (size_t)8 << 20);
 #define ROWS(P, T) {T " -> MFMA, 0 states between", k_##P##0}, {T " 1 state", k_##P##1}, {T " 2 states", k_##P##2}, \
                    {T " 3 states", k_##P##3}, {T " 4 states", k_##P##4}
   Case cases[] = {ROWS(mov, "v_mov_b32"), ROWS(cvtpk, "v_cvt_pk_f16_f32"), ROWS(pkrtz, "v_cvt_pkrtz_f16_f32"),
@@ -178,13 +207,13 @@ int main() {
                   {"MFMA -> v_mov_b32 of its B operand, 0 states", k_war0}, {"MFMA -> v_mov_b32 1 state", k_war1},
                   {"split3 triple, sources rewritten 0 states after", k_triple0}, {"split3 triple, 1 state", k_triple1},
                   {"split3 triple, 8 states", k_triple8}};
-  for (int aggr = 0; aggr < 2; ++aggr)
+  for (int aggr = 0; aggr < 4; ++aggr)
     for (auto& c : cases) {
       long bad = 0, quarter[4] = {0, 0, 0, 0};
       float worst = 0.f;
       for (int rep = 0; rep < 3; ++rep) {
         hipMemset(d, 0, h.size() * sizeof(float));
-        hipLaunchKernelGGL(c.k, dim3(blocks), dim3(512), 0, 0, d, iters, aggr);
+        hipLaunchKernelGGL(c.k, dim3(blocks), dim3(512), 0, 0, d, iters, aggr, lbuf);
         if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
         hipMemcpy(h.data(), d, h.size() * sizeof(float), hipMemcpyDeviceToHost);
         const float want = 16.0f * iters;
@@ -194,7 +223,7 @@ int main() {
             if (h[i] - want > worst) worst = h[i] - want;
           }
       }
-      printf("%-48s sibling MFMA stream %d: %8ld wrong values of %zu  (lanes 0-15: %ld, 16-31: %ld, 32-47: %ld, 48-63: %ld; worst excess %.0f)\n",
+      printf("%-48s sibling stream %d (0 none, 1 MFMA, 2 loads, 3 loads+MFMA): %8ld wrong values of %zu  (lanes 0-15: %ld, 16-31: %ld, 32-47: %ld, 48-63: %ld; worst excess %.0f)\n",
              c.name, aggr, bad, 3 * h.size(), quarter[0], quarter[1], quarter[2], quarter[3], worst);
     }
   return 0;
