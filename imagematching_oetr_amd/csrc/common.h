@@ -567,7 +567,11 @@ __device__ __forceinline__ void split8(const f32x4& a0, const f32x4& a1, f32x4& 
 #endif
 #define OETR_STR2(x) #x
 #define OETR_STR(x) OETR_STR2(x)
+#ifdef OETR_SPLIT3_PAD_OFF   // (tools/kv_state_probe.hip: the unfenced form, for the record)
+template <bool FENCE = false>
+#else
 template <bool FENCE = true>
+#endif
 __device__ __forceinline__ void mma16_split3(const f32x4& ah, const f32x4& al, const f32x4& bh,
                                              const f32x4& bl, f32x16& main, f32x16& cross) {
   if constexpr (FENCE) {
