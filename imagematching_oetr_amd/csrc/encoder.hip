@@ -41,6 +41,9 @@
 #ifndef OETR_SPLIT_STATE
 #define OETR_SPLIT_STATE 0
 #endif
+#ifndef OETR_STATE_PIPELINED
+#define OETR_STATE_PIPELINED 1
+#endif
 #ifndef OETR_APPLY_FENCE
 #define OETR_APPLY_FENCE 1
 #endif
@@ -126,6 +129,28 @@ __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& ac
 #pragma unroll
     for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
   } else {
+#if OETR_STATE_PIPELINED
+    // One f32 MFMA (64 matrix-pipe cycles) per accumulator register: the operands of register
+    // r + 1 - phi, row mask, 1/S - are computed while the MFMA of register r runs (a fence per
+    // step keeps hipcc from batching the exps; same operations in the same order: same bits).
+    auto operands = [&](int r, float& k, float& v) {
+      const float m = crow(r, half) < nvalid ? 1.0f : 0.0f;
+      const float x = accK[r];
+      k = (skip_phi ? x : elu1(x)) * m;
+      v = accV[r] * (inv_len * m);
+      ksum += k;
+    };
+    float kc, vc;
+    operands(0, kc, vc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float kn = 0.f, vn = 0.f;
+      if (r + 1 < 16) operands(r + 1, kn, vn);
+      kv = __builtin_amdgcn_mfma_f32_32x32x2f32(kc, vc, kv, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      kc = kn; vc = vn;
+    }
+#else
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += 4) {
       float k[4], v[4];
@@ -141,6 +166,7 @@ __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& ac
       for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
   }
 }
 
@@ -967,6 +993,31 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
 #pragma unroll
     for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
   } else {
+#if OETR_STATE_PIPELINED
+    // (see kv_state_32: the operands of the next register under the current f32 MFMA)
+    auto row_tile = [&](auto MT_) {
+      constexpr int mt = decltype(MT_)::value;
+      auto operands = [&](int r, float& k, float& v) {
+        const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
+        const float x = accK[mt][r];
+        k = (elu1(x)) * m;
+        ksum += k;
+        v = accV[mt][r] * (inv_len * m);
+      };
+      float kc, vc;
+      operands(0, kc, vc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float kn = 0.f, vn = 0.f;
+        if (r + 1 < 16) operands(r + 1, kn, vn);
+        kv = __builtin_amdgcn_mfma_f32_32x32x2f32(kc, vc, kv, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        kc = kn; vc = vn;
+      }
+    };
+    row_tile(std::integral_constant<int, 0>{});
+    if (two) row_tile(std::integral_constant<int, 1>{});   // (else: no valid row in the second row tile)
+#else
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       if (mt == 1 && !two) break;  // no valid row in the second row tile
@@ -986,6 +1037,7 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#endif
   }
   ksum += __shfl_xor(ksum, 32, 64);
 }
