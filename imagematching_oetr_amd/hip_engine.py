@@ -277,8 +277,9 @@ class FlagTicket:
     only (an event recorded right behind it) - by the time the next batch is submitted it has
     long completed."""
 
-    def __init__(self, slot, event):
+    def __init__(self, slot, event, owner=None, index=None):
         self._slot, self._event = slot, event
+        self._owner, self._index = owner, index     # graph words: handed back by release()
 
     def ready(self):
         return self._event is None or self._event.query()
@@ -288,40 +289,71 @@ class FlagTicket:
             self._event.synchronize()
         return int(self._slot.item())
 
+    def release(self):
+        """Hand a word captured into a HIP graph back to its reader (the graph was discarded:
+        nothing will write the word again).  No-op for eager tickets."""
+        if self._owner is not None:
+            self._owner._release(self._index)
+            self._owner = None
+
 
 class _FlagReader:
     """Pinned host words for asynchronous status reads, one set per engine: a ring for eager
     calls (each word is consumed before the ring comes round: the deferred check settles
-    batch i when batch i+1 is submitted) and words handed out for good to calls captured into
-    a HIP graph (every replay rewrites them).  Allocated up front - pinning host memory is
-    not allowed while a stream is capturing."""
+    batch i when batch i+1 is submitted) and words handed out to calls captured into a HIP
+    graph (every replay rewrites them) until the ticket is released.  Pinning host memory is
+    not allowed while a stream is capturing, so graph words come in pages allocated OUTSIDE
+    capture: one page up front, another whenever an eager call finds the free list short
+    (``reserve_graph_words``) - an engine that re-captures per shape never runs dry as long
+    as it releases the tickets of discarded graphs or makes an eager call in between."""
 
-    SLOTS, GRAPH_SLOTS = 16, 16
+    SLOTS, GRAPH_PAGE = 16, 16
 
     def __init__(self):
-        self._words = torch.zeros(self.SLOTS + self.GRAPH_SLOTS, dtype=torch.int32).pin_memory()
+        self._words = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
         self._next = 0
-        self._graph_next = 0
+        self._pages = []          # pinned pages of graph words (kept alive here)
+        self._free = []           # (page, index) pairs not handed out
+        self.reserve_graph_words(self.GRAPH_PAGE)
+
+    def reserve_graph_words(self, n):
+        """Make sure at least ``n`` graph words are free (allocates pinned pages; not while
+        a stream is capturing)."""
+        while len(self._free) < n:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise OetrError('graph status words must be reserved outside stream capture')
+            page = torch.zeros(self.GRAPH_PAGE, dtype=torch.int32).pin_memory()
+            self._pages.append(page)
+            self._free += [(len(self._pages) - 1, i) for i in range(self.GRAPH_PAGE)]
+
+    def _release(self, key):
+        self._free.append(key)
 
     def read(self, lib, fn, handle, ws, device, clear):
         capturing = torch.cuda.is_current_stream_capturing()
+        owner = key = None
         if capturing:
-            if self._graph_next >= self.GRAPH_SLOTS:
-                raise OetrError('too many status reads captured into HIP graphs on one engine')
-            i = self.SLOTS + self._graph_next
-            self._graph_next += 1
+            if not self._free:
+                raise OetrError('no free status word for a read captured into a HIP graph: release the '
+                                'tickets of discarded graphs (OETR.hip_graph_release) or reserve more '
+                                'outside capture (reserve_graph_words)')
+            key = self._free.pop(0)
+            slot = self._pages[key[0]][key[1]:key[1] + 1]
+            owner = self
         else:
+            if len(self._free) < self.GRAPH_PAGE // 2:
+                self.reserve_graph_words(self.GRAPH_PAGE)      # top up while pinning is allowed
             i = self._next
             self._next = (self._next + 1) % self.SLOTS
-        slot = self._words[i:i + 1]
+            slot = self._words[i:i + 1]
         if ws is None:
             slot.zero_()
-            return FlagTicket(slot, None)
+            return FlagTicket(slot, None, owner, key)
         with torch.cuda.device(device):
             _check(lib, fn(handle, ws.data_ptr(), slot.data_ptr(), int(bool(clear)), _stream(device)),
                    fn.__name__)
             if capturing:
-                return FlagTicket(slot, None)      # valid once a replay has been synchronised
+                return FlagTicket(slot, None, owner, key)      # valid once a replay has been synchronised
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
         return FlagTicket(slot, ev)

@@ -330,6 +330,7 @@ class OETR(nn.Module):
         ``bb1``/``bb2`` are halves of (one neck call).  Same values as
         ``feature_extraction`` + ``boxes_from_features``, which is also the route taken
         when a range flag trips."""
+        self.hip_flush()          # (idempotent after forward_dummy's: a direct caller's previous batch)
         eng, neck = self.engine(), self.neck_engine()
         n = int(bb1.shape[0])
         hf1, wf1 = int(bb1.shape[2]) // 2, int(bb1.shape[3]) // 2
@@ -379,6 +380,14 @@ class OETR(nn.Module):
         if tripped:
             raise OetrRangeError('a batch replayed from a HIP graph overflowed the f16 operand range: '
                                  're-submit it eagerly (exact-fp32 re-run) or use hip_precision "f32"')
+
+    def hip_graph_release(self):
+        """Forget the status reads of captured graphs (call when those graphs are discarded, e.g.
+        before re-capturing for another shape): their pinned words go back to the engines'
+        free lists, ``hip_graph_check`` starts from an empty list."""
+        for t in self._graph_tickets:
+            t.release()
+        self._graph_tickets = []
 
     def _settle(self, boxes, tickets, rerun):
         if not any(t.value() & FLAG_F16_RANGE for t in tickets):

@@ -75,9 +75,15 @@ class BoxGatherer:
     ``submit(box1, box2)``: every rank holds the same number of pairs (the bench's weak
     scaling).  ``submit(box1, box2, n_pairs=N)``: the ranks hold the contiguous
     ``shard_bounds`` slices of N pairs (sizes differ by at most one); shards are padded to
-    the largest and the padding dropped after the gather, like ``gather_boxes``."""
+    the largest and the padding dropped after the gather, like ``gather_boxes``.
 
-    def __init__(self, group=None):
+    The gather copies VALUES: boxes that come from ``OETR.forward_dummy`` with the deferred
+    range check (``hip_defer_check``, the default) must be settled first - call
+    ``model.hip_flush()`` before ``submit`` (or pass ``settle=model.hip_flush``), otherwise
+    a batch that is corrected in place afterwards leaves its stale boxes on the other ranks."""
+
+    def __init__(self, group=None, settle=None):
+        self.settle = settle
         self.group = group
         self._pending = None
 
@@ -93,6 +99,8 @@ class BoxGatherer:
         return (everyone[:, 0].reshape(n_pairs, 4), everyone[:, 1].reshape(n_pairs, 4))
 
     def submit(self, box1, box2, n_pairs=None):
+        if self.settle is not None:
+            self.settle()
         done = self._finish()
         world = dist.get_world_size(self.group)
         if n_pairs is None or n_pairs % world == 0:
@@ -134,4 +142,9 @@ def forward_sharded(model, image1, image2, group=None):
     else:
         lo, hi = 0, n
     b1, b2 = model.forward_dummy(image1[lo:hi], image2[lo:hi])
+    # forward_dummy defers its f16 range check and corrects a tripped batch IN PLACE later
+    # (OETR.hip_defer_check): settle it before the boxes are copied to the other ranks
+    flush = getattr(model, 'hip_flush', None)
+    if flush is not None:
+        flush()
     return gather_boxes(b1, b2, n, group)

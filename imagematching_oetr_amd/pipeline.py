@@ -115,6 +115,11 @@ def forward_pairs_raw(model, raw_pairs, resize=(640,), grayscale=True, align='di
     res = dict(box0=torch.zeros(n, 4, device=device), box1=torch.zeros(n, 4, device=device),
                scales0=[None] * n, scales1=[None] * n, overlap_scales0=[None] * n,
                overlap_scales1=[None] * n, inp0=[None] * n, inp1=[None] * n)
+    # Boxes are copied into `res` only AFTER the final flush: forward_dummy defers its range
+    # check (OETR.hip_defer_check) and corrects a tripped batch IN PLACE in the tensors it
+    # returned - at the next forward_dummy or at hip_flush() - so a by-value copy taken right
+    # after the call would keep the out-of-range boxes.
+    produced = []      # (result indices, b0, b1, rows of b0 / b1)
     for s in range(0, n, max(1, max_batch)):
         chunk = list(range(s, min(n, s + max_batch)))
         m = len(chunk)
@@ -125,15 +130,13 @@ def forward_pairs_raw(model, raw_pairs, resize=(640,), grayscale=True, align='di
             # one OETR frame for every picture (always, unless resize == [-1]): the reader filled ONE
             # [2m,S,S,3] batch, image0s first - the two halves ARE forward_dummy's inputs, no copy
             b0, b1 = model.forward_dummy(read[0]._batch[:m], read[0]._batch[m:])
-            for k, i in enumerate(chunk):
-                res['box0'][i], res['box1'][i] = b0[k], b1[k]
+            produced.append((chunk, b0, b1, list(range(m))))
         else:   # native-size frames: bucket the pairs by shape
             shapes = [(tuple(a.overlap_inp.shape[1:3]), tuple(b.overlap_inp.shape[1:3])) for a, b in zip(r0, r1)]
             for _, idx in bucket_by_shape(shapes).items():
                 im0, im1 = torch.cat([r0[k].overlap_inp for k in idx]), torch.cat([r1[k].overlap_inp for k in idx])
                 b0, b1 = model.forward_dummy(im0, im1)
-                for j, k in enumerate(idx):
-                    res['box0'][chunk[k]], res['box1'][chunk[k]] = b0[j], b1[j]
+                produced.append(([chunk[k] for k in idx], b0, b1, list(range(len(idx)))))
         for k, i in enumerate(chunk):
             res['scales0'][i], res['scales1'][i] = r0[k].scales, r1[k].scales
             res['overlap_scales0'][i], res['overlap_scales1'][i] = r0[k].overlap_scales, r1[k].overlap_scales
@@ -141,6 +144,9 @@ def forward_pairs_raw(model, raw_pairs, resize=(640,), grayscale=True, align='di
     flush = getattr(model, 'hip_flush', None)
     if flush is not None:
         flush()
+    for dst, b0, b1, rows in produced:     # settled (and, if need be, corrected) boxes -> result
+        di = torch.as_tensor(dst, device=res['box0'].device)
+        res['box0'][di], res['box1'][di] = b0[rows], b1[rows]
     return res
 
 

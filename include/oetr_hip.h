@@ -165,9 +165,12 @@ void oetr_destroy(oetr_handle h);
  * first 4 bytes of the workspace (the first OETR_WORKSPACE_STATUS_BYTES are reserved for it,
  * at a shape-independent position), so callers that overlap batches on several streams - one
  * workspace per stream - see and clear only their own stream's calls.
- *   OETR_FLAG_F16_RANGE  a GEMM operand (activation) reached |x| >= 65504 in an
- *                        f16-based dtype (F32_SPLIT_F16, F32_SPLIT_QK16, F16) and could not be
- *                        represented: the outputs of that call are INVALID.  Re-run
+ *   OETR_FLAG_F16_RANGE  a GEMM operand (activation) reached |x| >= 65520 in an
+ *                        f16-based dtype (F32_SPLIT_F16, F32_SPLIT_QK16, F16): the operand
+ *                        conversion rounds to nearest even, so 65520 is the first magnitude
+ *                        that becomes f16 inf (65504 < |x| < 65520 still rounds to 65504, the
+ *                        largest f16, and is handled exactly by the split).  The outputs of
+ *                        that call are INVALID.  Re-run
  *                        with a handle created as OETR_DTYPE_F32 or OETR_DTYPE_BF16.
  * oetr_workspace_init   zeroes the status block (enqueued on `stream`); call it once after
  *                       allocating a workspace (or zero the first 256 bytes yourself).

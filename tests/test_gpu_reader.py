@@ -92,13 +92,24 @@ def test_raw_pairs_to_crops_without_a_host_round_trip(gpu):
 def test_raw_pairs_native_size_frames_are_bucketed(gpu):
     """``resize=[-1]`` keeps every picture's own size as its OETR frame (reference
     utils.py:297-298): pairs are then bucketed by shape, boxes still in input order."""
-    class Stub:   # forward_dummy's contract, boxes that identify the inputs
+    class Stub:   # forward_dummy's contract, boxes that identify the inputs - DEFERRED like
+        _pending = None   # OETR.hip_defer_check: garbage until the next call / hip_flush() fixes it in place
+
         def parameters(self):
             return iter([torch.zeros(1, device=gpu)])
 
+        def hip_flush(self):
+            if self._pending is not None:
+                for t in self._pending:
+                    t -= 1000.0
+                self._pending = None
+
         def forward_dummy(self, a, b):
+            self.hip_flush()
             k = torch.arange(4, dtype=torch.float32, device=a.device)
-            return a.reshape(a.shape[0], -1).mean(1, keepdim=True) + k, b.reshape(b.shape[0], -1).mean(1, keepdim=True) - k
+            self._pending = (a.reshape(a.shape[0], -1).mean(1, keepdim=True) + k + 1000.0,
+                             b.reshape(b.shape[0], -1).mean(1, keepdim=True) - k + 1000.0)
+            return self._pending
     g = torch.Generator().manual_seed(8)
     sizes = [((64, 96), (64, 96)), ((32, 32), (64, 96)), ((64, 96), (64, 96)), ((32, 32), (64, 96))]
     raw = [((torch.rand(*a, 3, generator=g) * 255).to(torch.uint8), (torch.rand(*b, 3, generator=g) * 255).to(torch.uint8))
@@ -109,3 +120,32 @@ def test_raw_pairs_native_size_frames_are_bucketed(gpu):
         assert abs(float(out['box0'][i, 0]) - float(ra['overlap_inp'].mean())) <= 1e-5, i
         assert abs(float(out['box1'][i, 0]) - float(rb['overlap_inp'].mean())) <= 1e-5, i
         assert tuple(out['inp0'][i].shape) == tuple(ra['inp'].shape) and out['overlap_scales0'][i] == (1.0, 1.0)
+
+
+def test_raw_pairs_overflowing_batch_is_rerun_before_the_boxes_are_copied(gpu):
+    """``forward_pairs_raw`` on the REAL model with a hot path that overflows the f16 operand
+    range: forward_dummy defers its range check and re-runs the batch in exact fp32 INTO the
+    tensors it returned; the result dict must hold those corrected boxes (round 3 copied the
+    boxes by value right after the call and returned the out-of-range ones silently)."""
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    sd = model.state_dict()
+    sd.update(orc.make_hot_weights(6, sharpen=True))
+    sd['input_proj2.weight'] = sd['input_proj2.weight'] * 4.0e5     # features beyond the f16 range
+    sd['input_proj2.bias'] = sd['input_proj2.bias'] * 4.0e5
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    model.hip_neck = False          # (the torch neck: only the HOT PATH's guard is under test)
+    g = torch.Generator().manual_seed(5)
+    raw = [((torch.rand(160, 200, 3, generator=g) * 255).to(torch.uint8).numpy(),
+            (torch.rand(200, 160, 3, generator=g) * 255).to(torch.uint8).numpy()) for _ in range(5)]
+    out = pkg.forward_pairs_raw(model, raw, resize=[320], grayscale=True, align='disk', max_batch=2)
+    assert bool(torch.isfinite(out['box0']).all()) and bool(torch.isfinite(out['box1']).all())
+    # reference: the same pictures through the exact-fp32 engine, synchronously
+    model.hip_precision = 'f32'
+    model.hip_defer_check = False
+    for i, (a, b) in enumerate(raw):
+        ra, rb = rdo.read_overlap_image(a, [320], True, 'disk'), rdo.read_overlap_image(b, [320], True, 'disk')
+        e0, e1 = model.forward_dummy(ra['overlap_inp'].to(gpu), rb['overlap_inp'].to(gpu))
+        assert float((out['box0'][i] - e0[0]).abs().max()) <= 5e-2, i
+        assert float((out['box1'][i] - e1[0]).abs().max()) <= 5e-2, i

@@ -160,13 +160,28 @@ def test_pipelined_box_gatherer_unequal_shards_world2_gloo():
 
 class _StubModel:
     """forward_dummy with the reference's contract ([N,H,W,3] images -> two [N,4]
-    boxes) computed from the images alone, so that sharding is observable."""
+    boxes) computed from the images alone, so that sharding is observable.
+
+    It DEFERS like ``OETR.forward_dummy`` under ``hip_defer_check``: the tensors it returns
+    hold out-of-range garbage until ``hip_flush()`` (or the next call) corrects them in place -
+    a consumer that copies the boxes before settling ships the garbage."""
+
+    def __init__(self):
+        self._pending = None
+
+    def hip_flush(self):
+        if self._pending is not None:
+            for t in self._pending:
+                t -= 1000.0
+            self._pending = None
 
     def forward_dummy(self, image1, image2):
+        self.hip_flush()
         m1 = image1.reshape(image1.shape[0], -1).mean(1, keepdim=True)
         m2 = image2.reshape(image2.shape[0], -1).mean(1, keepdim=True)
         k = torch.arange(4, dtype=torch.float32)
-        return m1 + k, m2 - k
+        self._pending = (m1 + k + 1000.0, m2 - k + 1000.0)
+        return self._pending
 
 
 def _sharded_worker(rank, world, port, n_pairs, q):
@@ -202,7 +217,10 @@ def test_forward_sharded_world2_gloo(n_pairs):
     g = torch.Generator().manual_seed(3)
     im1 = torch.rand(n_pairs, 6, 5, 3, generator=g)
     im2 = torch.rand(n_pairs, 4, 7, 3, generator=g)
-    e1, e2 = _StubModel().forward_dummy(im1, im2)
+    ref = _StubModel()
+    e1, e2 = ref.forward_dummy(im1, im2)
+    ref.hip_flush()
+    assert float(e1.abs().max()) < 100.0      # settled values
     for rank, b1, b2 in results:
         assert torch.equal(torch.tensor(b1), e1) and torch.equal(torch.tensor(b2), e2), rank
 

@@ -22,14 +22,25 @@ class StubModel:
 
     def __init__(self):
         self.calls = []
+        self._pending = None
+
+    def hip_flush(self):
+        """Deferred settle of the last batch, IN PLACE (what OETR does under hip_defer_check
+        when a batch tripped the f16 range flag): until then its boxes are garbage."""
+        if self._pending is not None:
+            for t in self._pending:
+                t -= 1000.0
+            self._pending = None
 
     def forward_dummy(self, image1, image2):
         assert image1.shape[0] == image2.shape[0] and image1.shape[-1] == 3
+        self.hip_flush()
         self.calls.append((tuple(image1.shape), tuple(image2.shape)))
         m1 = image1.reshape(image1.shape[0], -1).mean(1, keepdim=True)
         m2 = image2.reshape(image2.shape[0], -1).mean(1, keepdim=True)
         k = torch.arange(4, dtype=torch.float32)
-        return m1 * image1.shape[2] + k, m2 * image2.shape[1] - k
+        self._pending = (m1 * image1.shape[2] + k + 1000.0, m2 * image2.shape[1] - k + 1000.0)
+        return self._pending
 
 
 def make_pairs(n, seed=0):
@@ -50,6 +61,7 @@ def per_pair_loop(pairs):
         a = a if a.dim() == 4 else a[None]
         b = b if b.dim() == 4 else b[None]
         b0, b1 = m.forward_dummy(a, b)
+        m.hip_flush()
         out0.append(b0[0]); out1.append(b1[0])
     return torch.stack(out0), torch.stack(out1)
 
