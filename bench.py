@@ -115,6 +115,14 @@ def parse_args(argv=None):
     ap.add_argument('--kernel', default=None, choices=[None, 'full_attention'],
                     help='micro-benchmark of one stand-alone kernel instead of the hot path')
     ap.add_argument('--L', type=int, default=1024, help='--kernel full_attention: tokens per image')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short driver-timed regions of BASELINE configs[2] / [3] / [4] (N=1, default '
+                         'workload only; about 20 s)')
+    ap.add_argument('--workload', default='uniform', choices=['uniform', 'mixed'],
+                    help="'mixed' = BASELINE configs[4] as a mixed-scale job: every rank holds the same global "
+                         'pair list (640x640 vs 640x640 and 640x640 vs 1280x1280, --pairs-per-gpu of each per '
+                         'GPU), buckets it by (L1, L2), runs its contiguous shard of every bucket and all-gathers '
+                         'the boxes per bucket; reports the per-rank step-time spread')
     return ap.parse_args(argv)
 
 
@@ -407,6 +415,180 @@ def cpu_full_forward(model, size, budget_s=20.0):
     return res
 
 
+def _pair_flop(l1, l2):
+    """Algorithmic FLOP of one B;A encoder launch per pair."""
+    return ENC_FLOP_PER_TOKEN * (l1 + l2)
+
+
+def other_configs(args, device, pkg):
+    """BASELINE configs[2] / [3] / [4] under the SAME clock as `value`: short
+    regions - median of 5 regions of `steps` steps, batches alternating over --streams streams like
+    `value` - each with the roofline of its dominant kernel from a traced serial pass and an IoU
+    check of a 2-pair slice against the CPU oracle OUTSIDE the timed regions.  Bounded to ~20 s."""
+    import torch
+    from oracle import oetr_oracle as orc
+    t_start = time.perf_counter()
+    cases = [
+        # key, pairs, size1, size2, precision, forced tile (0 = auto), steps
+        ('configs[3] 32 pairs @1024x1024, auto tile', 32, 1024, 1024, 'f32_split_f16', 0, 8),
+        ('configs[3] 32 pairs @1024x1024, 32-row tile (LDS-tile sweep)', 32, 1024, 1024, 'f32_split_f16', 32, 8),
+        ('configs[3] 32 pairs @1024x1024, 64-row tile (LDS-tile sweep)', 32, 1024, 1024, 'f32_split_f16', 64, 8),
+        ('configs[4] share: 8 pairs 640x640 vs 1280x1280, default precision', 8, 640, 1280, 'f32_split_f16', 0, 16),
+        ('configs[4] share: 8 pairs 640x640 vs 1280x1280, precision policy', 8, 640, 1280, 'f32_split_qk16', 0, 16),
+        ('configs[2] share: 8 pairs @640x640, precision policy', 8, 640, 640, 'f32_split_qk16', 0, 40),
+    ]
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+    out, inputs, engines = {}, {}, {}
+    for key, n, s1, s2, prec, tile, steps in cases:
+        ik = (n, s1, s2)
+        if ik not in inputs:
+            inputs[ik] = synthetic_inputs(n, s1, s2, device)
+        model, weights, f1, f2, p1, p2, hf, hf2 = inputs[ik]
+        if prec not in engines:
+            engines[prec] = pkg.HotPathEngine(weights, device=device, precision=prec)
+        eng = engines[prec]
+        hw, hw2 = (s1, s1), (s2, s2)
+        L1, L2 = hf * hf, hf2 * hf2
+        eff_tile = tile or (64 if n_streams > 1 else 0)     # like `value`: 64-row tiles while batches overlap
+        eng.set_encoder_tile(eff_tile)
+
+        def region(ns, k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k):
+                with torch.cuda.stream(streams[i % ns]):
+                    eng.forward(f1, f2, p1, p2, hw, hw2)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        region(n_streams, 2)
+        over = statistics.median(region(n_streams, steps) for _ in range(5))
+        eng.set_encoder_tile(tile)                           # serial: the forced tile, or the library's choice
+        region(1, 2)
+        ser = statistics.median(region(1, steps) for _ in range(5))
+        eng.set_encoder_tile(eff_tile)
+        with pkg.KernelTrace(eng, max_launches=24 * steps + 64) as tr:
+            t_tr = region(1, steps)
+            kern = tr.summary()
+        cost, pipe_peak, _ = MFMA_COST[prec]
+        pair_gflop = PAIR_GFLOP_640 * (L1 + L2) / 800
+        rec = {'pairs_per_s': round(n * steps / over, 1), 'ms_per_step': round(over / steps * 1e3, 4),
+               'serial_pairs_per_s': round(n * steps / ser, 1), 'steps': steps, 'streams': n_streams,
+               'precision': prec, 'encoder_tile_rows': eff_tile or 'auto',
+               'hot_path_frac_of_mfma_peak': round(n * steps / over * pair_gflop / 1e3 / (pipe_peak / cost), 4)}
+        used_tile = eff_tile or 64      # (auto on one stream picks 64 rows whenever the 32-row grid exceeds the chip)
+        rb = roofline_block(kern, prec, n * (L1 + L2), used_tile, steps, t_tr, False, 0, grids=(n, L1, L2))
+        if rb:
+            rec['roofline'] = {k: rb[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                                  'avg_launch_us', 'launches', 'workgroups_per_launch',
+                                                  'cu_share', 'traffic')}
+        # parity on a 2-pair slice, outside every timed region
+        b1, b2 = eng.forward(f1, f2, p1, p2, hw, hw2)
+        torch.cuda.synchronize()
+        w = {k: v.cpu() for k, v in weights.items()}
+        r1, r2 = orc.hot_path(f1[:2].cpu(), f2[:2].cpu(), w, hw, hw2)
+        iou = torch.cat([orc.bbox_iou_aligned(b1[:2].cpu(), r1), orc.bbox_iou_aligned(b2[:2].cpu(), r2)])
+        rec['iou_vs_cpu_min_2pairs'] = round(float(iou.min()), 6)
+        if eng.precision in eng.F16_RANGE:
+            rec['f16_range_flag'] = eng.query_flags()
+        out[key] = rec
+    out['_seconds'] = round(time.perf_counter() - t_start, 1)
+    out['_note'] = ('each entry: median of 5 regions of `steps` steps, batches alternating over `streams` HIP streams '
+                    '(64-row encoder tiles unless forced), `serial_pairs_per_s` = the same steps on one stream; '
+                    'roofline = dominant kernel from a traced serial pass (HIP events on the launch stream); IoU of a '
+                    '2-pair slice vs the CPU oracle outside the timed regions')
+    return out
+
+
+def bench_mixed(args, device, world, rank, use_pg, pkg):
+    """--workload mixed: BASELINE configs[4] as a mixed-scale multi-GPU job (bucket by
+    (L1, L2) BEFORE sharding so every rank runs equal work).  The global list holds
+    world * --pairs-per-gpu pairs of 640x640 vs 640x640 and as many of 640x640 vs 1280x1280,
+    interleaved; every rank buckets it, takes its contiguous `shard_bounds` slice of each bucket,
+    runs one hot-path batch per bucket per step and all-gathers the boxes per bucket (BoxGatherer,
+    asynchronous, under the next bucket's kernels).  Reported: whole-job pairs/s (max over ranks)
+    and the per-rank step-time spread."""
+    import torch
+    import torch.distributed as dist
+    from imagematching_oetr_amd.parallel import BoxGatherer, bucket_by_shape, shard_bounds
+    n = args.pairs_per_gpu
+    s_small, s_big = args.size, args.size2 or 2 * args.size
+    shapes = []
+    for i in range(n * world):
+        shapes += [((s_small, s_small), (s_small, s_small)), ((s_small, s_small), (s_big, s_big))]
+    buckets = bucket_by_shape(shapes)                  # same on every rank (first-seen order)
+    work, eng = [], None
+    for key, idx in buckets.items():
+        lo, hi = shard_bounds(len(idx), rank, world)
+        (h1, _), (h2, _) = key
+        model, weights, f1, f2, p1, p2, hf, hf2 = synthetic_inputs(hi - lo, h1, h2, device)
+        if eng is None:
+            eng = pkg.HotPathEngine(weights, device=device, precision=args.precision)
+        work.append(dict(key=key, n_bucket=len(idx), n_local=hi - lo, f1=f1, f2=f2, p1=p1, p2=p2,
+                         hw=(h1, h1), hw2=(h2, h2), tokens=hf * hf + hf2 * hf2))
+    gatherer = BoxGatherer() if use_pg else None
+    streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
+    eng.set_encoder_tile(args.enc_tile or (64 if len(streams) > 1 else 0))
+
+    def barrier():
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def region(k):
+        barrier()
+        t0 = time.perf_counter()
+        j = 0
+        for _ in range(k):
+            for wk in work:
+                with torch.cuda.stream(streams[j % len(streams)]):
+                    b1, b2 = eng.forward(wk['f1'], wk['f2'], wk['p1'], wk['p2'], wk['hw'], wk['hw2'])
+                    if gatherer is not None:
+                        gatherer.submit(b1, b2, n_pairs=wk['n_bucket'])
+                j += 1
+        if gatherer is not None:
+            gatherer.flush()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0       # this rank's own time (before the closing barrier)
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_pg:
+            t = torch.tensor([dt, mine], device=device, dtype=torch.float64)
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            return max(float(e[0]) for e in every), [float(e[1]) for e in every]
+        return dt, [mine]
+    region(max(1, args.warmup))
+    regs = sorted((region(args.steps) for _ in range(max(1, args.repeats))), key=lambda r: r[0])
+    dt, per_rank = regs[len(regs) // 2]
+    if rank != 0:
+        return None
+    pairs_step = sum(wk['n_bucket'] for wk in work)
+    cost, pipe_peak, _ = MFMA_COST[args.precision]
+    gflop_step = sum(wk['n_bucket'] * PAIR_GFLOP_640 * wk['tokens'] / 800 for wk in work)
+    return {
+        'metric': f'image-pairs/sec, mixed-scale job ({s_small}x{s_small} vs {s_small}x{s_small} and vs '
+                  f'{s_big}x{s_big}; OETR hot path, features resident in HBM)',
+        'value': round(pairs_step * args.steps / dt, 1), 'unit': 'image-pairs/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.precision in ('f32', 'f32_split_f16') else args.precision,
+        'gemm_mode': GEMM_MODE_TEXT[args.precision], 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[4] mixed-scale: {n * world} pairs {s_small}^2 vs {s_small}^2 + '
+                               f'{n * world} pairs {s_small}^2 vs {s_big}^2 per step, bucketed by (L1, L2) then '
+                               f'sharded contiguously over {world} rank(s), {args.precision}',
+                   'buckets': [{'shapes': [list(k[0]), list(k[1])], 'global_pairs': wk['n_bucket'],
+                                'pairs_this_rank': wk['n_local']} for k, wk in zip(buckets, work)],
+                   'streams': len(streams), 'parallelism': f'every bucket sharded over {world} rank(s); one '
+                                                           'all-gather of [n_local,2,4] boxes per bucket'},
+        'rank_step_ms': {'per_rank': [round(t / args.steps * 1e3, 4) for t in per_rank],
+                         'min': round(min(per_rank) / args.steps * 1e3, 4),
+                         'max': round(max(per_rank) / args.steps * 1e3, 4),
+                         'spread': round((max(per_rank) - min(per_rank)) / max(per_rank), 4)},
+        'hot_path_frac_of_mfma_peak': round(args.steps / dt * gflop_step / 1e3 / (pipe_peak / cost) / world, 4),
+    }
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -461,6 +643,20 @@ def main():
 
     import imagematching_oetr_amd as pkg
     from imagematching_oetr_amd.parallel import BoxGatherer
+    if args.workload == 'mixed':
+        res = bench_mixed(args, device, world, rank, use_pg, pkg)
+        if use_pg:
+            if rank == 0:
+                res['process_group'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size()}
+            dist.destroy_process_group()
+        if rank == 0:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(res), flush=True)
+        return
     n = args.pairs_per_gpu
     size2 = args.size2 or args.size
     model, weights, feat1, feat2, pos, pos2, hf, hf2 = synthetic_inputs(n, args.size, size2, device)
@@ -654,6 +850,12 @@ def main():
                 out['cpu_baseline_full_forward'] = cpu_full_forward(model, args.size)
         except Exception as e:  # host-side extras must never break the bench line
             out['end_to_end_error'] = repr(e)[:200]
+    if (not args.no_other_configs and world == 1 and standard and args.precision == 'f32_split_f16'
+            and not args.no_trace):
+        try:     # configs[2] / [3] / [4] under the same clock (short regions, ~20 s)
+            out['other_configs'] = other_configs(args, device, pkg)
+        except Exception as e:
+            out['other_configs_error'] = repr(e)[:300]
     if use_pg:
         out['process_group'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
                                 'forced_at_world_1': bool(force_pg and world == 1),

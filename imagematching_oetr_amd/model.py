@@ -148,6 +148,13 @@ class OETR(nn.Module):
         #: into the hot path's workspace (no NCHW feat tensors, no transpose launch);
         #: False: feature_extraction + boxes_from_features as separate steps
         self.hip_fuse_neck = True
+        #: arithmetic of the torch / MIOpen TRUNK in forward_dummy on a GPU (host code by
+        #: north_star; 93 % of the end-to-end time): None = fp32 as the reference, 'float16' /
+        #: 'bfloat16' = the trunk's convolutions under torch.autocast (output cast back to
+        #: fp32 for the neck).  OPT-IN: measured drift and speed in profiles/r4_trunk_autocast.txt
+        self.hip_trunk_dtype = None
+        #: run the trunk in channels_last memory format (MIOpen's NHWC kernels)
+        self.hip_trunk_channels_last = False
         self._engine = None
         self._engine_key = None
         self._engine_f32 = None
@@ -176,6 +183,22 @@ class OETR(nn.Module):
     def _neck_torch(self, x):
         return self.input_proj2(self.patchmerging(self.input_proj(x)))
 
+    def trunk(self, images):
+        """``self.backbone(images)`` (reference ``src/models/backbone.py:159-174``) with the
+        opt-in GPU settings ``hip_trunk_dtype`` / ``hip_trunk_channels_last``; always returns
+        the contiguous fp32 ``[n,1024,hb,wb]`` map the neck takes."""
+        if not images.is_cuda or (self.hip_trunk_dtype is None and not self.hip_trunk_channels_last):
+            return self.backbone(images)
+        if self.hip_trunk_channels_last and not getattr(self, '_trunk_cl', False):
+            self.backbone.to(memory_format=torch.channels_last)
+            self._trunk_cl = True
+        if self.hip_trunk_dtype is None:
+            return self.backbone(images).contiguous()
+        dt = {'float16': torch.float16, 'bfloat16': torch.bfloat16}[self.hip_trunk_dtype]
+        with torch.autocast('cuda', dtype=dt):
+            out = self.backbone(images)
+        return out.float().contiguous()
+
     def feature_extraction(self, image1, image2, mask1=None, mask2=None):
         """Reference ``src/model.py:109-130``.  Same-sized image batches go through
         the trunk and the neck as ONE batch of 2N images (per-sample ops: same
@@ -184,11 +207,11 @@ class OETR(nn.Module):
             # (eval only: in train() mode one batch of 2N would change the BatchNorm
             #  statistics against the reference's two separate trunk calls)
             n = image1.shape[0]
-            f = self.neck(self.backbone(torch.cat([image1, image2], dim=0)))
+            f = self.neck(self.trunk(torch.cat([image1, image2], dim=0)))
             feat1, feat2 = f[:n], f[n:]
         else:
-            feat1 = self.neck(self.backbone(image1))
-            feat2 = self.neck(self.backbone(image2))
+            feat1 = self.neck(self.trunk(image1))
+            feat2 = self.neck(self.trunk(image2))
         hf1, wf1 = feat1.shape[2:]
         hf2, wf2 = feat2.shape[2:]
         return (feat1, feat2, self.pos_encoding(feat1), self.pos_encoding(feat2),
@@ -313,9 +336,9 @@ class OETR(nn.Module):
             # trunk -> HIP neck storing token-major straight into the hot path's workspace
             if image1.shape == image2.shape:
                 n = image1.shape[0]
-                bb = self.backbone(torch.cat([image1, image2], dim=0))
+                bb = self.trunk(torch.cat([image1, image2], dim=0))
                 return self.boxes_from_backbone(bb[:n], bb[n:], (h1, w1), (h2, w2), both=bb)
-            return self.boxes_from_backbone(self.backbone(image1), self.backbone(image2),
+            return self.boxes_from_backbone(self.trunk(image1), self.trunk(image2),
                                             (h1, w1), (h2, w2))
         feat1, feat2, pos1, pos2, _, _, _, _ = self.feature_extraction(
             image1, image2)

@@ -28,8 +28,8 @@ class StubModel:
         """Deferred settle of the last batch, IN PLACE (what OETR does under hip_defer_check
         when a batch tripped the f16 range flag): until then its boxes are garbage."""
         if self._pending is not None:
-            for t in self._pending:
-                t -= 1000.0
+            for t, good in self._pending:
+                t.copy_(good)
             self._pending = None
 
     def forward_dummy(self, image1, image2):
@@ -39,8 +39,10 @@ class StubModel:
         m1 = image1.reshape(image1.shape[0], -1).mean(1, keepdim=True)
         m2 = image2.reshape(image2.shape[0], -1).mean(1, keepdim=True)
         k = torch.arange(4, dtype=torch.float32)
-        self._pending = (m1 * image1.shape[2] + k + 1000.0, m2 * image2.shape[1] - k + 1000.0)
-        return self._pending
+        good = (m1 * image1.shape[2] + k, m2 * image2.shape[1] - k)
+        out = tuple(torch.full_like(t, 7.0e4) for t in good)      # "overflowed" until settled
+        self._pending = list(zip(out, good))
+        return out
 
 
 def make_pairs(n, seed=0):

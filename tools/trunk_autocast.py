@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""one host-side experiment for the number a dloc user sees.
+
+The torch / MIOpen trunk (ResNet-50 conv1..layer3, reference src/models/backbone.py:159-174;
+host code by north_star) is 93 % of `forward_dummy`.  This runs it under torch.autocast(float16 /
+bfloat16), with and without channels_last, and records for each setting
+
+  * end-to-end `forward_dummy` pairs/s on the bench batch (8 pairs @640x640),
+  * box IoU against `tests/golden/full_640.npz` (the REFERENCE's own fp32 CPU forward_dummy on the
+    same seeded weights and images),
+  * box IoU against this repo's fp32 CPU full forward (torch trunk/neck + oracle hot path) on the
+    bench batch, sharpened heads (plain random-init heads give boxes that barely depend on the input).
+
+    python tools/trunk_autocast.py > profiles/r4_trunk_autocast.txt
+"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+import imagematching_oetr_amd as pkg          # noqa: E402
+from oracle import oetr_oracle as orc         # noqa: E402
+
+torch.set_grad_enabled(False)
+gpu = torch.device('cuda', 0)
+
+
+def build(seed_hot):
+    torch.manual_seed(0)
+    m = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    sd = m.state_dict()
+    sd.update(orc.make_hot_weights(seed_hot, sharpen=True))
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def main():
+    g = np.load(REPO / 'tests' / 'golden' / 'full_640.npz')
+    cpu_model = build(int(g['weight_seed']))
+    gen = torch.Generator().manual_seed(int(g['image_seed']))
+    gi1 = torch.rand(1, 640, 640, 3, generator=gen)
+    gi2 = torch.rand(1, 640, 640, 3, generator=gen)
+    gold = torch.from_numpy(np.concatenate([g['box1'], g['box2']]))
+
+    # the bench batch (bench.py end_to_end: seed 2) and its fp32 CPU full forward
+    n = 8
+    gen = torch.Generator().manual_seed(2)
+    im1 = torch.rand(n, 640, 640, 3, generator=gen)
+    im2 = torch.rand(n, 640, 640, 3, generator=gen)
+    torch.set_num_threads(32)
+    t0 = time.perf_counter()
+    f = cpu_model._neck_torch(cpu_model.backbone(torch.cat([im1, im2])))
+    w = {k: v.detach() for k, v in cpu_model.hot_path_state().items()}
+    c1, c2 = orc.hot_path(f[:n], f[n:], w, (640, 640), (640, 640))
+    cpu_ref = torch.cat([c1, c2])
+    print(f'# fp32 CPU full forward of the bench batch: {time.perf_counter() - t0:.1f} s; boxes span '
+          f'x {float(cpu_ref[:, 0].min()):.1f}..{float(cpu_ref[:, 2].max()):.1f}')
+
+    model = build(int(g['weight_seed'])).to(gpu)
+    d1, d2, dg1, dg2 = im1.to(gpu), im2.to(gpu), gi1.to(gpu), gi2.to(gpu)
+    rows = []
+    for name, dt, cl in [('fp32 (reference arithmetic)', None, False),
+                         ('fp32 channels_last', None, True),
+                         ('autocast float16', 'float16', False),
+                         ('autocast float16 + channels_last', 'float16', True),
+                         ('autocast bfloat16', 'bfloat16', False),
+                         ('autocast bfloat16 + channels_last', 'bfloat16', True)]:
+        if cl != getattr(model, '_trunk_cl', False):     # memory format is sticky: fresh module per change
+            model = build(int(g['weight_seed'])).to(gpu)
+        model.hip_trunk_dtype, model.hip_trunk_channels_last = dt, cl
+        b1, b2 = model.forward_dummy(dg1, dg2)
+        model.hip_flush()
+        iou_gold = orc.bbox_iou_aligned(torch.cat([b1, b2]).cpu(), gold)
+        b1, b2 = model.forward_dummy(d1, d2)
+        model.hip_flush()
+        mine = torch.cat([b1, b2]).cpu()
+        iou_cpu = orc.bbox_iou_aligned(mine, cpu_ref)
+        dpx = float((mine - cpu_ref).abs().max())
+        for _ in range(3):
+            model.forward_dummy(d1, d2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            model.forward_dummy(d1, d2)
+        model.hip_flush()
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / reps
+        # trunk alone
+        imgs = torch.cat([d1, d2])
+        for _ in range(2):
+            model.trunk(imgs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model.trunk(imgs)
+        torch.cuda.synchronize()
+        tt = (time.perf_counter() - t0) / reps
+        rows.append((name, n / dt_s, dt_s * 1e3, tt * 1e3, float(iou_gold.min()), float(iou_cpu.min()), dpx))
+    print('# OETR.forward_dummy end to end, 8 pairs @640x640, hot path f32_split_f16, HIP neck; IoU bar = 1 - 1e-3')
+    print(f'{"trunk setting":38s} {"pairs/s":>8s} {"ms/batch":>9s} {"trunk ms":>9s} {"1-IoU vs reference golden":>26s} '
+          f'{"1-IoU vs fp32 CPU (8 pairs)":>28s} {"max |dbox| px":>14s} {"verdict":>8s}')
+    for name, pps, ms, tms, ig, ic, dpx in rows:
+        ok = (1 - ig) <= 1e-3 and (1 - ic) <= 1e-3
+        print(f'{name:38s} {pps:8.1f} {ms:9.2f} {tms:9.2f} {1 - ig:26.2e} {1 - ic:28.2e} {dpx:14.3f} '
+              f'{"ok" if ok else "FAILS":>8s}')
+
+
+if __name__ == '__main__':
+    main()
