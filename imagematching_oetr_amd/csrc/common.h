@@ -219,36 +219,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
-// Branch-free fp32 erf (coefficients and error analysis: tools/fit_erf.py;
-// max 1.3 ulp / 7.7e-8 abs vs double-precision erf).  Both branches are
-// evaluated and selected, so a wave never diverges; ocml's erff costs ~3x the
-// issue slots in the GELU epilogue because of its divergent range split.
-//   |x| <= 0.92 : x + x*P(x^2)
-//   |x| >  0.92 : sign(x) * (1 - 2^(t*R(t))),  t = min(|x|, 4)
-__device__ __forceinline__ float erf_f32(float x) {
-  const float ax = fabsf(x);
-  const float t = fminf(ax, 4.0f);
-  const float s = x * x;
-  float p = 8.404849575e-05f;
-  p = fmaf(p, s, -8.151340561e-04f);
-  p = fmaf(p, s, 5.201837672e-03f);
-  p = fmaf(p, s, -2.685974483e-02f);
-  p = fmaf(p, s, 1.128370225e-01f);
-  p = fmaf(p, s, -3.761263422e-01f);
-  p = fmaf(p, s, 1.283791667e-01f);
-  const float small_v = fmaf(x, p, x);
-  float r = 4.358980029e-07f;
-  r = fmaf(r, t, -7.196586003e-06f);
-  r = fmaf(r, t, 2.439359676e-05f);
-  r = fmaf(r, t, 3.708157171e-04f);
-  r = fmaf(r, t, -5.214545892e-03f);
-  r = fmaf(r, t, 3.451753623e-02f);
-  r = fmaf(r, t, -1.537478043e-01f);
-  r = fmaf(r, t, -9.159608808e-01f);
-  r = fmaf(r, t, -1.628399401e+00f);
-  const float large_v = copysignf(1.0f - __builtin_amdgcn_exp2f(t * r), x);
-  return ax <= 0.92f ? small_v : large_v;
-}
 // Exact-erf GELU (torch nn.GELU default): 0.5 v (1 + erf(v / sqrt 2)).
 //
 // GELU needs erf only to ABSOLUTE accuracy (it is added to 1), so one formula serves
@@ -258,27 +228,18 @@ __device__ __forceinline__ float erf_f32(float x) {
 // accuracy only where |v| erfc is not small) - tools/fit_erf.py: max abs error 3.1e-7 over
 // |v| <= 12 (half an ulp of the result at |v| ~ 4 is 2.4e-7), 1.6e-7 for |v| < 2, every operation
 // rounded to fp32.  Round 2's uniform degree-9 fit of Q measured 2.4e-7 / 1.2e-7 with four more
-// FMAs per value; the two-branch erf_f32 form before it 6.8e-7.
-#ifndef OETR_GELU_TWO_BRANCH
-#define OETR_GELU_TWO_BRANCH 0
-#endif
+// FMAs per value; round 1's two-branch erf form 6.8e-7.
 constexpr float GELU_T = 5.5f;
 constexpr int GELU_DEG = 5;
 constexpr float GELU_Q[GELU_DEG + 1] = {-1.151147082e+00f, -4.589156863e-01f, -5.323818670e-02f,
                                         7.977462822e-03f,  -7.398742635e-04f, 2.992419385e-05f};
 __device__ __forceinline__ float gelu_erf(float x) {
-#ifdef OETR_OCML_ERF
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-#elif OETR_GELU_TWO_BRANCH
-  return 0.5f * x * (1.0f + erf_f32(x * 0.70710678118654752440f));
-#else
   const float ax = fabsf(x), w = fminf(ax, GELU_T);
   float q = GELU_Q[GELU_DEG];
 #pragma unroll
   for (int i = GELU_DEG - 1; i >= 0; --i) q = fmaf(q, w, GELU_Q[i]);
   const float e = __builtin_amdgcn_exp2f(fmaf(w, q, -1.0f));   // 0.5 erfc: the 0.5 rides in the exponent
   return fmaf(-ax, e, fmaxf(x, 0.f));                            // (-|x| is a source modifier, not an instruction)
-#endif
 }
 
 // Two GELUs per instruction stream: the polynomial chain runs as v_pk_fma_f32
@@ -287,39 +248,6 @@ __device__ __forceinline__ float gelu_erf(float x) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
-#if defined(OETR_OCML_ERF)
-  return f32x2{gelu_erf(v[0]), gelu_erf(v[1])};
-#elif OETR_GELU_TWO_BRANCH
-  const f32x2 x = v * splat2(0.70710678118654752440f);
-  const f32x2 ax = __builtin_elementwise_abs(x);
-  const f32x2 t = __builtin_elementwise_min(ax, splat2(4.0f));
-  const f32x2 s = x * x;
-  f32x2 p = splat2(8.404849575e-05f);
-  p = __builtin_elementwise_fma(p, s, splat2(-8.151340561e-04f));
-  p = __builtin_elementwise_fma(p, s, splat2(5.201837672e-03f));
-  p = __builtin_elementwise_fma(p, s, splat2(-2.685974483e-02f));
-  p = __builtin_elementwise_fma(p, s, splat2(1.128370225e-01f));
-  p = __builtin_elementwise_fma(p, s, splat2(-3.761263422e-01f));
-  p = __builtin_elementwise_fma(p, s, splat2(1.283791667e-01f));
-  const f32x2 small_v = __builtin_elementwise_fma(x, p, x);
-  f32x2 r = splat2(4.358980029e-07f);
-  r = __builtin_elementwise_fma(r, t, splat2(-7.196586003e-06f));
-  r = __builtin_elementwise_fma(r, t, splat2(2.439359676e-05f));
-  r = __builtin_elementwise_fma(r, t, splat2(3.708157171e-04f));
-  r = __builtin_elementwise_fma(r, t, splat2(-5.214545892e-03f));
-  r = __builtin_elementwise_fma(r, t, splat2(3.451753623e-02f));
-  r = __builtin_elementwise_fma(r, t, splat2(-1.537478043e-01f));
-  r = __builtin_elementwise_fma(r, t, splat2(-9.159608808e-01f));
-  r = __builtin_elementwise_fma(r, t, splat2(-1.628399401e+00f));
-  const f32x2 tr = t * r;
-  f32x2 e;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float large_v = copysignf(1.0f - __builtin_amdgcn_exp2f(tr[i]), x[i]);
-    e[i] = ax[i] <= 0.92f ? small_v[i] : large_v;
-  }
-  return (splat2(0.5f) * v) * (splat2(1.0f) + e);
-#else
   const f32x2 ax = __builtin_elementwise_abs(v);
   const f32x2 w = f32x2{fminf(ax[0], GELU_T), fminf(ax[1], GELU_T)};
   f32x2 q = splat2(GELU_Q[GELU_DEG]);
@@ -331,17 +259,12 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
   for (int i = 0; i < 2; ++i)
     g[i] = fmaf(-fabsf(v[i]), __builtin_amdgcn_exp2f(u[i]), fmaxf(v[i], 0.f));
   return g;
-#endif
 }
 
 // Four GELUs as TWO interleaved packed chains: the polynomial is a serial chain of dependent
 // FMAs (one chain alone issues an instruction every ~8 cycles beside MFMAs); two independent
 // chains stepping together fill each other's latency.  Same operations per value as gelu_erf2.
 __device__ __forceinline__ f32x4 gelu_erf4(const f32x4& v) {
-#if defined(OETR_OCML_ERF) || OETR_GELU_TWO_BRANCH
-  const f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});
-  return f32x4{a[0], a[1], b[0], b[1]};
-#else
   const f32x2 v0 = f32x2{v[0], v[1]}, v1 = f32x2{v[2], v[3]};
   const f32x2 a0 = __builtin_elementwise_abs(v0), a1 = __builtin_elementwise_abs(v1);
   const f32x2 w0 = f32x2{fminf(a0[0], GELU_T), fminf(a0[1], GELU_T)};
@@ -360,7 +283,6 @@ __device__ __forceinline__ f32x4 gelu_erf4(const f32x4& v) {
   g[1] = fmaf(-fabsf(v[1]), __builtin_amdgcn_exp2f(u0[1]), fmaxf(v[1], 0.f));
   g[3] = fmaf(-fabsf(v[3]), __builtin_amdgcn_exp2f(u1[1]), fmaxf(v[3], 0.f));
   return g;
-#endif
 }
 
 // XCD-aware bijective remap: hardware block b runs on XCD b % 8; give each

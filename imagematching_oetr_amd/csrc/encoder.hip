@@ -54,6 +54,12 @@
 #ifndef OETR_ABL_EPI
 #define OETR_ABL_EPI 0
 #endif
+// Round-4 hazard study (tools/r4_hazard_study.sh): bit mask of interventions around the
+// split-f16 KV state of the 64-row kernel.  0 in every shipped build.
+#ifndef OETR_HZ
+#define OETR_HZ 0
+#endif
+#define OETR_HZ_NOP64 "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
 #ifndef OETR_MLP1_TR
 #define OETR_MLP1_TR 1
 #endif
@@ -980,16 +986,35 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
         split8(v0, v1, bh, bl, rg);
         mma16_split3(ah, al, bh, bl, kv, c1);
         __builtin_amdgcn_sched_barrier(0);
+#if OETR_HZ & 32
+        asm volatile(OETR_HZ_NOP64);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+#if OETR_HZ & 1     // study: the unmasked path always (rows past the end hold finite duplicates)
+    row_tile(I0{}, std::false_type{});
+    if (two) row_tile(I1{}, std::false_type{});
+#elif OETR_HZ & 256   // study: the masked path always
+    row_tile(I0{}, std::true_type{});
+    if (two) row_tile(I1{}, std::true_type{});
+#elif OETR_HZ & 512   // study: the run-time branch kept, BOTH sides the masked path (a tag keeps hipcc from merging them)
+    if (nvalid >= 32) { asm volatile("; full row tile 0"); row_tile(I0{}, std::true_type{}); }
+    else { asm volatile("; ragged row tile 0"); row_tile(I0{}, std::true_type{}); }
+    if (two) {
+      if (nvalid >= 64) { asm volatile("; full row tile 1"); row_tile(I1{}, std::true_type{}); }
+      else { asm volatile("; ragged row tile 1"); row_tile(I1{}, std::true_type{}); }
+    }
+#else
     if (nvalid >= 32) row_tile(I0{}, std::false_type{});
     else row_tile(I0{}, std::true_type{});
     if (two) {   // (else: no valid row in the second row tile)
       if (nvalid >= 64) row_tile(I1{}, std::false_type{});
       else row_tile(I1{}, std::true_type{});
     }
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
   } else {
@@ -1118,14 +1143,6 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
 
     // ---- round 3: the residual stream lives in the TRANSPOSED accumulator layout (lane = token,
     //      register quads = 4 consecutive channels), merge / MLP2 run transposed like MLP1 ----
-    // phi(Q) tile -> R2 (f32): a wave copies rows wave, wave + 8, ...: full 1-KB rows, 16 bytes
-    // per lane, the row address a scalar
-#pragma unroll
-    for (int i = 0; i < RT / 8; ++i) {
-      const int r = wave + 8 * i;
-      *reinterpret_cast<f32x4*>(R2f + r * LDA + 4 * lane) =
-          reinterpret_cast<const f32x4*>(p.qp + (qrow_base + min(r, nvalid - 1)) * C)[(unsigned)lane];
-    }
     // reduce the source image's partial KV states (fixed order): the registers are this head's
     // state in MFMA fragment order (A operand of the transposed apply)
     f32x4 kvB[4];
@@ -1163,6 +1180,19 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       if (tid < C) ksum_s[tid] = ks;
     }
     ws.template prime<C, P_MERGE, SP::MERGE>(p.b.wmerge, p.b.wmerge_l, wave, 0, lane);
+    // phi(Q) of this wave's head for the lane's token, both row tiles: the B fragments of the
+    // transposed apply exactly as phase A left them (round 4: FRAGMENT-major phi(Q) buffer,
+    // [slot][head][row tile][4][64 lanes] 16-byte units = {step 0 hi, step 0 lo, step 1 hi, step 1 lo}
+    // f16 planes - or four f32x4 k-groups in the bf16 build, whose apply runs on f32 MFMAs).  Eight
+    // coalesced 1-KB loads per wave straight into registers: no LDS staging tile, no conversion here.
+    f32x4 qfrag[2][4];
+    {
+      const f32x4* qf = reinterpret_cast<const f32x4*>(p.qp + qrow_base * C) + (size_t)wave * 2 * 4 * 64;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qfrag[mt][u] = qf[(mt * 4 + u) * 64 + (unsigned)lane];
+    }
     // residual x of token (32 mt + col), channels wcol + 8 g + 4 half + 0..3: straight into the
     // merge GEMM's accumulators, issued LAST (the loads return in order - nothing waits on these
     // before the merge GEMM, the state reduction and the apply run under them)
@@ -1205,9 +1235,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
           f32x16 c1 = {0}, cz = {0};
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
-            const float* qrow = R2f + (32 * mt + col) * LDA + wave * HD + 4 * half + 16 * s2;
-            f32x4 qh, ql;
-            split8(*reinterpret_cast<const f32x4*>(qrow), *reinterpret_cast<const f32x4*>(qrow + 8), qh, ql, rg);
+            const f32x4 qh = qfrag[mt][2 * s2], ql = qfrag[mt][2 * s2 + 1];
             mma16_split3<OETR_APPLY_FENCE != 0>(kvh[s2], kvl[s2], qh, ql, macc, c1);
             mma16_split3<OETR_APPLY_FENCE != 0>(ksh[s2], ksl[s2], qh, ql, zacc, cz);
           }
@@ -1217,7 +1245,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
         } else {
 #pragma unroll
           for (int ks4 = 0; ks4 < 4; ++ks4) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(R2f + (32 * mt + col) * LDA + wave * HD + 4 * half + ks4 * 8);
+            const f32x4 q = qfrag[mt][ks4];
             const f32x4 kk = *reinterpret_cast<const f32x4*>(ksum_s + wave * HD + 4 * half + ks4 * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1433,22 +1461,39 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // (issuing the x store under this GEMM, or phi(K) under the V GEMM below, was measured
     //  neutral to slightly slower - one-process A/B, 51.6 vs 51.9 us; only the GELU epilogues
     //  and the phi(Q) store pay for the interleave)
-    ws.template gemm<C, P_T0, true, C, SP::Q, SP::K>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
-                                                     p.a.wk_l, wave, 0);
+    ws.template gemm<C, P_T0, true, C, SP::Q, SP::K, true>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
+                                                           p.a.wk_l, wave, 0);
     PHASE_STAMP(p, 10);
     f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
     {
-      // phi(Q) -> HBM under the K GEMM's MFMAs (two accumulator values per k16 step)
-      float* qs = p.qp + qrow_base * C + wcol;                  // (scalar)
-      const unsigned qoff = 4 * half * C + col;                 // row crow(r, half) = crow(r, 0) + 4 half
+      // phi(Q) -> HBM under the K GEMM's MFMAs, one register pair per k16 step.  The Q GEMM ran
+      // TRANSPOSED: lane (token 32 mt + col, half) holds channels 8 g + 4 half + i of its head in
+      // register 4 g + i - which is, for k16 step s2 of the apply, exactly the B fragment of that
+      // lane (k-slot 8 half + i' <-> d = 16 s2 + 8 (i' >> 2) + 4 half + (i' & 3)): registers
+      // 8 s2 .. 8 s2 + 7.  So the wave stores the consumer's register image, split into the f16
+      // planes here (6 VALU per pair beside MFMAs instead of in the apply), 16 bytes per lane and
+      // 1 KB per instruction: 8 stores per lane instead of 32.
+      f32x4* qf = reinterpret_cast<f32x4*>(p.qp + qrow_base * C) + (size_t)wave * 2 * 4 * 64;   // (scalar)
       const bool two = ws.two();
+      u32x4 qhi = {0, 0, 0, 0}, qlo = {0, 0, 0, 0};
       auto qepi = [&](auto CI_) {
-        constexpr int CI = decltype(CI_)::value, mt = CI / 8, r0 = 2 * (CI % 8);
+        constexpr int CI = decltype(CI_)::value, mt = CI / 8, pr = CI % 8, s2 = pr / 4, j = pr % 4;
         if (mt == 1 && !two) return;   // (rows 32.. of a one-row-tile workgroup are never read)
-#pragma unroll
-        for (int r = r0; r < r0 + 2; ++r) {
-          const float x = accQ[mt][r];
-          (qs + (32 * mt + crow(r, 0)) * C)[qoff] = elu1(x);
+        const float a = elu1(accQ[mt][2 * pr]), b = elu1(accQ[mt][2 * pr + 1]);
+        if constexpr (MODE == GM_BF16) {   // the bf16 build's apply takes f32 fragments: k-group = register quad
+          if constexpr (pr % 2 == 0) { qhi[0] = __builtin_bit_cast(uint32_t, a); qhi[1] = __builtin_bit_cast(uint32_t, b); }
+          else {
+            qhi[2] = __builtin_bit_cast(uint32_t, a); qhi[3] = __builtin_bit_cast(uint32_t, b);
+            qf[(mt * 4 + pr / 2) * 64 + (unsigned)lane] = __builtin_bit_cast(f32x4, qhi);
+          }
+        } else {
+          uint32_t h, l;
+          cvt_planes2<GM_SPLIT>(a, b, h, l, rg);
+          qhi[j] = h; qlo[j] = l;
+          if constexpr (j == 3) {
+            qf[(mt * 4 + 2 * s2) * 64 + (unsigned)lane] = __builtin_bit_cast(f32x4, qhi);
+            qf[(mt * 4 + 2 * s2 + 1) * 64 + (unsigned)lane] = __builtin_bit_cast(f32x4, qlo);
+          }
         }
       };
       ws.template gemm_epi<C, P_T1, true, C, SP::K, SP::V>(P2, p.a.wk, p.a.wk_l, wave, 0, lane, accK, p.a.wv,
@@ -1459,7 +1504,29 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     PHASE_STAMP(p, 11);
     f32x16 kv;
     float ksum;
+#if OETR_HZ & 2
+    __syncthreads();
+#endif
+#if OETR_HZ & 4
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#if OETR_HZ & 8
+    asm volatile(OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64
+                 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64);
+#endif
+#if OETR_HZ & 64
+    __builtin_amdgcn_s_setprio(3);
+#endif
     kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
+#if OETR_HZ & 64
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if OETR_HZ & 16
+    __syncthreads();
+#endif
+#if OETR_HZ & 128
+    asm volatile(OETR_HZ_NOP64 ::: "memory");
+#endif
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
     // (the LayerNorm exchange buffer is dead after phase B)
@@ -1501,7 +1568,29 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
                                                    nullptr, 0, 0);
       f32x16 kv;
       float ksum;
+#if OETR_HZ & 2
+      __syncthreads();
+#endif
+#if OETR_HZ & 4
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#if OETR_HZ & 8
+      asm volatile(OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64
+                   OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64);
+#endif
+#if OETR_HZ & 64
+      __builtin_amdgcn_s_setprio(3);
+#endif
       kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
+#if OETR_HZ & 64
+      __builtin_amdgcn_s_setprio(0);
+#endif
+#if OETR_HZ & 16
+      __syncthreads();
+#endif
+#if OETR_HZ & 128
+      asm volatile(OETR_HZ_NOP64 ::: "memory");
+#endif
       if constexpr (dl == 1) {
         kv_state_write(kv, ksum, lane, wave, p.dkv1_out, p.dks1_out, slot);
       } else {

@@ -27,16 +27,24 @@ def model():
     return pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
 
 
-@pytest.mark.parametrize('precision,tile,rounds,attention',
-                         [('f32_split_f16', 64, 400, 'linear'), ('f32_split_qk16', 64, 300, 'linear'),
-                          ('f16', 64, 400, 'linear'), ('bf16', 64, 150, 'linear'),
-                          ('f32_split_f16', 32, 300, 'linear'), ('f16', 32, 150, 'linear'), ('f32', 32, 40, 'linear'),
-                          ('f32_split_f16', 32, 100, 'full'),     # (the all-pairs mode's MFMA triples are fenced too)
-                          ('f32', 32, 20, 'full')])
-def test_forward_is_a_function_of_its_inputs(model, precision, tile, rounds, attention):
+@pytest.mark.parametrize('precision,tile,rounds,attention,prereduce',
+                         [('f32_split_f16', 64, 400, 'linear', 0), ('f32_split_qk16', 64, 300, 'linear', 0),
+                          ('f16', 64, 400, 'linear', 0), ('bf16', 64, 150, 'linear', 0),
+                          ('f32_split_f16', 32, 300, 'linear', 0), ('f32_split_qk16', 32, 200, 'linear', 0),
+                          ('f16', 32, 150, 'linear', 0), ('f32', 32, 40, 'linear', 0),
+                          # both state pre-reduction forms (oetr_set_state_prereduce): the reduction launch and the
+                          # last-arriving workgroup inside the producing launch (agent-scope release / ticket / acquire)
+                          ('f32_split_f16', 64, 200, 'linear', 1), ('f32_split_f16', 64, 200, 'linear', 2),
+                          ('f32_split_qk16', 64, 150, 'linear', 2), ('f32_split_f16', 32, 150, 'linear', 2),
+                          ('f32_split_f16', 32, 100, 'full', 0),     # (the all-pairs mode's MFMA triples are fenced too)
+                          ('f32_split_f16', 64, 100, 'full', 0),     # (tile request ignored by the all-pairs mode: 32 rows)
+                          ('f32', 32, 20, 'full', 0)])
+def test_forward_is_a_function_of_its_inputs(model, precision, tile, rounds, attention, prereduce):
     dev = torch.device('cuda', 0)
     eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision=precision, enc_tile=tile,
                             attention=attention)
+    if prereduce:
+        eng.set_state_prereduce(prereduce)
     gen = torch.Generator().manual_seed(1)
     cases = []
     for n, h1, w1, h2, w2 in SHAPES:
