@@ -477,23 +477,23 @@ __device__ __forceinline__ void split8(const f32x4& a0, const f32x4& a1, f32x4& 
 // The operands of these MFMAs come straight out of VALU conversions (split2), not from LDS or a
 // load.  Left to hipcc's scheduler the conversions of `al` sit between the MFMAs, an operand
 // register is written one or two issue slots before the MFMA that reads it and rewritten right
-// after - legal by hipcc's hazard tables and by tools/mfma_hazard_probe.hip (every VALU
-// producer needs ONE wait state before the MFMA, overwriting a source right after it is safe,
-// with or without a sibling MFMA stream) - and yet this is where the timing-dependent results
-// of round 3 came from (encoder.hip: OETR_SPLIT_STATE; 230 -> 0-1 of 20 000 forwards with the
-// fences below under the vmcnt(0) amplifier, tools/hunt_multi.sh; the mechanism was not
-// isolated).  So: every operand is complete OETR_SPLIT3_PAD + 1 wait states before the first
-// MFMA and the three MFMAs issue back to back.  0.7 us per encoder launch.
+// after - legal by hipcc's hazard tables and by the hardware probes (tools/mfma_hazard_probe.hip:
+// every VALU producer needs ONE wait state before the MFMA, overwriting a source right after it
+// is safe, with or without a sibling MFMA stream; tools/mfma_branch_hazard_probe.hip: a VALU read
+// of the result needs 12 states for the last accumulator register, 6 for the first, and hipcc
+// provides them).  Round 3 fenced these triples (every operand complete OETR_SPLIT3_PAD + 1
+// states before the first MFMA, the three MFMAs back to back) when the split-f16 KV state
+// returned timing-dependent results; round 4 showed the fences were NOT what removed the
+// failures (the fenced two-path state still failed 7 of 37 000 at s_setprio 3; what every
+// failing build shares is a run-time branch between two forms of the state code, see
+// encoder.hip).  The attention apply - the only user left - has one code path and 0 differing
+// of 858 000 forwards with the fences; they stay as they were measured (0.3 us per launch).
 #ifndef OETR_SPLIT3_PAD
 #define OETR_SPLIT3_PAD 7
 #endif
 #define OETR_STR2(x) #x
 #define OETR_STR(x) OETR_STR2(x)
-#ifdef OETR_SPLIT3_PAD_OFF   // (tools/kv_state_probe.hip: the unfenced form, for the record)
-template <bool FENCE = false>
-#else
 template <bool FENCE = true>
-#endif
 __device__ __forceinline__ void mma16_split3(const f32x4& ah, const f32x4& al, const f32x4& bh,
                                              const f32x4& bl, f32x16& main, f32x16& cross) {
   if constexpr (FENCE) {
@@ -778,16 +778,6 @@ __device__ __forceinline__ void ln_rows(const float* S, int tid, f32x4 (&xn)[F4]
 #ifndef OETR_RING1
 #define OETR_RING1 6    // ring depth of the single-plane (f16 / bf16) weight stream
 #endif
-// Optional explicit waits before every step of the weight streams (a constexpr of the ring
-// position):  1 = an allowance that counts the younger LOADS only,  2 = vmcnt(0).  Default 0:
-// hipcc's own s_waitcnt placement.  (Round 3 first blamed its timing-dependent results on
-// stores retiring before older loads and shipped variant 1; the cause was elsewhere -
-// encoder.hip: OETR_SPLIT_STATE - and with that fixed the plain build shows 0 differing of
-// 129 000 forwards.  Variant 2 slows the short-step workgroups down and is the AMPLIFIER the
-// determinism hunts use: tools/hunt_multi.sh.)
-#ifndef OETR_VMCNT_LOADS
-#define OETR_VMCNT_LOADS 0
-#endif
 #ifndef OETR_WS_U
 #define OETR_WS_U 1     // k16 steps per chunk
 #endif
@@ -867,16 +857,6 @@ struct WStream<M, 1, true> {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-#if OETR_VMCNT_LOADS
-      {
-        // (OETR_VMCNT_LOADS: see above)
-        constexpr int L_THIS = (TWO && site_w_lo(SITE)) ? 2 : 1, L_NEXT = (TWO && site_w_lo(NSITE)) ? 2 : 1;
-        constexpr int IN_THIS = (CI + PRE < NCH ? PRE : NCH - 1 - CI);
-        constexpr int younger = OETR_VMCNT_LOADS == 2 ? 0 : U * (IN_THIS * L_THIS + (NK != 0 ? (PRE - IN_THIS) * L_NEXT : 0));
-        __builtin_amdgcn_s_waitcnt((younger & 0xF) | ((younger >> 4) << 14) | 0x0F70);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
       const BChunk& b = ring[(P + CI) % D];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1044,18 +1024,6 @@ struct WStream2T {
       __builtin_amdgcn_sched_barrier(0);
       const BStep& b = ring[(P + CI) % D];
       const AStep& ac = a[CI & 1];
-#if OETR_VMCNT_LOADS
-      {
-        // this step's fragments are in the registers once at most `younger` vector-memory
-        // operations are outstanding, counting only the LOADS issued after them (the PRE steps
-        // fetched since)
-        constexpr int L_THIS = (TWO && site_w_lo(SITE)) ? 2 : 1, L_NEXT = (TWO && site_w_lo(NSITE)) ? 2 : 1;
-        constexpr int IN_THIS = (CI + PRE < NS ? PRE : NS - 1 - CI);      // later steps of this GEMM in flight
-        constexpr int younger = OETR_VMCNT_LOADS == 2 ? 0 : IN_THIS * L_THIS + (HAS_NEXT ? (PRE - IN_THIS) * L_NEXT : 0);
-        __builtin_amdgcn_s_waitcnt((younger & 0xF) | ((younger >> 4) << 14) | 0x0F70);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
       epi(std::integral_constant<int, CI>{});
       auto mm = [](const f32x4& act, const f32x4& wgt, const f32x16& c) {
         if constexpr (TR) return mma16<M>(wgt, act, c);

@@ -31,38 +31,20 @@
 // The two small attention blocks of the f16-based modes - the per-tile KV state phi(K)^T V and
 // the attention apply phi(Q).KV - take their MFMA operands straight from VALU conversions.
 //  * APPLY runs as fp32-class split f16 MFMAs (common.h: mma16_split3, fenced).
-//  * STATE runs on f32 MFMAs (v_mfma_f32_32x32x2_f32, exact products).  The split form
-//    (OETR_SPLIT_STATE=1, round 2's default) is 1.8 us per launch faster in the 64-row kernel
-//    (2.2 us SLOWER in the 32-row one) and gave timing-dependent states: with the two waves of a
-//    SIMD in different phases - a ragged last tile behind cold weight loads - one head's state
-//    came out with the columns 16..31 of its B operand (V) wrong, 2-800 of 25 000 forwards
-//    depending on mode and box (tools/determinism_hunt.py).  No failure in 120 000
-//    forwards with the state on f32 MFMAs, 77 000 of them under the vmcnt(0) amplifier.
-#ifndef OETR_SPLIT_STATE
-#define OETR_SPLIT_STATE 0
-#endif
-#ifndef OETR_STATE_PIPELINED
-#define OETR_STATE_PIPELINED 1
-#endif
-#ifndef OETR_APPLY_FENCE
-#define OETR_APPLY_FENCE 1
-#endif
-#ifndef OETR_SPLIT_APPLY
-#define OETR_SPLIT_APPLY 1
-#endif
-
-#ifndef OETR_ABL_EPI
-#define OETR_ABL_EPI 0
-#endif
-// Round-4 hazard study (tools/r4_hazard_study.sh): bit mask of interventions around the
-// split-f16 KV state of the 64-row kernel.  0 in every shipped build.
-#ifndef OETR_HZ
-#define OETR_HZ 0
-#endif
-#define OETR_HZ_NOP64 "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
-#ifndef OETR_MLP1_TR
-#define OETR_MLP1_TR 1
-#endif
+//  * STATE runs on f32 MFMAs (v_mfma_f32_32x32x2_f32, exact products), software-pipelined: the
+//    operands of accumulator register r + 1 are formed while the MFMA of register r runs.
+//    Round 2's split-f16 form of the state (6 f16 MFMAs per row tile instead of 16 f32 ones,
+//    1.8 us per 64-row launch faster) returned timing-dependent states and is gone from the
+//    source.  What round 4 established about it (profiles/r4_hazard_study.txt): the
+//    failures need BOTH row-tile code paths of that form in the kernel - a workgroup-uniform
+//    run-time branch between a path with the row masks (ragged tiles) and one without (full
+//    tiles); builds with either path alone: 0 differing of 157 000 forwards under both
+//    amplifiers (vmcnt(0) before every GEMM step, s_setprio 3 around the state), two-path
+//    builds 14 .. 8002 of 37 000, fenced or not.  Every hazard distance in the failing
+//    instruction stream was checked against hardware probes (tools/mfma_branch_hazard_probe.hip,
+//    tools/sgpr_war_probe.hip, tools/mfma_hazard_probe.hip) and holds; the mechanism is still
+//    not named, so no split-f16 state ships and none can be built by a flag.  Commit 23fac5d
+//    holds the study's knobs (OETR_SPLIT_STATE, OETR_HZ).
 
 namespace oetr {
 
@@ -106,36 +88,7 @@ __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& ac
   const float inv_len = 1.0f / (float)S_len;
   kv = f32x16{0};
   ksum = 0.f;
-  if constexpr (gm_f16_range(MODE) && OETR_SPLIT_STATE) {
-    // f16-based modes: the 32-token contraction as 2 k16 steps of the fp32-class split
-    // (6 f16 MFMAs = 192 matrix-pipe cycles instead of 16 f32 MFMAs = 1024).  Lane (d, half)
-    // supplies, for k-slot 8*half + i of step s, the token in its accumulator register
-    // 8s + i - the same token in the phi(K) (A) and V (B) operand, which is all the
-    // contraction needs.
-    f32x16 c1 = {0};
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x4 k0, k1, v0, v1;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = 8 * s + i;
-        const float m = crow(r, half) < nvalid ? 1.0f : 0.0f;
-        const float x = accK[r];
-        const float kk = (skip_phi ? x : elu1(x)) * m;
-        const float vv = accV[r] * (inv_len * m);
-        ksum += kk;
-        if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
-      }
-      f32x4 ah, al, bh, bl;
-      split8(k0, k1, ah, al, rg);
-      split8(v0, v1, bh, bl, rg);
-      mma16_split3(ah, al, bh, bl, kv, c1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
-  } else {
-#if OETR_STATE_PIPELINED
+  {
     // One f32 MFMA (64 matrix-pipe cycles) per accumulator register: the operands of register
     // r + 1 - phi, row mask, 1/S - are computed while the MFMA of register r runs (a fence per
     // step keeps hipcc from batching the exps; same operations in the same order: same bits).
@@ -156,23 +109,6 @@ __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& ac
       __builtin_amdgcn_sched_barrier(0);
       kc = kn; vc = vn;
     }
-#else
-#pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 4) {
-      float k[4], v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float m = crow(r0 + j, half) < nvalid ? 1.0f : 0.0f;
-        const float x = accK[r0 + j];
-        k[j] = (skip_phi ? x : elu1(x)) * m;
-        v[j] = accV[r0 + j] * (inv_len * m);
-        ksum += k[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
   }
 }
 
@@ -639,7 +575,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
       f32x16 macc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) macc[t] = f32x16{0};
-      if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
+      if constexpr (gm_f16_range(MODE)) {
         // phi(Q).KV as 2 k16 steps of the fp32-class split per head (same reads of the
         // phi(Q) tile; k-slot 8*half + i of step s <-> d = 16s + 8*(i>>2) + 4*half + (i&3)
         // in BOTH operands)
@@ -653,7 +589,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
             split8(*reinterpret_cast<const f32x4*>(qrow), *reinterpret_cast<const f32x4*>(qrow + 8),
                    ah, al, rg);
             split8(kvB[t][2 * s2], kvB[t][2 * s2 + 1], bh, bl, rg);
-            mma16_split3<OETR_APPLY_FENCE != 0>(ah, al, bh, bl, macc[t], c1);
+            mma16_split3(ah, al, bh, bl, macc[t], c1);
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) macc[t][r] = fmaf(c1[r], SPLIT_INV, macc[t][r]);
@@ -947,9 +883,8 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
                                             int S_len, int nvalid, int half, bool two, f32x16& kv,
                                             float& ksum, Range& rg) {
   // Branch-free phi (common.h: elu1, a median) on scalars, a few at a time: unfenced, hipcc
-  // schedules all 32 exps at once and spills.  A row tile whose 32 rows are all valid (every
-  // tile of an image but its last) takes the path without the row masks - a workgroup-uniform
-  // branch per row tile.
+  // schedules all 32 exps at once and spills.  ONE code path with the row masks for every tile
+  // (see the file header: no run-time choice between a masked and an unmasked form).
   const float inv_len = 1.0f / (float)S_len;
   kv = f32x16{0};
   ksum = 0.f;
@@ -957,68 +892,7 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
   //  clamps at the top of the kernel and 32 values live - spilled - until here)
   int nv2 = nvalid - 4 * half;
   asm volatile("" : "+v"(nv2));
-  if constexpr (gm_f16_range(MODE) && OETR_SPLIT_STATE) {
-    // 64-token contraction as 4 k16 steps of the fp32-class split (see kv_state_32)
-    f32x16 c1 = {0};
-    auto row_tile = [&](auto MT_, auto MASKED_) {
-      constexpr int mt = decltype(MT_)::value;
-      constexpr bool MASKED = decltype(MASKED_)::value;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        f32x4 k0, k1, v0, v1;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int r = 8 * s + i;
-          const float x = accK[mt][r];
-          float kk = elu1(x), vv;
-          if constexpr (MASKED) {
-            const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
-            kk *= m;
-            vv = accV[mt][r] * (inv_len * m);
-          } else {
-            vv = accV[mt][r] * inv_len;
-          }
-          ksum += kk;
-          if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
-        }
-        f32x4 ah, al, bh, bl;
-        split8(k0, k1, ah, al, rg);
-        split8(v0, v1, bh, bl, rg);
-        mma16_split3(ah, al, bh, bl, kv, c1);
-        __builtin_amdgcn_sched_barrier(0);
-#if OETR_HZ & 32
-        asm volatile(OETR_HZ_NOP64);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-#if OETR_HZ & 1     // study: the unmasked path always (rows past the end hold finite duplicates)
-    row_tile(I0{}, std::false_type{});
-    if (two) row_tile(I1{}, std::false_type{});
-#elif OETR_HZ & 256   // study: the masked path always
-    row_tile(I0{}, std::true_type{});
-    if (two) row_tile(I1{}, std::true_type{});
-#elif OETR_HZ & 512   // study: the run-time branch kept, BOTH sides the masked path (a tag keeps hipcc from merging them)
-    if (nvalid >= 32) { asm volatile("; full row tile 0"); row_tile(I0{}, std::true_type{}); }
-    else { asm volatile("; ragged row tile 0"); row_tile(I0{}, std::true_type{}); }
-    if (two) {
-      if (nvalid >= 64) { asm volatile("; full row tile 1"); row_tile(I1{}, std::true_type{}); }
-      else { asm volatile("; ragged row tile 1"); row_tile(I1{}, std::true_type{}); }
-    }
-#else
-    if (nvalid >= 32) row_tile(I0{}, std::false_type{});
-    else row_tile(I0{}, std::true_type{});
-    if (two) {   // (else: no valid row in the second row tile)
-      if (nvalid >= 64) row_tile(I1{}, std::false_type{});
-      else row_tile(I1{}, std::true_type{});
-    }
-#endif
-#pragma unroll
-    for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
-  } else {
-#if OETR_STATE_PIPELINED
+  {
     // (see kv_state_32: the operands of the next register under the current f32 MFMA)
     auto row_tile = [&](auto MT_) {
       constexpr int mt = decltype(MT_)::value;
@@ -1042,27 +916,6 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
     };
     row_tile(std::integral_constant<int, 0>{});
     if (two) row_tile(std::integral_constant<int, 1>{});   // (else: no valid row in the second row tile)
-#else
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if (mt == 1 && !two) break;  // no valid row in the second row tile
-#pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += 4) {
-        float k[4], v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float m = 32 * mt + crow(r0 + j, 0) < nv2 ? 1.0f : 0.0f;
-          const float x = accK[mt][r0 + j];
-          k[j] = (elu1(x)) * m;
-          ksum += k[j];
-          v[j] = accV[mt][r0 + j] * (inv_len * m);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(k[j], v[j], kv, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#endif
   }
   ksum += __shfl_xor(ksum, 32, 64);
 }
@@ -1216,7 +1069,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       f32x4 kvh[2], kvl[2], ksh[2], ksl[2];
       const float inv_S = 1.0f / (float)S_len;
       (void)inv_S;
-      if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
+      if constexpr (gm_f16_range(MODE)) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           split8(kvB[2 * s2], kvB[2 * s2 + 1], kvh[s2], kvl[s2], rg);
@@ -1231,13 +1084,13 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       for (int mt = 0; mt < 2; ++mt) {
         if (mt == 1 && !ws.two()) break;  // ragged tile: rows 32.. are never stored
         f32x16 macc = {0}, zacc = {0};
-        if constexpr (gm_f16_range(MODE) && OETR_SPLIT_APPLY) {
+        if constexpr (gm_f16_range(MODE)) {
           f32x16 c1 = {0}, cz = {0};
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const f32x4 qh = qfrag[mt][2 * s2], ql = qfrag[mt][2 * s2 + 1];
-            mma16_split3<OETR_APPLY_FENCE != 0>(kvh[s2], kvl[s2], qh, ql, macc, c1);
-            mma16_split3<OETR_APPLY_FENCE != 0>(ksh[s2], ksl[s2], qh, ql, zacc, cz);
+            mma16_split3(kvh[s2], kvl[s2], qh, ql, macc, c1);
+            mma16_split3(ksh[s2], ksl[s2], qh, ql, zacc, cz);
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) macc[r] = fmaf(c1[r], SPLIT_INV, macc[r]);
@@ -1254,7 +1107,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
             }
           }
         }
-        const float zdot = gm_f16_range(MODE) && OETR_SPLIT_APPLY ? zacc[0] * (float)S_len : zacc[0];
+        const float zdot = gm_f16_range(MODE) ? zacc[0] * (float)S_len : zacc[0];
         const float zs = (float)S_len / (zdot + ATTN_EPS);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
@@ -1327,7 +1180,6 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       constexpr int SNEXT = TAIL == 0 ? SP::Q : SP::DEC_K;   // first GEMM of the tail
       constexpr bool XTR = true;                            // residual stream in the transposed layout
       f32x16 haccA[2] = {f32x16{0}, f32x16{0}}, haccB[2] = {f32x16{0}, f32x16{0}};
-#if OETR_MLP1_TR
       // MLP1 runs TRANSPOSED (WStream2T: TR): a lane then holds, per register quad, FOUR
       // CONSECUTIVE hidden channels of one token - the GELU epilogue writes its planes with
       // 8-byte LDS stores (2 per quad) instead of 2-byte ones (8 per quad), one quad = two
@@ -1340,40 +1192,14 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
           constexpr int CI = decltype(CI_)::value, mt = CI / 8, g4 = (CI % 8) / 2;
           if constexpr (CI % 2 == 0) {
             if (mt == 1 && !two) return;   // (hidden rows 32.. stay unwritten: never consumed)
-#if OETR_ABL_EPI == 1      // timing ablation only (wrong results): no GELU arithmetic
-            const f32x4 ge = f32x4{h[mt][4 * g4], h[mt][4 * g4 + 1], h[mt][4 * g4 + 2], h[mt][4 * g4 + 3]};
-#else
             const f32x4 ge = gelu_erf4(f32x4{h[mt][4 * g4], h[mt][4 * g4 + 1], h[mt][4 * g4 + 2], h[mt][4 * g4 + 3]});
-#endif
-#if OETR_ABL_EPI == 2      // timing ablation only: GELU kept alive, no split conversion / plane stores
-            if (ge[0] + ge[1] + ge[2] + ge[3] == 123.456f) dst.h[lane] = (_Float16)1;
-#elif OETR_ABL_EPI == 3    // timing ablation only: nothing at all
-            (void)ge;
-#else
             dst.template put4<site_act_lo(SP::MLP2)>(32 * mt + col, wcol + 8 * g4 + 4 * half, ge);
-#endif
           }
         };
       };
       auto epiA = gelu_to(P2, haccA);
       ws.template gemm_epi<C, P_1B, true, FF, SP::MLP1, SP::MLP2, true>(P1, p.b.w1, p.b.w1_l, 8 + wave, 0, lane,
                                                                         haccB, p.b.w2, p.b.w2_l, wave, 0, epiA);
-#else
-      ws.template gemm<C, P_1A, true, C, SP::MLP1, SP::MLP1>(P1, p.b.w1, p.b.w1_l, wave, 0, lane, haccA,
-                                                             p.b.w1, p.b.w1_l, 8 + wave, 0);
-      const bool two = ws.two();
-      auto gelu_to = [&](const PlanesT<MODE>& dst, const f32x16 (&h)[2]) {
-        return [&, two](auto CI_) {   // two accumulator values (one packed GELU) per k16 step
-          constexpr int CI = decltype(CI_)::value, mt = CI / 8, r = 2 * (CI % 8);
-          if (mt == 1 && !two) return;   // (hidden rows 32.. stay unwritten: never consumed)
-          const f32x2 ge = gelu_erf2(f32x2{h[mt][r], h[mt][r + 1]});
-          dst.template put_pair<r, site_act_lo(SP::MLP2)>(mt, wcol, lane, ge[0], ge[1]);
-        };
-      };
-      auto epiA = gelu_to(P2, haccA);
-      ws.template gemm_epi<C, P_1B, true, FF, SP::MLP1, SP::MLP2>(P1, p.b.w1, p.b.w1_l, 8 + wave, 0, lane,
-                                                                  haccB, p.b.w2, p.b.w2_l, wave, 0, epiA);
-#endif
       __syncthreads();   // hidden half a complete; every wave is done reading the LN2 planes
       PHASE_STAMP(p, 5);
       auto epiB = gelu_to(P1, haccB);
@@ -1504,29 +1330,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     PHASE_STAMP(p, 11);
     f32x16 kv;
     float ksum;
-#if OETR_HZ & 2
-    __syncthreads();
-#endif
-#if OETR_HZ & 4
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-#if OETR_HZ & 8
-    asm volatile(OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64
-                 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64);
-#endif
-#if OETR_HZ & 64
-    __builtin_amdgcn_s_setprio(3);
-#endif
     kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
-#if OETR_HZ & 64
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#if OETR_HZ & 16
-    __syncthreads();
-#endif
-#if OETR_HZ & 128
-    asm volatile(OETR_HZ_NOP64 ::: "memory");
-#endif
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
     // (the LayerNorm exchange buffer is dead after phase B)
@@ -1568,29 +1372,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
                                                    nullptr, 0, 0);
       f32x16 kv;
       float ksum;
-#if OETR_HZ & 2
-      __syncthreads();
-#endif
-#if OETR_HZ & 4
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-#if OETR_HZ & 8
-      asm volatile(OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64
-                   OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64 OETR_HZ_NOP64);
-#endif
-#if OETR_HZ & 64
-      __builtin_amdgcn_s_setprio(3);
-#endif
       kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
-#if OETR_HZ & 64
-      __builtin_amdgcn_s_setprio(0);
-#endif
-#if OETR_HZ & 16
-      __syncthreads();
-#endif
-#if OETR_HZ & 128
-      asm volatile(OETR_HZ_NOP64 ::: "memory");
-#endif
       if constexpr (dl == 1) {
         kv_state_write(kv, ksum, lane, wave, p.dkv1_out, p.dks1_out, slot);
       } else {
