@@ -13,6 +13,10 @@
 
 using namespace oetr;
 
+// oetr_set_state_prereduce(h, -1): source tokens per image from which the partial linear-attention
+// states are summed by a launch of their own (see forward_impl)
+constexpr int OETR_PREREDUCE_MIN_TOKENS = 768;
+
 namespace {
 
 thread_local std::string g_err;
@@ -136,7 +140,7 @@ struct oetr_ctx {
   oetr_trace* trace = nullptr;
   int device = 0;
   int mode = GM_SPLIT;  // GEMM mode GM_* (common.h) of the oetr_dtype
-  int kv_prereduce = 0; // oetr_set_state_prereduce
+  int kv_prereduce = -1; // oetr_set_state_prereduce (-1 = auto)
   int policy = 0;       // precision policy (SitePolicy<>) of the oetr_dtype: 1 = OETR_DTYPE_F32_SPLIT_QK16
   int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
   int attn_full = 0;   // OETR_ATTENTION_FULL (oetr_set_attention)
@@ -361,7 +365,12 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   // chain - serial steps slower, overlapped throughput unchanged).  2 = by the LAST workgroup of
   // the image to finish, inside the launch that writes the partials (encoder.hip:
   // reduce_states_last_arriver; the counters are zeroed here, once per call).
-  const int prereduce = h->attn_full ? 0 : h->kv_prereduce;
+  // -1 (default) = auto: the reduction launch pays once an image has many partials - measured on
+  // MI355X, 64-row tiles (profiles/r4_prereduce_auto.txt): 400 tokens per image (7 partials) +0.9 %
+  // step time with it, 1024 tokens (16) -3.9 % (k_encoder64<B,A> 246 -> 225 us), 1600 tokens (25)
+  // -4.2 % (120 -> 105 us) - so it is on from OETR_PREREDUCE_MIN_TOKENS source tokens per image.
+  int prereduce = h->attn_full ? 0 : h->kv_prereduce;
+  if (prereduce < 0) prereduce = (g.L[0] >= OETR_PREREDUCE_MIN_TOKENS || g.L[1] >= OETR_PREREDUCE_MIN_TOKENS) ? 1 : 0;
   const size_t cnt_per_launch = (size_t)2 * g.N;
   p.kvr_out = p.ksr_out = nullptr; p.red_cnt = nullptr;
   if (prereduce == 2) {
@@ -1266,7 +1275,7 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows) {
 
 oetr_status oetr_set_state_prereduce(oetr_handle h, int on) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: NULL handle");
-  if (on < 0 || on > 2) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: 0 (off), 1 (own launch) or 2 (in-launch, last arriver)");
+  if (on < -1 || on > 2) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: -1 (auto), 0 (off), 1 (own launch) or 2 (in-launch, last arriver)");
   h->kv_prereduce = on;
   return OETR_OK;
 }

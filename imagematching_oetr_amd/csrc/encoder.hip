@@ -1523,46 +1523,44 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
 // item of its prologue).  Same summation order as the in-kernel loop (tile 0, 1, ...):
 // bit-identical results.  One wave per (image, head).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_kv_reduce(Geom g, const float* __restrict__ kvp,
-                                                  const float* __restrict__ ksp, float* __restrict__ kvr,
-                                                  float* __restrict__ ksr) {
-  const int img = blockIdx.x >> 3, head = blockIdx.x & 7, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_kv_reduce(Geom g, const float* __restrict__ kvp,
+                                                   const float* __restrict__ ksp, float* __restrict__ kvr,
+                                                   float* __restrict__ ksr) {
+  // one workgroup per (image, head), wave e sums the e-th 1-KB quarter of the head's 4-KB state
+  // over the image's tiles (round 4: four waves instead of one per state - 9.5 -> see profiles)
+  const int img = blockIdx.x >> 3, head = blockIdx.x & 7, lane = threadIdx.x & 63;
+  const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int side = img >= g.N, n = img - side * g.N;
   const int nt = g.nt[side];
   const int slot0 = g.tile0[side] + n * nt;
-  const f32x4* src = reinterpret_cast<const f32x4*>(kvp) + ((size_t)slot0 * NH + head) * 256 + lane;
+  const f32x4* src = reinterpret_cast<const f32x4*>(kvp) + ((size_t)slot0 * NH + head) * 256 + e * 64 + lane;
   const float* ks = ksp + (size_t)slot0 * C + head * HD + (lane & 31);
-  f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
-                  f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   float kacc = 0.f;
-  constexpr int U = 8;   // tiles in flight per round trip
+  constexpr int U = 16;   // tiles in flight per round trip
   for (int t0 = 0; t0 < nt; t0 += U) {
-    f32x4 tmp[U][4];
+    f32x4 tmp[U];
     float kt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = min(t0 + u, nt - 1);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) tmp[u][e] = src[(size_t)t * (NH * 256) + e * 64];
+      tmp[u] = src[(size_t)t * (NH * 256)];
       kt[u] = ks[(size_t)t * C];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (t0 + u < nt) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += tmp[u][e];
+        acc += tmp[u];
         kacc += kt[u];
       }
   }
-  f32x4* dst = reinterpret_cast<f32x4*>(kvr) + ((size_t)img * NH + head) * 256 + lane;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) dst[e * 64] = acc[e];
-  if (lane < 32) ksr[(size_t)img * C + head * HD + lane] = kacc;
+  reinterpret_cast<f32x4*>(kvr)[((size_t)img * NH + head) * 256 + e * 64 + lane] = acc;
+  if (e == 0 && lane < 32) ksr[(size_t)img * C + head * HD + lane] = kacc;
 }
 
 hipError_t launch_kv_reduce(const Geom& g, const float* kvp, const float* ksp, float* kvr, float* ksr,
                             hipStream_t s) {
-  hipLaunchKernelGGL(k_kv_reduce, dim3(2 * g.N * NH), dim3(64), 0, s, g, kvp, ksp, kvr, ksr);
+  hipLaunchKernelGGL(k_kv_reduce, dim3(2 * g.N * NH), dim3(256), 0, s, g, kvp, ksp, kvr, ksr);
   return hipGetLastError();
 }
 

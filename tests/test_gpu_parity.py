@@ -412,3 +412,23 @@ def test_state_prereduce_is_bit_identical(gpu, tile, mode, precision):
             assert torch.equal(a[k], b[k]), (k, rep)
     with pytest.raises(Exception):
         eng.set_state_prereduce(3)
+
+
+def test_state_prereduce_auto_switches_on_by_size_and_changes_no_bit(gpu):
+    """The library default (-1 = auto) runs the reduction launch from 768 source tokens per image
+    (measured: it pays from about there, profiles/r4_prereduce_auto.txt) and not below; either way
+    the boxes are those of the setting 0, bit for bit."""
+    from imagematching_oetr_amd import HotPathEngine, KernelTrace
+    w = orc.make_hot_weights(2, sharpen=True)
+    for (h1, w1, h2, w2), expect_launches in (((28, 28, 20, 20), 8), ((20, 20, 25, 25), 0)):
+        f1, f2 = orc.make_features(71, 2, h1, w1).to(gpu), orc.make_features(72, 2, h2, w2).to(gpu)
+        p1, p2 = orc.position_table(h1, w1).to(gpu), orc.position_table(h2, w2).to(gpu)
+        eng = HotPathEngine(w, device=gpu)
+        with KernelTrace(eng) as tr:
+            a = eng.forward(f1, f2, p1, p2, (h1 * 32, w1 * 32), (h2 * 32, w2 * 32), stages=True)
+            torch.cuda.synchronize()
+        assert tr.summary().get('k_kv_reduce', (0, 0.0))[0] == expect_launches
+        eng.set_state_prereduce(0)
+        b = eng.forward(f1, f2, p1, p2, (h1 * 32, w1 * 32), (h2 * 32, w2 * 32), stages=True)
+        for k in ('memory1', 'memory2', 'hs1', 'hs2', 'box1', 'box2'):
+            assert torch.equal(a[k], b[k]), k
