@@ -905,12 +905,12 @@ struct WStream<M, 1, true> {
 constexpr int RT = 64;                                   // token rows per workgroup
 constexpr int R_FLOATS = (2 * RT * LDAH * 2 + 3) / 4;    // 16896 >= RT * LDA = 16640
 static_assert(R_FLOATS >= RT * LDA, "region holds the f32 tile too");
-template <int M>
-struct PlanesT {  // 16-bit planes [RT][LDAH] (hi, and lo*2^11 in GM_SPLIT) in one region
+template <int M, int ROWS_P = RT>
+struct PlanesT {  // 16-bit planes [ROWS_P][LDAH] (hi, and lo*2^11 in GM_SPLIT) in one region; ROWS_P = 64 or 32 token rows
   _Float16 *h, *l;
   Range* rg;
   __device__ __forceinline__ PlanesT(float* base, Range* rg_)
-      : h(reinterpret_cast<_Float16*>(base)), l(reinterpret_cast<_Float16*>(base) + RT * LDAH), rg(rg_) {}
+      : h(reinterpret_cast<_Float16*>(base)), l(reinterpret_cast<_Float16*>(base) + ROWS_P * LDAH), rg(rg_) {}
   // LO = false: the consumer site reads the hi plane only (common.h: SITE_*), the lo plane is
   // not written
   template <bool LO = true>
@@ -942,6 +942,9 @@ typedef PlanesT<GM_SPLIT> Planes2;
 #ifndef OETR_RING2_1P
 #define OETR_RING2_1P 4   // the same for the single-plane modes
 #endif
+#ifndef OETR_RING2_32
+#define OETR_RING2_32 6   // ... and for the 32-row form of the body (NMT = 1)
+#endif
 struct NoEpi { template <class T> __device__ __forceinline__ void operator()(T) const {} };
 
 // ROWS: how many of the tile's two 32-row MFMA tiles run.  2 / 1: fixed at compile time - the
@@ -951,12 +954,18 @@ struct NoEpi { template <class T> __device__ __forceinline__ void operator()(T) 
 // second-tile MFMA: conv-P work items, single-plane modes - measured better there: their steps
 // are two MFMAs long).  With one row tile the accumulators of the second keep their (finite)
 // initial values, which every consumer masks by row validity.
-template <int M, int ROWS = 0>
+// NMT: MFMA row tiles of the workgroup's token tile - 2 (64 token rows, the shape all of the above
+// describes) or 1 (32 token rows: round 4's form of the 32-row encoder - the same body with one
+// row tile, so a fragment feeds 3 MFMAs instead of 6 and the GEMM phases are bound by the weight
+// stream again; ROWS is then irrelevant).
+template <int M, int ROWS = 0, int NMT = 2>
 struct WStream2T {
   static constexpr bool TWO = gm_planes(M) == 2;
-  static constexpr int D = TWO ? OETR_RING2 : OETR_RING2_1P, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
+  // (one row tile: the GEMM phases are bound by the weight stream, which wants more fragments in flight -
+  //  and the registers of the second row tile are free for them)
+  static constexpr int D = NMT == 1 ? OETR_RING2_32 : TWO ? OETR_RING2 : OETR_RING2_1P, PRE = D - 1, NS = C / 16;  // every GEMM here has K = 256: 16 steps
   struct BStep { f32x4 bh, bl; };
-  struct AStep { f32x4 ah[2], al[2]; };
+  struct AStep { f32x4 ah[NMT], al[NMT]; };
   BStep ring[D];
   bool two_rt = true;
   // lane as the LAST, 32-bit index of every fragment address: the slab pointers stay uniform
@@ -964,9 +973,9 @@ struct WStream2T {
   // the per-step address arithmetic is SALU work
   unsigned ln = 0;
   __device__ __forceinline__ void set_lane(int lane) { ln = (unsigned)lane; }
-  __device__ __forceinline__ bool two() const { return ROWS == 2 || (ROWS == 0 && two_rt); }
+  __device__ __forceinline__ bool two() const { return NMT == 2 && (ROWS == 2 || (ROWS == 0 && two_rt)); }
   __device__ __forceinline__ void set_rows(int nvalid) {
-    if constexpr (ROWS == 0) two_rt = __builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0) != 0;
+    if constexpr (ROWS == 0 && NMT == 2) two_rt = __builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0) != 0;
   }
   static constexpr int adv(int P) { return (P + NS) % D; }
 
@@ -995,7 +1004,7 @@ struct WStream2T {
   __device__ __forceinline__ static void load_a(AStep& a, const _Float16* ah_ptr, const _Float16* al_ptr,
                                                 int step) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
       a.ah[mt] = *reinterpret_cast<const f32x4*>(ah_ptr + mt * 32 * LDAH + step * 16);
       if constexpr (TWO && site_act_lo(SITE))
         a.al[mt] = *reinterpret_cast<const f32x4*>(al_ptr + mt * 32 * LDAH + step * 16);
@@ -1014,8 +1023,8 @@ struct WStream2T {
   template <int P, bool HAS_NEXT, int CI, class EPI, bool TR, int SITE, int NSITE>
   __device__ __forceinline__ void step(const _Float16* ah_ptr, const _Float16* al_ptr,
                                        const f32x4* wh, const f32x4* wl, const f32x4* nwh,
-                                       const f32x4* nwl, AStep (&a)[2], f32x16 (&acc)[2],
-                                       f32x16 (&cross)[2], EPI& epi) {
+                                       const f32x4* nwl, AStep (&a)[2], f32x16 (&acc)[NMT],
+                                       f32x16 (&cross)[NMT], EPI& epi) {
     if constexpr (CI < NS) {
       constexpr int PF = CI + PRE;
       if constexpr (PF < NS) fetch<(P + PF) % D, SITE>(wh, wl, PF);
@@ -1029,16 +1038,15 @@ struct WStream2T {
         if constexpr (TR) return mma16<M>(wgt, act, c);
         else return mma16<M>(act, wgt, c);
       };
-      const bool t2 = two();
       acc[0] = mm(ac.ah[0], b.bh, acc[0]);
-      if (t2) acc[1] = mm(ac.ah[1], b.bh, acc[1]);
+      if constexpr (NMT == 2) { if (two()) acc[1] = mm(ac.ah[1], b.bh, acc[1]); }
       if constexpr (TWO && site_w_lo(SITE)) {
         cross[0] = mm(ac.ah[0], b.bl, cross[0]);
-        if (t2) cross[1] = mm(ac.ah[1], b.bl, cross[1]);
+        if constexpr (NMT == 2) { if (two()) cross[1] = mm(ac.ah[1], b.bl, cross[1]); }
       }
       if constexpr (TWO && site_act_lo(SITE)) {
         cross[0] = mm(ac.al[0], b.bh, cross[0]);
-        if (t2) cross[1] = mm(ac.al[1], b.bh, cross[1]);
+        if constexpr (NMT == 2) { if (two()) cross[1] = mm(ac.al[1], b.bh, cross[1]); }
       }
       __builtin_amdgcn_sched_barrier(0);
       step<P, HAS_NEXT, CI + 1, EPI, TR, SITE, NSITE>(ah_ptr, al_ptr, wh, wl, nwh, nwl, a, acc, cross, epi);
@@ -1049,18 +1057,18 @@ struct WStream2T {
   // (nW, nWl, nnt0, nks0 of a matrix with NKTOT/16 steps per n-tile, arithmetic NSITE) is
   // primed meanwhile.
   template <int KTOT, int P, bool HAS_NEXT, int NKTOT, int SITE = SITE_FULL, int NSITE = SITE_FULL,
-            bool TR = false>
-  __device__ __forceinline__ void gemm(const PlanesT<M>& A, const f32x4* W, const f32x4* Wl, int nt0,
-                                       int ks0, int lane, f32x16 (&acc)[2], const f32x4* nW,
+            bool TR = false, int RP>
+  __device__ __forceinline__ void gemm(const PlanesT<M, RP>& A, const f32x4* W, const f32x4* Wl, int nt0,
+                                       int ks0, int lane, f32x16 (&acc)[NMT], const f32x4* nW,
                                        const f32x4* nWl, int nnt0, int nks0) {
     NoEpi none;
     gemm_epi<KTOT, P, HAS_NEXT, NKTOT, SITE, NSITE, TR>(A, W, Wl, nt0, ks0, lane, acc, nW, nWl, nnt0,
                                                         nks0, none);
   }
   template <int KTOT, int P, bool HAS_NEXT, int NKTOT, int SITE = SITE_FULL, int NSITE = SITE_FULL,
-            bool TR = false, class EPI>
-  __device__ __forceinline__ void gemm_epi(const PlanesT<M>& A, const f32x4* W, const f32x4* Wl, int nt0,
-                                           int ks0, int lane, f32x16 (&acc)[2], const f32x4* nW,
+            bool TR = false, class EPI, int RP>
+  __device__ __forceinline__ void gemm_epi(const PlanesT<M, RP>& A, const f32x4* W, const f32x4* Wl, int nt0,
+                                           int ks0, int lane, f32x16 (&acc)[NMT], const f32x4* nW,
                                            const f32x4* nWl, int nnt0, int nks0, EPI& epi) {
     const size_t off = ((size_t)nt0 * (KTOT / 16) + ks0) * 64;
     const size_t noff = ((size_t)nnt0 * (NKTOT / 16) + nks0) * 64;
@@ -1069,13 +1077,15 @@ struct WStream2T {
     const _Float16* al_ptr = A.l + a_off;
     AStep a[2];
     load_a<SITE>(a[0], ah_ptr, al_ptr, 0);
-    f32x16 cross[2] = {f32x16{0}, f32x16{0}};
+    f32x16 cross[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) cross[mt] = f32x16{0};
     step<P, HAS_NEXT, 0, EPI, TR, SITE, NSITE>(ah_ptr, al_ptr, W + off, Wl + off,
                                                HAS_NEXT ? nW + noff : nullptr,
                                                HAS_NEXT ? nWl + noff : nullptr, a, acc, cross, epi);
     if constexpr (TWO && SITE != SITE_HI) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(cross[mt][r], SPLIT_INV, acc[mt][r]);
     }
@@ -1135,6 +1145,8 @@ struct EncLaunch {
   size_t vt_off[2];      // first float of the side's images in vt
   int tile_rows;         // token rows per workgroup: 32 (TM) or 64 (split mode, k_encoder64);
                          // g.nt / g.tile0 / g.ntiles are in units of this tile
+  int enc32_modern;      // tile_rows == 32, two-plane mode, linear attention: k_encoder32m (the 64-row
+                         // kernel's body on one row tile; phi(Q) buffer fragment-major) instead of k_encoder
   int b_cross;           // phase-B layer is a cross layer
   int kv_reduced;        // kv_in / ks_in hold ONE reduced state per image ([2N][8192] / [2N][256], side 0
                          // first) instead of per-tile partials: k_kv_reduce ran between the launches,

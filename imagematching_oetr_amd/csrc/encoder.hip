@@ -869,17 +869,20 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 // The per-wave weight stream (WStream2) is a ring of 6 k16-steps of B fragments
 // (5 in flight) running ahead across GEMM calls like WStream.
 // ===========================================================================
-constexpr int E2_R1 = 0;
-constexpr int E2_R2 = R_FLOATS;
-constexpr int E2_KSUM = 2 * R_FLOATS;
-constexpr int E2_LNP = E2_KSUM + C;
 constexpr int LNX_LD = 36;                               // (padded: 16 lanes' b128 reads hit 16 bank groups)
-constexpr int E2_LNX = E2_LNP + 6 * C;                   // LayerNorm partial statistics [64 tokens][16][mean, M2]
-constexpr int E2_SMEM = E2_LNX + RT * LNX_LD;            // 37888 floats = 148 KB
+// LDS layout (floats) of a workgroup of RTW = 64 or 32 token rows: 148 KB / 77.5 KB
+template <int RTW>
+struct E2 {
+  static constexpr int RFL = (2 * RTW * LDAH * 2 + 3) / 4;   // one region: planes hi | lo, or the f32 tile
+  static_assert(RFL >= RTW * LDA, "region holds the f32 tile too");
+  static constexpr int R1 = 0, R2 = RFL, KSUM = 2 * RFL, LNP = KSUM + C;
+  static constexpr int LNX = LNP + 6 * C;                    // LayerNorm partial statistics [tokens][16][mean, M2]
+  static constexpr int SMEM = LNX + RTW * LNX_LD;
+};
 
 // phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
-template <int MODE>
-__device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x16 (&accV)[2],
+template <int MODE, int NMT = 2>
+__device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[NMT], const f32x16 (&accV)[NMT],
                                             int S_len, int nvalid, int half, bool two, f32x16& kv,
                                             float& ksum, Range& rg) {
   // Branch-free phi (common.h: elu1, a median) on scalars, a few at a time: unfenced, hipcc
@@ -915,7 +918,9 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[2], const f32x1
       }
     };
     row_tile(std::integral_constant<int, 0>{});
-    if (two) row_tile(std::integral_constant<int, 1>{});   // (else: no valid row in the second row tile)
+    if constexpr (NMT == 2) {
+      if (two) row_tile(std::integral_constant<int, 1>{});   // (else: no valid row in the second row tile)
+    }
   }
   ksum += __shfl_xor(ksum, 32, 64);
 }
@@ -934,24 +939,30 @@ __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int
 // Body of k_encoder64 for one workgroup.  ROWS (WStream2T): 2 = both 32-row MFMA tiles hold valid
 // rows, 1 = only the first does (a ragged last tile of an image: every piece of work on the
 // second row tile is compiled out), 0 = decided at run time (single-plane modes).
-template <bool HAS_B, int TAIL, int MODE, int POL, int ROWS>
+// RTW: token rows of the workgroup, 64 (two MFMA row tiles) or 32 (one: round 4's 32-row encoder,
+// the same body - transposed residual stream, fragment-major phi(Q), epilogues beside MFMAs -
+// with a weight fragment feeding 3 MFMAs instead of 6).
+template <bool HAS_B, int TAIL, int MODE, int POL, int ROWS, int RTW = RT>
 __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) {
-  constexpr int THREADS = 512, TPR = 8, F4 = 8;
+  constexpr int NMT = RTW / 32, THREADS = 512, TPR = THREADS / RTW, F4 = 64 / TPR;
+  using L2 = E2<RTW>;
   using SP = SitePolicy<POL>;   // arithmetic per GEMM site (two-plane mode only)
-  float* R1f = smem + E2_R1;
-  float* R2f = smem + E2_R2;
+  float* R1f = smem + L2::R1;
+  float* R2f = smem + L2::R2;
   Range rg;
-  const PlanesT<MODE> P1(R1f, &rg), P2(R2f, &rg);
+  const PlanesT<MODE, RTW> P1(R1f, &rg), P2(R2f, &rg);
   // f32 staging tile of the residual stream between phase B and the tail (LayerNorm input):
   // R2 after phase B (R1 then holds the second hidden half until MLP2b has read it)
   float* Xf = HAS_B ? R2f : R1f;
-  float* ksum_s = smem + E2_KSUM;
-  float* lnp_s = smem + E2_LNP;
-  float* lnx_s = smem + E2_LNX;
-  using WS = WStream2T<MODE, ROWS>;
+  float* ksum_s = smem + L2::KSUM;
+  float* lnp_s = smem + L2::LNP;
+  float* lnx_s = smem + L2::LNX;
+  using WS = WStream2T<MODE, ROWS, NMT>;
   WS ws;
   constexpr int P_MERGE = 0;
-  constexpr int P_1A = WS::adv(P_MERGE), P_2A = WS::adv(P_1A), P_1B = WS::adv(P_2A), P_2B = WS::adv(P_1B);
+  // (in EXECUTION order: merge, MLP1a, MLP1b, MLP2a, MLP2b - round 3 chained them as 1a, 2a, 1b, 2b, which
+  //  only a ring depth dividing 16 forgives)
+  constexpr int P_1A = WS::adv(P_MERGE), P_1B = WS::adv(P_1A), P_2A = WS::adv(P_1B), P_2B = WS::adv(P_2A);
   constexpr int P_T0 = HAS_B ? WS::adv(P_2B) : 0;
   constexpr int P_T1 = WS::adv(P_T0), P_T2 = WS::adv(P_T1), P_T3 = WS::adv(P_T2);
 
@@ -970,11 +981,11 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   const int side = rem >= g.nt[0];
   const int t_idx = side ? rem - g.nt[0] : rem;
   const int L = g.L[side];
-  const int l0 = t_idx * RT;
-  const int nvalid = min(RT, L - l0);
+  const int l0 = t_idx * RTW;
+  const int nvalid = min(RTW, L - l0);
   const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
   const int slot = g.tile0[side] + n * g.nt[side] + t_idx;
-  const size_t qrow_base = (size_t)slot * RT;   // this tile's rows of the TILE-major phi(Q) buffer
+  const size_t qrow_base = (size_t)slot * RTW;   // this tile's rows of the TILE-major phi(Q) buffer
   const bool nchw = !HAS_B && p.feat_nchw[0] != nullptr;   // first launch on NCHW inputs (launch-uniform)
   ws.set_rows(nvalid);
   ws.set_lane(lane);
@@ -984,7 +995,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   const f32x4* pos = reinterpret_cast<const f32x4*>(
                          p.pos + (size_t)(g.prow0[side] + l0 + min(lrow, nvalid - 1)) * C) + lpart;
 
-  f32x16 xacc[2];  // residual stream of this wave's 32 channels, both row tiles (transposed C layout)
+  f32x16 xacc[NMT];  // residual stream of this wave's 32 channels, both row tiles (transposed C layout)
   PHASE_STAMP(p, 0);
 
   if (HAS_B) {
@@ -1038,11 +1049,11 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // [slot][head][row tile][4][64 lanes] 16-byte units = {step 0 hi, step 0 lo, step 1 hi, step 1 lo}
     // f16 planes - or four f32x4 k-groups in the bf16 build, whose apply runs on f32 MFMAs).  Eight
     // coalesced 1-KB loads per wave straight into registers: no LDS staging tile, no conversion here.
-    f32x4 qfrag[2][4];
+    f32x4 qfrag[NMT][4];
     {
-      const f32x4* qf = reinterpret_cast<const f32x4*>(p.qp + qrow_base * C) + (size_t)wave * 2 * 4 * 64;
+      const f32x4* qf = reinterpret_cast<const f32x4*>(p.qp + qrow_base * C) + (size_t)wave * NMT * 4 * 64;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int u = 0; u < 4; ++u) qfrag[mt][u] = qf[(mt * 4 + u) * 64 + (unsigned)lane];
     }
@@ -1050,7 +1061,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // merge GEMM's accumulators, issued LAST (the loads return in order - nothing waits on these
     // before the merge GEMM, the state reduction and the apply run under them)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
       const float* xr = p.x + (row_base + min(32 * mt + col, nvalid - 1)) * C + wcol + 4 * half;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -1081,7 +1092,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
         }
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         if (mt == 1 && !ws.two()) break;  // ragged tile: rows 32.. are never stored
         f32x16 macc = {0}, zacc = {0};
         if constexpr (gm_f16_range(MODE)) {
@@ -1126,9 +1137,9 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // M2), the 16 partials of a token (8 waves x 2 half-waves) combined after ONE exchange
     // through LDS (Chan's parallel update: as accurate as the two-pass form)
     {
-      float pm[2], pq[2];
+      float pm[NMT], pq[NMT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += xacc[mt][r];
@@ -1141,7 +1152,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       }
       __syncthreads();   // partials visible; every wave is done reading the message planes
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         if (mt == 1 && !ws.two()) break;
         const f32x4* pp = reinterpret_cast<const f32x4*>(lnx_s + (32 * mt + col) * LNX_LD);
         f32x4 t[8];
@@ -1179,7 +1190,9 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     {
       constexpr int SNEXT = TAIL == 0 ? SP::Q : SP::DEC_K;   // first GEMM of the tail
       constexpr bool XTR = true;                            // residual stream in the transposed layout
-      f32x16 haccA[2] = {f32x16{0}, f32x16{0}}, haccB[2] = {f32x16{0}, f32x16{0}};
+      f32x16 haccA[NMT], haccB[NMT];
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) { haccA[mt] = f32x16{0}; haccB[mt] = f32x16{0}; }
       // MLP1 runs TRANSPOSED (WStream2T: TR): a lane then holds, per register quad, FOUR
       // CONSECUTIVE hidden channels of one token - the GELU epilogue writes its planes with
       // 8-byte LDS stores (2 per quad) instead of 2-byte ones (8 per quad), one quad = two
@@ -1187,10 +1200,11 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       ws.template gemm<C, P_1A, true, C, SP::MLP1, SP::MLP1, true>(P1, p.b.w1, p.b.w1_l, wave, 0, lane, haccA,
                                                                    p.b.w1, p.b.w1_l, 8 + wave, 0);
       const bool two = ws.two();
-      auto gelu_to = [&](const PlanesT<MODE>& dst, const f32x16 (&h)[2]) {
+      auto gelu_to = [&](const PlanesT<MODE, RTW>& dst, const f32x16 (&h)[NMT]) {
         return [&, two](auto CI_) {
-          constexpr int CI = decltype(CI_)::value, mt = CI / 8, g4 = (CI % 8) / 2;
-          if constexpr (CI % 2 == 0) {
+          // 4 register quads per row tile over the 16 k16 steps: every 2nd step (two row tiles) / every 4th (one)
+          constexpr int CI = decltype(CI_)::value, mt = NMT == 2 ? CI / 8 : 0, g4 = NMT == 2 ? (CI % 8) / 2 : CI / 4;
+          if constexpr (CI % (NMT == 2 ? 2 : 4) == 0) {
             if (mt == 1 && !two) return;   // (hidden rows 32.. stay unwritten: never consumed)
             const f32x4 ge = gelu_erf4(f32x4{h[mt][4 * g4], h[mt][4 * g4 + 1], h[mt][4 * g4 + 2], h[mt][4 * g4 + 3]});
             dst.template put4<site_act_lo(SP::MLP2)>(32 * mt + col, wcol + 8 * g4 + 4 * half, ge);
@@ -1216,14 +1230,14 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // full 1-KB rows.  (The region's planes were last read by a GEMM every wave finished before
     // a barrier above: R2 by MLP2a; R1 holds the second hidden half, which MLP2b reads.)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
         *reinterpret_cast<f32x4*>(Xf + (32 * mt + col) * LDA + wcol + 8 * g4 + 4 * half) =
             f32x4{xacc[mt][4 * g4], xacc[mt][4 * g4 + 1], xacc[mt][4 * g4 + 2], xacc[mt][4 * g4 + 3]};
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RT / 8; ++i) {
+    for (int i = 0; i < RTW / 8; ++i) {
       const int r = wave + 8 * i;   // (scalar: a wave-uniform branch, an SGPR row address)
       if (r < nvalid)
         reinterpret_cast<f32x4*>(p.x + (row_base + r) * C)[(unsigned)lane] =
@@ -1233,11 +1247,11 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     if (TAIL == 2) { range_report<MODE>(rg, p.flags); return; }
   } else {
     if (nchw) {  // first launch, reference layout: transpose on the way in (R2 is free until phase A writes P2)
-      load_tile_nchw<THREADS, RT>(R1f, p.feat_nchw[side] + (size_t)n * C * L + l0, L, nvalid, tid);
-      load_tile_nchw<THREADS, RT>(R2f, p.pos_nchw[side] + l0, L, nvalid, tid);
+      load_tile_nchw<THREADS, RTW>(R1f, p.feat_nchw[side] + (size_t)n * C * L + l0, L, nvalid, tid);
+      load_tile_nchw<THREADS, RTW>(R2f, p.pos_nchw[side] + l0, L, nvalid, tid);
     } else {
 #pragma unroll
-      for (int i = 0; i < (RT * C / 4) / THREADS; ++i) {  // first launch: x from HBM
+      for (int i = 0; i < (RTW * C / 4) / THREADS; ++i) {  // first launch: x from HBM
         const int idx = tid + THREADS * i;
         const int r = idx >> 6, c4 = idx & 63;
         *reinterpret_cast<f32x4*>(R1f + r * LDA + 4 * c4) =
@@ -1248,8 +1262,8 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     if (TAIL == 1) ws.template prime<C, P_T0, SP::DEC_K>(p.d.wk[0], p.d.wk_l[0], wave, 0, lane);
     __syncthreads();
     if (nchw) {  // token-major copies for the later launches (residual reads, position rows)
-      store_tile_tokens<THREADS, RT>(p.x + row_base * C, R1f, nvalid, tid);
-      if (n == 0) store_tile_tokens<THREADS, RT>(p.pos_out + (size_t)(g.prow0[side] + l0) * C, R2f, nvalid, tid);
+      store_tile_tokens<THREADS, RTW>(p.x + row_base * C, R1f, nvalid, tid);
+      if (n == 0) store_tile_tokens<THREADS, RTW>(p.pos_out + (size_t)(g.prow0[side] + l0) * C, R2f, nvalid, tid);
     }
   }
 
@@ -1283,14 +1297,18 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // phi(Q) -> HBM, issued under the K GEMM's MFMAs (two accumulator values per k16 step).  The
     // phi(Q) buffer is TILE-major ([slot][64][256], rows past an image's end are padding), so
     // every store is unconditional: an SGPR row address, one per-lane offset, no select
-    f32x16 accQ[2] = {f32x16{0}, f32x16{0}};
+    f32x16 accQ[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) accQ[mt] = f32x16{0};
     // (issuing the x store under this GEMM, or phi(K) under the V GEMM below, was measured
     //  neutral to slightly slower - one-process A/B, 51.6 vs 51.9 us; only the GELU epilogues
     //  and the phi(Q) store pay for the interleave)
     ws.template gemm<C, P_T0, true, C, SP::Q, SP::K, true>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
                                                            p.a.wk_l, wave, 0);
     PHASE_STAMP(p, 10);
-    f32x16 accK[2] = {f32x16{0}, f32x16{0}}, accV[2] = {f32x16{0}, f32x16{0}};
+    f32x16 accK[NMT], accV[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) { accK[mt] = f32x16{0}; accV[mt] = f32x16{0}; }
     {
       // phi(Q) -> HBM under the K GEMM's MFMAs, one register pair per k16 step.  The Q GEMM ran
       // TRANSPOSED: lane (token 32 mt + col, half) holds channels 8 g + 4 half + i of its head in
@@ -1299,11 +1317,14 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       // 8 s2 .. 8 s2 + 7.  So the wave stores the consumer's register image, split into the f16
       // planes here (6 VALU per pair beside MFMAs instead of in the apply), 16 bytes per lane and
       // 1 KB per instruction: 8 stores per lane instead of 32.
-      f32x4* qf = reinterpret_cast<f32x4*>(p.qp + qrow_base * C) + (size_t)wave * 2 * 4 * 64;   // (scalar)
+      f32x4* qf = reinterpret_cast<f32x4*>(p.qp + qrow_base * C) + (size_t)wave * NMT * 4 * 64;   // (scalar)
       const bool two = ws.two();
       u32x4 qhi = {0, 0, 0, 0}, qlo = {0, 0, 0, 0};
       auto qepi = [&](auto CI_) {
-        constexpr int CI = decltype(CI_)::value, mt = CI / 8, pr = CI % 8, s2 = pr / 4, j = pr % 4;
+        // 8 register pairs per row tile over the 16 k16 steps: one per step (two row tiles) / every 2nd step (one)
+        constexpr int CI = decltype(CI_)::value, mt = NMT == 2 ? CI / 8 : 0, pr = NMT == 2 ? CI % 8 : CI / 2;
+        constexpr int s2 = pr / 4, j = pr % 4;
+        if constexpr (NMT == 1 && CI % 2 == 1) return;
         if (mt == 1 && !two) return;   // (rows 32.. of a one-row-tile workgroup are never read)
         const float a = elu1(accQ[mt][2 * pr]), b = elu1(accQ[mt][2 * pr + 1]);
         if constexpr (MODE == GM_BF16) {   // the bf16 build's apply takes f32 fragments: k-group = register quad
@@ -1330,7 +1351,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     PHASE_STAMP(p, 11);
     f32x16 kv;
     float ksum;
-    kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
+    kv_state_64<MODE, NMT>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
     // (the LayerNorm exchange buffer is dead after phase B)
@@ -1359,9 +1380,9 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     auto dec_layer = [&](auto DL) {
       constexpr int dl = decltype(DL)::value;
       constexpr int PK = dl == 0 ? P_T0 : P_T2, PV = dl == 0 ? P_T1 : P_T3;
-      f32x16 accK[2], accV[2];
+      f32x16 accK[NMT], accV[NMT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accK[mt][r] = bias_k[dl]; accV[mt][r] = bias_v[dl]; }
       ws.template gemm<C, PK, true, C, SP::DEC_K, SP::DEC_V>(P1, p.d.wk[dl], p.d.wk_l[dl], wave, 0, lane, accK,
@@ -1372,7 +1393,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
                                                    nullptr, 0, 0);
       f32x16 kv;
       float ksum;
-      kv_state_64<MODE>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
+      kv_state_64<MODE, NMT>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
       if constexpr (dl == 1) {
         kv_state_write(kv, ksum, lane, wave, p.dkv1_out, p.dks1_out, slot);
       } else {
@@ -1401,7 +1422,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
 
 template <bool HAS_B, int TAIL, int MODE, int POL = 0>
 __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
-  __shared__ __attribute__((aligned(16))) float smem[E2_SMEM];
+  __shared__ __attribute__((aligned(16))) float smem[E2<RT>::SMEM];
   if constexpr (gm_planes(MODE) == 2) {
     // split mode: the row-tile count is a compile-time property of the body (branch-free GEMM
     // steps, which is what lets hipcc interleave the epilogue slices with the MFMAs), chosen
@@ -1418,6 +1439,15 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
   } else {
     encoder64_body<HAS_B, TAIL, MODE, POL, 0>(p, smem);
   }
+}
+
+// 32 token rows per workgroup on the same body (round 4; two-plane mode): one MFMA row tile, 77.5 KB
+// of LDS.  Replaces k_encoder<..., 8> for the linear-attention split builds - that kernel stays for
+// the exact-fp32 mode (4 waves), the single-plane modes and attention = 'full'.
+template <bool HAS_B, int TAIL, int MODE, int POL = 0>
+__global__ __launch_bounds__(512) void k_encoder32m(EncLaunch p) {
+  __shared__ __attribute__((aligned(16))) float smem[E2<TM>::SMEM];
+  encoder64_body<HAS_B, TAIL, MODE, POL, 2, TM>(p, smem);
 }
 
 #ifndef OETR_SPLIT_WAVES
@@ -1460,6 +1490,27 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
         else return hipErrorInvalidValue;
       }
 #undef OETR_LAUNCH64
+      return hipGetLastError();
+    }
+  }
+  if constexpr (MODE == GM_SPLIT) {
+    if (p.enc32_modern && !p.attn_full) {
+      if (p.policy != 0 && p.policy != 1) return hipErrorInvalidValue;
+#define OETR_LAUNCH32M(B, T)                                                                    \
+  do {                                                                                          \
+    if (p.policy == 1) hipLaunchKernelGGL((k_encoder32m<B, T, MODE, 1>), grid, dim3(512), 0, s, p); \
+    else hipLaunchKernelGGL((k_encoder32m<B, T, MODE, 0>), grid, dim3(512), 0, s, p);            \
+  } while (0)
+      if (has_b) {
+        if (tail == 0) OETR_LAUNCH32M(true, 0);
+        else if (tail == 1) OETR_LAUNCH32M(true, 1);
+        else OETR_LAUNCH32M(true, 2);
+      } else {
+        if (tail == 0) OETR_LAUNCH32M(false, 0);
+        else if (tail == 1) OETR_LAUNCH32M(false, 1);
+        else return hipErrorInvalidValue;
+      }
+#undef OETR_LAUNCH32M
       return hipGetLastError();
     }
   }
