@@ -144,7 +144,6 @@ struct oetr_ctx {
   int policy = 0;       // precision policy (SitePolicy<>) of the oetr_dtype: 1 = OETR_DTYPE_F32_SPLIT_QK16
   int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
   int attn_full = 0;   // OETR_ATTENTION_FULL (oetr_set_attention)
-  int enc32_legacy = 0;  // measurement switch (environment OETR_ENC32_LEGACY=1 at create): 32-row tiles on round 3's k_encoder
   int num_cus = 256;
   float* dev = nullptr;  // all repacked weights
   size_t dev_floats = 0;
@@ -339,7 +338,6 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
     p.pos_out = w.pos;
   }
   p.tile_rows = encoder_tile_rows(h, g);
-  p.enc32_modern = (p.tile_rows == TM && h->mode == GM_SPLIT && !h->attn_full && !h->enc32_legacy) ? 1 : 0;
   p.g = encoder_geom(g, p.tile_rows);
 #ifdef OETR_ABLATE
   { const char* e = getenv("OETR_ABLATE"); p.dbg = e ? atoi(e) : 0; }
@@ -537,7 +535,6 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   h->device = device;
   h->mode = split;
   h->policy = dtype == OETR_DTYPE_F32_SPLIT_QK16 ? 1 : 0;
-  { const char* e = getenv("OETR_ENC32_LEGACY"); h->enc32_legacy = (e && atoi(e) != 0) ? 1 : 0; }   // (A/B measurements only)
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   Packer pk;
   struct EncOff { size_t wq, wk, wv, wm, w1, w2, wq_l, wk_l, wv_l, wm_l, w1_l, w2_l, v[6]; } eo[OETR_N_ENC];

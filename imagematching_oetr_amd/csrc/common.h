@@ -1145,8 +1145,6 @@ struct EncLaunch {
   size_t vt_off[2];      // first float of the side's images in vt
   int tile_rows;         // token rows per workgroup: 32 (TM) or 64 (split mode, k_encoder64);
                          // g.nt / g.tile0 / g.ntiles are in units of this tile
-  int enc32_modern;      // tile_rows == 32, two-plane mode, linear attention: k_encoder32m (the 64-row
-                         // kernel's body on one row tile; phi(Q) buffer fragment-major) instead of k_encoder
   int b_cross;           // phase-B layer is a cross layer
   int kv_reduced;        // kv_in / ks_in hold ONE reduced state per image ([2N][8192] / [2N][256], side 0
                          // first) instead of per-tile partials: k_kv_reduce ran between the launches,

@@ -1190,9 +1190,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     {
       constexpr int SNEXT = TAIL == 0 ? SP::Q : SP::DEC_K;   // first GEMM of the tail
       constexpr bool XTR = true;                            // residual stream in the transposed layout
-      f32x16 haccA[NMT], haccB[NMT];
-#pragma unroll
-      for (int mt = 0; mt < NMT; ++mt) { haccA[mt] = f32x16{0}; haccB[mt] = f32x16{0}; }
+      f32x16 haccA[NMT] = {}, haccB[NMT] = {};
       // MLP1 runs TRANSPOSED (WStream2T: TR): a lane then holds, per register quad, FOUR
       // CONSECUTIVE hidden channels of one token - the GELU epilogue writes its planes with
       // 8-byte LDS stores (2 per quad) instead of 2-byte ones (8 per quad), one quad = two
@@ -1297,18 +1295,14 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     // phi(Q) -> HBM, issued under the K GEMM's MFMAs (two accumulator values per k16 step).  The
     // phi(Q) buffer is TILE-major ([slot][64][256], rows past an image's end are padding), so
     // every store is unconditional: an SGPR row address, one per-lane offset, no select
-    f32x16 accQ[NMT];
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) accQ[mt] = f32x16{0};
+    f32x16 accQ[NMT] = {};   // (value-initialised: a zeroing loop here cost the first launch's kernel 33 VGPRs and 28 spills)
     // (issuing the x store under this GEMM, or phi(K) under the V GEMM below, was measured
     //  neutral to slightly slower - one-process A/B, 51.6 vs 51.9 us; only the GELU epilogues
     //  and the phi(Q) store pay for the interleave)
     ws.template gemm<C, P_T0, true, C, SP::Q, SP::K, true>(P1, p.a.wq, p.a.wq_l, wave, 0, lane, accQ, p.a.wk,
                                                            p.a.wk_l, wave, 0);
     PHASE_STAMP(p, 10);
-    f32x16 accK[NMT], accV[NMT];
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) { accK[mt] = f32x16{0}; accV[mt] = f32x16{0}; }
+    f32x16 accK[NMT] = {}, accV[NMT] = {};
     {
       // phi(Q) -> HBM under the K GEMM's MFMAs, one register pair per k16 step.  The Q GEMM ran
       // TRANSPOSED: lane (token 32 mt + col, half) holds channels 8 g + 4 half + i of its head in
@@ -1494,7 +1488,7 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
     }
   }
   if constexpr (MODE == GM_SPLIT) {
-    if (p.enc32_modern && !p.attn_full) {
+    if (!p.attn_full) {   // 32 token rows, two-plane mode, linear attention: the 64-row kernel's body on one row tile
       if (p.policy != 0 && p.policy != 1) return hipErrorInvalidValue;
 #define OETR_LAUNCH32M(B, T)                                                                    \
   do {                                                                                          \
@@ -1514,26 +1508,9 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
       return hipGetLastError();
     }
   }
+  // round 1-3's 32-row kernel: exact fp32 (4 waves), the single-plane modes, attention = 'full'
   constexpr int NW = gm_half(MODE) ? OETR_SPLIT_WAVES : OETR_F32_WAVES;
-  if (p.policy != 0) {
-    if constexpr (MODE == GM_SPLIT && NW == 8) {
-      if (p.policy != 1 || p.attn_full) return hipErrorInvalidValue;
-#define OETR_LAUNCHP(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, NW, false, 1>), grid, dim3(64 * NW), 0, s, p)
-      if (has_b) {
-        if (tail == 0) OETR_LAUNCHP(true, 0);
-        else if (tail == 1) OETR_LAUNCHP(true, 1);
-        else OETR_LAUNCHP(true, 2);
-      } else {
-        if (tail == 0) OETR_LAUNCHP(false, 0);
-        else if (tail == 1) OETR_LAUNCHP(false, 1);
-        else OETR_LAUNCHP(false, 2);
-      }
-#undef OETR_LAUNCHP
-      return hipGetLastError();
-    } else {
-      return hipErrorInvalidValue;
-    }
-  }
+  if (p.policy != 0) return hipErrorInvalidValue;   // (policies exist in the two-plane mode only: handled above)
   if (p.attn_full) {
     // (the exact-fp32 build runs 8 waves here too: one head per wave in the attention core)
     if constexpr ((gm_f16_range(MODE) && NW == 8) || MODE == GM_F32) {
@@ -1552,18 +1529,21 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
       return hipErrorInvalidValue;
     }
   }
+  if constexpr (MODE != GM_SPLIT) {
 #define OETR_LAUNCH(B, T) hipLaunchKernelGGL((k_encoder<B, T, MODE, NW>), grid, dim3(64 * NW), 0, s, p)
-  if (has_b) {
-    if (tail == 0) OETR_LAUNCH(true, 0);
-    else if (tail == 1) OETR_LAUNCH(true, 1);
-    else OETR_LAUNCH(true, 2);
-  } else {
-    if (tail == 0) OETR_LAUNCH(false, 0);
-    else if (tail == 1) OETR_LAUNCH(false, 1);
-    else OETR_LAUNCH(false, 2);
-  }
+    if (has_b) {
+      if (tail == 0) OETR_LAUNCH(true, 0);
+      else if (tail == 1) OETR_LAUNCH(true, 1);
+      else OETR_LAUNCH(true, 2);
+    } else {
+      if (tail == 0) OETR_LAUNCH(false, 0);
+      else if (tail == 1) OETR_LAUNCH(false, 1);
+      else OETR_LAUNCH(false, 2);
+    }
 #undef OETR_LAUNCH
-  return hipGetLastError();
+    return hipGetLastError();
+  }
+  return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): bench lines + rocprofv3 kernel stats + PMC passes.
 # usage: tools/profile_round.sh <tag>     outputs under gpurun_out/<tag>/ ; copy the
 # summaries you want judged into profiles/<tag>_*.
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -20,6 +20,10 @@ timeout 300 python bench.py --steps 20 --warmup 5 --precision f16 --size2 1280 -
 OETR_BENCH_FORCE_PG=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-e2e --no-cpu-baseline --no-exact-f32 2>> $OUT/bench.err | grep '^{' > $OUT/bench_rccl_world1.json
 timeout 300 python bench.py --steps 20 --warmup 5 --attention full --no-e2e --no-cpu-baseline > $OUT/bench_attention_full.json 2>> $OUT/bench.err
 OETR_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 --no-e2e --no-exact-f32 2>> $OUT/bench.err | grep '^{' > $OUT/bench_gloo2.json
+# configs[4] as a mixed-scale job: bucket by (L1, L2), shard every bucket, per-rank step-time spread (2 ranks on this 1-GPU box, gloo)
+OETR_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --workload mixed --steps 10 --warmup 3 --precision f32_split_qk16 2>> $OUT/bench.err | grep '^{' > $OUT/bench_gloo2_mixed.json
+OETR_BENCH_FORCE_PG=1 timeout 300 python bench.py --workload mixed --steps 10 --warmup 3 --precision f32_split_qk16 2>> $OUT/bench.err | grep '^{' > $OUT/bench_rccl_world1_mixed.json
+timeout 600 python tools/trunk_autocast.py > $OUT/trunk_autocast.txt 2>> $OUT/bench.err
 for L in 1024 4096; do
   timeout 200 python bench.py --kernel full_attention --L $L --steps 20 --warmup 3 --repeats 5 > $OUT/full_attention_L$L.json 2>> $OUT/bench.err
 done
