@@ -16,6 +16,9 @@ using namespace oetr;
 // oetr_set_state_prereduce(h, -1): source tokens per image from which the partial linear-attention
 // states are summed by a launch of their own (see forward_impl)
 constexpr int OETR_PREREDUCE_MIN_TOKENS = 768;
+// oetr_set_tail_mode(h, 0): token rows (N (L1 + L2)) from which the forward path runs the decoder first and the
+// heat-map conv in its direct 64-row form (k_heat_conv64) instead of decoder || P = W_tap.memory + combine
+constexpr int OETR_DIRECT_TAIL_MIN_ROWS = 16000;   // measured crossover: 12 800 rows P form better by 15 us, 16 000 rows direct by 36 (profiles/r4_tail_forms.txt)
 
 namespace {
 
@@ -141,6 +144,7 @@ struct oetr_ctx {
   int device = 0;
   int mode = GM_SPLIT;  // GEMM mode GM_* (common.h) of the oetr_dtype
   int kv_prereduce = -1; // oetr_set_state_prereduce (-1 = auto)
+  int tail_mode = 0;     // oetr_set_tail_mode: 0 auto, 1 P form (decoder || conv-P, combine), 2 direct (decoder, conv)
   int policy = 0;       // precision policy (SitePolicy<>) of the oetr_dtype: 1 = OETR_DTYPE_F32_SPLIT_QK16
   int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
   int attn_full = 0;   // OETR_ATTENTION_FULL (oetr_set_attention)
@@ -737,9 +741,19 @@ oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
   hp.tlbr[0] = tl1; hp.tlbr[1] = tl2;
   hp.box[0] = box1; hp.box[1] = box2;
   hp.img_w[0] = img_w1; hp.img_w[1] = img_w2;
-  // decoder || P_tap = W_tap.memory in one launch, then the att-weighted combine
-  TRACED(h, s, K_DEC_CONVP, launch_decoder_convp(dec_launch(h, g, w), hp, w.convp, h->mode, s));
-  TRACED(h, s, K_HEAT_COMBINE, launch_heat_combine(hp, w.convp, s));
+  // Small batches: decoder || P_tap = W_tap.memory in one launch (the decoder chain, 50 us on 2N CUs, hides
+  // behind the conv GEMMs), then the att-weighted combine.  Large batches (two-plane mode): the P buffer's
+  // traffic (9 x rows x 1 KB written and read) costs more than the chain - decoder first, then the conv in
+  // its direct 64-row form (heads.hip: k_heat_conv64), no P.
+  const bool direct = h->mode == GM_SPLIT &&
+                      (h->tail_mode == 2 || (h->tail_mode == 0 && g.rows >= OETR_DIRECT_TAIL_MIN_ROWS));
+  if (direct) {
+    TRACED(h, s, K_DECODER, launch_decoder(dec_launch(h, g, w), s));
+    TRACED(h, s, K_HEAT_CONV, launch_heat_conv64(hp, h->mode, s));
+  } else {
+    TRACED(h, s, K_DEC_CONVP, launch_decoder_convp(dec_launch(h, g, w), hp, w.convp, h->mode, s));
+    TRACED(h, s, K_HEAT_COMBINE, launch_heat_combine(hp, w.convp, s));
+  }
   TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));  // + size regression + boxes
   if (st) {
     if ((rc = copy_out(st->hs1, hs1, (size_t)g.N * C, s))) return rc;
@@ -1270,6 +1284,15 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows) {
   if (rows != 0 && rows != TM && rows != 64)
     return fail(OETR_ERR_BAD_ARG, "oetr_set_encoder_tile: rows must be 0 (auto), 32 or 64");
   h->enc_tile = rows;
+  return OETR_OK;
+}
+
+oetr_status oetr_set_tail_mode(oetr_handle h, int mode) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_tail_mode: NULL handle");
+  if (mode < 0 || mode > 2) return fail(OETR_ERR_BAD_ARG, "oetr_set_tail_mode: 0 (auto), 1 (P form) or 2 (direct form)");
+  if (mode == 2 && h->mode != GM_SPLIT)
+    return fail(OETR_ERR_UNSUPPORTED, "the direct 64-row heat-map conv is built for the two-plane dtypes (F32_SPLIT_F16, F32_SPLIT_QK16)");
+  h->tail_mode = mode;
   return OETR_OK;
 }
 

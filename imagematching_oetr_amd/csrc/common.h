@@ -1233,6 +1233,8 @@ struct HeatLaunch {
   uint32_t* flags;         // the handle's status word (FLAG_F16_RANGE)
 };
 hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s);
+// 64 token rows per workgroup, two-plane mode only: the direct conv of the forward path for large batches
+hipError_t launch_heat_conv64(const HeatLaunch& p, int mode, hipStream_t s);
 // Forward path: decoder (2N workgroups) and the hs-independent part of the heat-map
 // conv, P_tap = W_tap . memory (one workgroup per token tile), in ONE launch so that
 // the 16-CU decoder runs beside the conv GEMMs; then the cheap combine

@@ -184,6 +184,203 @@ hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
+// The same conv for 64 token rows per workgroup (two-plane mode; round 4): the DIRECT form of the
+// forward path for large batches.  The P form (k_decoder_convp + k_heat_combine) hides the decoder
+// chain behind the hs-independent products W_tap.memory, at the price of a 9 x rows x 1 KB buffer
+// written and read once: 1.2 GB per step at 32 pairs @1024x1024, where k_heat_combine alone (HBM-bound)
+// costs 160 us and the tap stores make k_decoder_convp 285.  Here the decoder runs first (its 50 us on
+// 2N CUs are a few percent of such a step), att = memory.hs is known, and the nine taps accumulate in
+// registers: per tap the gathered, att-scaled A tile of the NEXT tap is staged (loads issued before
+// the GEMM, conversions and plane stores as the GEMM's epilogue slices beside its MFMAs) into the
+// other of two plane regions while this tap's GEMM runs; every weight fragment feeds two MFMA row
+// tiles (WStream2T), the weight stream runs from tap to tap.  One conv_out tile and the GroupNorm
+// moments of its two 32-row slots leave the workgroup - no P.
+// ROWS (WStream2T): 2 = both 32-row MFMA tiles hold valid rows, 1 = only the first does - fixed at compile
+// time so that the GEMM steps are branch-free and the staging slices interleave with their MFMAs (the
+// run-time form, a wave-uniform branch around every second-tile MFMA, measured 250 us instead of 238 at
+// 32 pairs @1024x1024); the kernel picks the body per workgroup.
+template <int MODE, int ROWS>
+__device__ __forceinline__ void heat_conv64_body(const HeatLaunch& p, float* smem, float* att_s, float* attmax_s) {
+  static_assert(gm_planes(MODE) == 2, "two-plane mode");
+  static_assert(16 % WStream2T<MODE, ROWS>::D == 0, "tap loop below assumes a ring phase of 0 after every GEMM");
+  constexpr int THREADS = 512, TPR = THREADS / RT, F4 = 64 / TPR;   // 8 threads per row, 8 float4 each
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
+  const int logical = xcd_remap(blockIdx.x, g.N * (nt0 + nt1));
+  const int per = nt0 + nt1;
+  const int n = logical / per;
+  const int rem = logical - n * per;
+  const int side = rem >= nt0;
+  const int t_idx = side ? rem - nt0 : rem;
+  const int L = g.L[side], hf = g.hf[side], wf = g.wf[side];
+  const int l0 = t_idx * RT;
+  const int nvalid = min(RT, L - l0);
+  const float* mem = p.mem[side] + (size_t)n * L * C;
+  const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
+  Range rg;
+  // att[l'] = memory[l'] . hs for the halo rows l0-wf-1 .. l0+RT+wf of this tile, once
+  const int halo0 = l0 - wf - 1, nhalo = RT + 2 * (wf + 1);
+  const int hrow = tid / TPR, hpart = tid % TPR;
+  {
+    const f32x4* hsp = reinterpret_cast<const f32x4*>(p.hs[side] + (size_t)n * C) + hpart;
+    f32x4 hv[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) hv[i] = hsp[i * TPR];
+    for (int r0 = 0; r0 < nhalo; r0 += RT) {
+      const int hr = r0 + hrow;
+      const int l = min(max(halo0 + hr, 0), L - 1);  // clamped: out-of-image rows are masked below
+      const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)l * C) + hpart;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < F4; ++i) {
+        const f32x4 v = mp[i * TPR];
+        d += (v[0] * hv[i][0] + v[1] * hv[i][1]) + (v[2] * hv[i][2] + v[3] * hv[i][3]);
+      }
+      d = sum8(d);
+      if (hpart == 0 && hr < nhalo) att_s[hr] = d;
+    }
+  }
+  __syncthreads();
+  // att weights of the tile divided by a power of two >= max |att| over its halo (exact), the GEMM
+  // result multiplied back: the converted operands are bounded by |memory| (see k_heat_conv)
+  {
+    float m = 0.f;
+    for (int i = tid; i < nhalo; i += THREADS) m = fmaxf(m, fabsf(att_s[i]));
+    m = wave_max(m);
+    if (lane == 0) attmax_s[wave] = m;
+  }
+  __syncthreads();
+  float att_scale = 1.0f, att_unscale = 1.0f;
+  {
+    float m = attmax_s[0];
+#pragma unroll
+    for (int i = 1; i < THREADS / 64; ++i) m = fmaxf(m, attmax_s[i]);
+    if (m > 0.f && m < INFINITY) {
+      const int e = ilogbf(m) + 1;          // 2^e > m
+      att_scale = ldexpf(1.0f, -e);
+      att_unscale = ldexpf(1.0f, e);
+    }
+  }
+  // two plane regions, tap t in region t & 1 (addresses computed, not looked up: a run-time index into an
+  // array of plane descriptors would put the array in scratch)
+  auto region = [&](int t) { return PlanesT<MODE>(smem + (t & 1) * R_FLOATS, &rg); };
+  // this thread's row of the tile: source row and att weight of tap `tap`, the row's 8 float4 pieces
+  const int lrow = l0 + hrow;
+  const int y = lrow / wf, x = lrow - y * wf;
+  auto tap_loads = [&](int tap, f32x4 (&v)[F4], float& att) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int yy = y + dy, xx = x + dx;
+    const bool ok = (lrow < L) && (yy >= 0) && (yy < hf) && (xx >= 0) && (xx < wf);
+    const int src_row = ok ? yy * wf + xx : 0;   // unconditional loads from a clamped row + select
+    att = ok ? att_s[src_row - halo0] * att_scale : 0.f;
+    const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)src_row * C) + hpart;
+#pragma unroll
+    for (int i = 0; i < F4; ++i) v[i] = mp[i * TPR];
+  };
+  WStream2T<MODE, ROWS> ws;
+  ws.set_rows(nvalid);
+  ws.set_lane(lane);
+  constexpr size_t TAP_UNITS = (size_t)C * C / 8;
+  {
+    f32x4 v[F4];
+    float att;
+    tap_loads(0, v, att);
+    ws.template prime<C, 0>(p.w.conv_w, p.w.conv_w_l, wave, 0, lane);
+    const PlanesT<MODE> first = region(0);
+#pragma unroll
+    for (int i = 0; i < F4; ++i) first.put4(hrow, 4 * (i * TPR + hpart), v[i] * att);
+  }
+  __syncthreads();
+  f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+#pragma unroll 1
+  for (int tap = 0; tap < 8; ++tap) {
+    f32x4 v[F4];
+    float att;
+    tap_loads(tap + 1, v, att);                  // next tap's rows: in flight under this tap's GEMM
+    const PlanesT<MODE> cur = region(tap), nxt = region(tap + 1);
+    auto epi = [&](auto CI_) {                   // ... converted and stored beside its MFMAs, one piece per 2 k16 steps
+      constexpr int CI = decltype(CI_)::value;
+      if constexpr (CI % 2 == 1) nxt.put4(hrow, 4 * ((CI / 2) * TPR + hpart), v[CI / 2] * att);
+    };
+    const f32x4* w = p.w.conv_w + tap * TAP_UNITS;
+    const f32x4* wl = p.w.conv_w_l + tap * TAP_UNITS;
+    ws.template gemm_epi<C, 0, true, C>(cur, w, wl, wave, 0, lane, acc, w + TAP_UNITS, wl + TAP_UNITS,
+                                        wave, 0, epi);
+    __syncthreads();   // next tap's planes complete; every wave is done reading this tap's
+  }
+  ws.template gemm<C, 0, false, C>(region(8), p.w.conv_w + 8 * TAP_UNITS, p.w.conv_w_l + 8 * TAP_UNITS, wave, 0, lane,
+                                   acc, nullptr, nullptr, 0, 0);
+  const float bias = p.w.conv_b[32 * wave + col];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(acc[mt][r], att_unscale, bias);
+  range_report<MODE>(rg, p.flags);
+
+  // conv output + per-(32-row slot, group) moments for GroupNorm (the slots k_heat_final folds)
+  const int c = 32 * wave + col;
+  const int slot0 = g.tile0[side] + n * g.nt[side] + 2 * t_idx;   // g = the heads' TM-row geometry
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int nv = min(TM, nvalid - 32 * mt);      // valid rows of this 32-row slot (<= 0: none)
+    if (nv <= 0) break;                            // (workgroup-uniform)
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      if (row < nv) {
+        p.conv_out[(row_base + 32 * mt + row) * C + c] = acc[mt][r];
+        sum += acc[mt][r];
+      }
+    }
+    // 8 channels of a group = lanes with equal (lane&31)>>3, both halves
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum / (float)(nv * 8);
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (crow(r, half) < nv) { const float d = acc[mt][r] - mean; m2 += d * d; }
+    m2 += __shfl_xor(m2, 1, 64);
+    m2 += __shfl_xor(m2, 2, 64);
+    m2 += __shfl_xor(m2, 4, 64);
+    m2 += __shfl_xor(m2, 32, 64);
+    if ((lane & 39) == 0) {  // lane&7 == 0 and half == 0
+      float* dst = p.gn_part + ((size_t)(slot0 + mt) * GN_GROUPS + (c >> 3)) * 2;
+      dst[0] = mean;
+      dst[1] = m2;
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_heat_conv64(HeatLaunch p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * R_FLOATS];
+  __shared__ float att_s[RT + 2 * (100 + 1) + 6];
+  __shared__ float attmax_s[512 / 64];
+  const Geom& g = p.g;
+  const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
+  const int logical = xcd_remap(blockIdx.x, g.N * (nt0 + nt1));
+  const int rem = logical - (logical / (nt0 + nt1)) * (nt0 + nt1);
+  const int side = rem >= nt0;
+  const int t_idx = side ? rem - nt0 : rem;
+  const int nvalid = min(RT, g.L[side] - t_idx * RT);
+  if (__builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0)) heat_conv64_body<MODE, 2>(p, smem, att_s, attmax_s);
+  else heat_conv64_body<MODE, 1>(p, smem, att_s, attmax_s);
+}
+
+hipError_t launch_heat_conv64(const HeatLaunch& p, int mode, hipStream_t s) {
+  if (mode != GM_SPLIT) return hipErrorInvalidValue;
+  const int tiles = p.g.N * ((p.g.L[0] + RT - 1) / RT + (p.g.L[1] + RT - 1) / RT);
+  hipLaunchKernelGGL((k_heat_conv64<GM_SPLIT>), dim3(tiles), dim3(512), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // conv_out[l] = b + sum_tap att[l+tap] * P_tap[l+tap]  (P from k_decoder_convp),
 // plus the per-tile GroupNorm moments.  512 threads, 16 per token row.
 __global__ __launch_bounds__(512) void k_heat_combine(HeatLaunch p, const float* __restrict__ P) {

@@ -83,7 +83,7 @@ EXPORTS = (
     'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel',
     'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens',
     'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async',
-    'oetr_set_state_prereduce', 'oetr_overlap_frame', 'oetr_read_overlap_image')
+    'oetr_set_state_prereduce', 'oetr_set_tail_mode', 'oetr_overlap_frame', 'oetr_read_overlap_image')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 
@@ -193,6 +193,8 @@ def load_library(path=None):
     lib.oetr_set_attention.argtypes = [vp, i]
     lib.oetr_set_state_prereduce.restype = i
     lib.oetr_set_state_prereduce.argtypes = [vp, i]
+    lib.oetr_set_tail_mode.restype = i
+    lib.oetr_set_tail_mode.argtypes = [vp, i]
     lib.oetr_neck_create.restype = i
     lib.oetr_neck_create.argtypes = [C.POINTER(_NeckWeights), i, C.POINTER(vp)]
     lib.oetr_neck_destroy.restype = None
@@ -492,6 +494,13 @@ class HotPathEngine:
         the producing launch by the last workgroup of the image to finish (bit-identical
         results in every setting)."""
         _check(self.lib, self.lib.oetr_set_state_prereduce(self._h, int(mode)), 'oetr_set_state_prereduce')
+
+    def set_tail_mode(self, mode):
+        """``oetr_set_tail_mode``: order of the forward path's tail - 0 automatic (the default), 1
+        'P form' (decoder beside the hs-independent conv products, then the combine: small batches),
+        2 'direct form' (decoder, then the 64-row conv with the taps accumulated in registers, no P
+        buffer: large batches; two-plane precisions only)."""
+        _check(self.lib, self.lib.oetr_set_tail_mode(self._h, int(mode)), 'oetr_set_tail_mode')
 
     def query_flags(self, clear=True):
         """Status word of the CURRENT STREAM's workspace (``oetr_query_flags``): synchronises

@@ -213,6 +213,18 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows);
  * summation order).  Mutates the handle like the other setters. */
 oetr_status oetr_set_state_prereduce(oetr_handle h, int on);
 
+/* How the forward path orders its tail (center_estimation, reference src/model.py:145-186; decoder
+ * transformer.py:361-381).  1: "P form" - the decoder and the hs-independent products
+ * P_tap = W_tap . memory of the 3x3 conv in ONE launch, then the att-weighted combine: the decoder's
+ * GEMV chain hides behind the conv GEMMs (best for small batches).  2: "direct form" - decoder first,
+ * then the conv of memory * att with the nine taps accumulated in registers, 64 token rows per
+ * workgroup, no P buffer (best once the 9 x rows x 1 KB of P traffic outweigh the decoder chain;
+ * two-plane dtypes only).  0 (default): automatic - direct from 16 000 token rows (N (L1 + L2)) in
+ * the two-plane dtypes, P form otherwise.  Same arithmetic per product; results agree to fp32
+ * summation order (the nine taps are summed in the MFMA accumulator instead of in k_heat_combine).
+ * Mutates the handle like the other setters. */
+oetr_status oetr_set_tail_mode(oetr_handle h, int mode);
+
 /* Attention core of the eight encoder layers.  The reference builds
  * QueryTransformer(attention_mode='linear') (src/model.py:82-84; the config knob
  * OETR.NECK.ATTENTION is never read), LINEAR is therefore the default; FULL is

@@ -432,3 +432,60 @@ def test_state_prereduce_auto_switches_on_by_size_and_changes_no_bit(gpu):
         b = eng.forward(f1, f2, p1, p2, (h1 * 32, w1 * 32), (h2 * 32, w2 * 32), stages=True)
         for k in ('memory1', 'memory2', 'hs1', 'hs2', 'box1', 'box2'):
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('precision', ['f32_split_f16', 'f32_split_qk16'])
+@pytest.mark.parametrize('path', HOT, ids=lambda p: p.split('hot_')[-1][:-4])
+def test_tail_forms_agree_and_match_the_goldens(path, precision, gpu):
+    """``oetr_set_tail_mode``: the P form (decoder beside W_tap.memory, then the combine) and the direct
+    form (decoder, then the 64-row conv with the nine taps accumulated in registers; what large batches
+    run) produce the reference's heat-map logits, centres and boxes within the same tolerances - on every
+    golden, ragged grids included - and agree with each other to fp32 summation order."""
+    from imagematching_oetr_amd import HotPathEngine
+    from tests.test_oracle_golden import load_hot_case
+    g, w, f1, f2 = load_hot_case(path)
+    im1, im2 = tuple(int(v) for v in g['img1']), tuple(int(v) for v in g['img2'])
+    dev = [t.to(gpu) for t in (f1, f2, orc.position_table(*g['grid1']), orc.position_table(*g['grid2']))]
+    eng = HotPathEngine(orc.make_hot_weights(int(g['weight_seed']), sharpen=bool(g['sharpen'])), device=gpu,
+                        precision=precision)
+    outs = {}
+    for mode in (1, 2):
+        eng.set_tail_mode(mode)
+        outs[mode] = eng.forward(*dev, im1, im2, stages=True)
+        tol_scale = 1.0 if precision == 'f32_split_f16' else 30.0   # (policy: bounded drift, test_gpu_precision has the bar)
+        for s in ('1', '2'):
+            assert maxerr(outs[mode]['logits' + s], g['logits' + s]) <= TOL['logits'] * tol_scale, (mode, s)
+            assert maxerr(outs[mode]['cxy' + s], g['cxy' + s]) <= TOL['cxy'] * tol_scale, (mode, s)
+            assert maxerr(outs[mode]['box' + s], g['box' + s]) <= TOL['box'] * tol_scale, (mode, s)
+    for s in ('1', '2'):
+        assert torch.equal(outs[1]['hs' + s], outs[2]['hs' + s])            # same decoder
+        # (the nine taps are summed in another order: a tenth of the golden tolerances, scaled by the logits' size)
+        scale = 1.0 + float(outs[1]['logits' + s].abs().max())
+        assert maxerr(outs[1]['logits' + s], outs[2]['logits' + s]) <= 1e-5 * scale
+        assert maxerr(outs[1]['box' + s], outs[2]['box' + s]) <= 0.2 * TOL['box']
+    with pytest.raises(Exception):
+        eng.set_tail_mode(3)
+    if True:
+        e32 = HotPathEngine(orc.make_hot_weights(int(g['weight_seed']), sharpen=bool(g['sharpen'])), device=gpu, precision='f32')
+        with pytest.raises(Exception):
+            e32.set_tail_mode(2)            # the direct 64-row conv exists in the two-plane builds only
+
+
+def test_direct_tail_edge_grids(gpu):
+    """The direct form on grids that stress its halo and its tiling: a single token, one row, one column,
+    an exact multiple of 64 rows, a ragged 64-row tile with an empty second half, the 100 x 100 maximum."""
+    from imagematching_oetr_amd import HotPathEngine
+    w = orc.make_hot_weights(3, sharpen=True)
+    eng = HotPathEngine(w, device=gpu)
+    eng.set_tail_mode(2)
+    for (h1, w1, h2, w2) in ((1, 1, 1, 1), (1, 7, 33, 1), (8, 8, 16, 8), (5, 6, 3, 11), (100, 100, 2, 2)):
+        n = 1 if h1 * w1 > 5000 else 2
+        f1, f2 = orc.make_features(81, n, h1, w1), orc.make_features(82, n, h2, w2)
+        p1, p2 = orc.position_table(h1, w1), orc.position_table(h2, w2)
+        im1, im2 = (h1 * 32, w1 * 32), (h2 * 32, w2 * 32)
+        out = eng.forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p2.to(gpu), im1, im2, stages=True)
+        ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
+        for s in ('1', '2'):
+            assert maxerr(out['logits' + s], ref['logits' + s]) <= TOL['logits'], (h1, w1, h2, w2, s)
+            assert maxerr(out['cxy' + s], ref['cxy' + s]) <= TOL['cxy'], (h1, w1, h2, w2, s)
+            assert maxerr(out['box' + s], ref['box' + s]) <= TOL['box'], (h1, w1, h2, w2, s)
