@@ -291,6 +291,7 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.box[0] = p.box[1] = nullptr;
   p.img_w[0] = p.img_w[1] = 0;
   p.flags = w.flags;
+  p.force_staged_conv = h->tail_mode == 3;
   return p;
 }
 
@@ -746,7 +747,7 @@ oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
   // traffic (9 x rows x 1 KB written and read) costs more than the chain - decoder first, then the conv in
   // its direct 64-row form (heads.hip: k_heat_conv64), no P.
   const bool direct = h->mode == GM_SPLIT &&
-                      (h->tail_mode == 2 || (h->tail_mode == 0 && g.rows >= OETR_DIRECT_TAIL_MIN_ROWS));
+                      (h->tail_mode >= 2 || (h->tail_mode == 0 && g.rows >= OETR_DIRECT_TAIL_MIN_ROWS));
   if (direct) {
     TRACED(h, s, K_DECODER, launch_decoder(dec_launch(h, g, w), s));
     TRACED(h, s, K_HEAT_CONV, launch_heat_conv64(hp, h->mode, s));
@@ -1289,8 +1290,9 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows) {
 
 oetr_status oetr_set_tail_mode(oetr_handle h, int mode) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_tail_mode: NULL handle");
-  if (mode < 0 || mode > 2) return fail(OETR_ERR_BAD_ARG, "oetr_set_tail_mode: 0 (auto), 1 (P form) or 2 (direct form)");
-  if (mode == 2 && h->mode != GM_SPLIT)
+  if (mode < 0 || mode > 3)
+    return fail(OETR_ERR_BAD_ARG, "oetr_set_tail_mode: 0 (auto), 1 (P form), 2 (direct form) or 3 (direct form, per-tap staging)");
+  if (mode >= 2 && h->mode != GM_SPLIT)
     return fail(OETR_ERR_UNSUPPORTED, "the direct 64-row heat-map conv is built for the two-plane dtypes (F32_SPLIT_F16, F32_SPLIT_QK16)");
   h->tail_mode = mode;
   return OETR_OK;

@@ -911,6 +911,8 @@ struct PlanesT {  // 16-bit planes [ROWS_P][LDAH] (hi, and lo*2^11 in GM_SPLIT) 
   Range* rg;
   __device__ __forceinline__ PlanesT(float* base, Range* rg_)
       : h(reinterpret_cast<_Float16*>(base)), l(reinterpret_cast<_Float16*>(base) + ROWS_P * LDAH), rg(rg_) {}
+  // a window of a larger plane pair (row stride LDAH): first row of the hi plane, first row of the lo plane
+  __device__ __forceinline__ PlanesT(_Float16* hi_row0, _Float16* lo_row0, Range* rg_) : h(hi_row0), l(lo_row0), rg(rg_) {}
   // LO = false: the consumer site reads the hi plane only (common.h: SITE_*), the lo plane is
   // not written
   template <bool LO = true>
@@ -1231,6 +1233,7 @@ struct HeatLaunch {
   float* box[2];           // [N][4] per side, or NULL
   int img_w[2];
   uint32_t* flags;         // the handle's status word (FLAG_F16_RANGE)
+  int force_staged_conv;   // direct form: k_heat_conv64 (per-tap staging) even where the halo-resident form fits
 };
 hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s);
 // 64 token rows per workgroup, two-plane mode only: the direct conv of the forward path for large batches

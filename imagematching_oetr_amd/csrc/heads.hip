@@ -195,6 +195,47 @@ hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s) {
 // other of two plane regions while this tap's GEMM runs; every weight fragment feeds two MFMA row
 // tiles (WStream2T), the weight stream runs from tap to tap.  One conv_out tile and the GroupNorm
 // moments of its two 32-row slots leave the workgroup - no P.
+// conv output + per-(32-row slot, group) moments for GroupNorm of a 64-row tile's accumulators
+__device__ __forceinline__ void heat_conv64_finish(const HeatLaunch& p, const f32x16 (&acc)[2], const Geom& g, int side, int n,
+                                                   int t_idx, int nvalid, size_t row_base, int lane, int wave, int half, int col) {
+  // conv output + per-(32-row slot, group) moments for GroupNorm (the slots k_heat_final folds)
+  const int c = 32 * wave + col;
+  const int slot0 = g.tile0[side] + n * g.nt[side] + 2 * t_idx;   // g = the heads' TM-row geometry
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int nv = min(TM, nvalid - 32 * mt);      // valid rows of this 32-row slot (<= 0: none)
+    if (nv <= 0) break;                            // (workgroup-uniform)
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, half);
+      if (row < nv) {
+        p.conv_out[(row_base + 32 * mt + row) * C + c] = acc[mt][r];
+        sum += acc[mt][r];
+      }
+    }
+    // 8 channels of a group = lanes with equal (lane&31)>>3, both halves
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum / (float)(nv * 8);
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (crow(r, half) < nv) { const float d = acc[mt][r] - mean; m2 += d * d; }
+    m2 += __shfl_xor(m2, 1, 64);
+    m2 += __shfl_xor(m2, 2, 64);
+    m2 += __shfl_xor(m2, 4, 64);
+    m2 += __shfl_xor(m2, 32, 64);
+    if ((lane & 39) == 0) {  // lane&7 == 0 and half == 0
+      float* dst = p.gn_part + ((size_t)(slot0 + mt) * GN_GROUPS + (c >> 3)) * 2;
+      dst[0] = mean;
+      dst[1] = m2;
+    }
+  }
+}
+
 // ROWS (WStream2T): 2 = both 32-row MFMA tiles hold valid rows, 1 = only the first does - fixed at compile
 // time so that the GEMM steps are branch-free and the staging slices interleave with their MFMAs (the
 // run-time form, a wave-uniform branch around every second-tile MFMA, measured 250 us instead of 238 at
@@ -319,42 +360,148 @@ __device__ __forceinline__ void heat_conv64_body(const HeatLaunch& p, float* sme
     for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(acc[mt][r], att_unscale, bias);
   range_report<MODE>(rg, p.flags);
 
-  // conv output + per-(32-row slot, group) moments for GroupNorm (the slots k_heat_final folds)
-  const int c = 32 * wave + col;
-  const int slot0 = g.tile0[side] + n * g.nt[side] + 2 * t_idx;   // g = the heads' TM-row geometry
+  heat_conv64_finish(p, acc, g, side, n, t_idx, nvalid, row_base, lane, wave, half, col);
+}
+
+// The direct conv with the tile's HALO resident in LDS (round 4, second form; token grids up to 40 wide).
+// The A operand of tap (dy, dx) is the tile's own rows shifted by dy * wf + dx tokens, so the rows
+// l0 - wf - 1 .. l0 + 64 + wf are staged ONCE - att-scaled, as split planes, zeros outside the image -
+// and every tap's GEMM reads the same planes from another first row: no per-tap gather, conversion or
+// barrier; nine GEMM units back to back on one weight stream.  What a shifted window cannot express is
+// the x border (a neighbour across the row end is another row's pixel, not a zero), and that mask
+// depends on the OUTPUT row and dx only: the three dx = -1 taps are accumulated first and their sum is
+// masked (rows with x = 0), the dx = 0 taps accumulate on top, the dx = +1 taps go to a second
+// accumulator that is masked (x = wf - 1) and added at the end.  LDS: (64 + 2 wf + 2) rows x 1056 B:
+// 137 KB at 32 x 32 tokens, 154 KB at 40 x 40 (HALO_MAX_ROWS); wider grids take k_heat_conv64.
+constexpr int HALO_MAX_WF = 40;
+constexpr int HALO_MAX_ROWS = RT + 2 * (HALO_MAX_WF + 1);   // 146
+template <int MODE, int ROWS>
+__device__ __forceinline__ void heat_conv64h_body(const HeatLaunch& p, _Float16* planes, float* att_s, float* mask_s,
+                                                  float* attmax_s) {
+  static_assert(gm_planes(MODE) == 2, "two-plane mode");
+  static_assert(16 % WStream2T<MODE, ROWS>::D == 0, "the tap sequence below assumes a ring phase of 0 after every GEMM");
+  constexpr int THREADS = 512, TPR = THREADS / RT, F4 = 64 / TPR;   // 8 threads per row, 8 float4 each
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
+  const int logical = xcd_remap(blockIdx.x, g.N * (nt0 + nt1));
+  const int per = nt0 + nt1;
+  const int n = logical / per;
+  const int rem = logical - n * per;
+  const int side = rem >= nt0;
+  const int t_idx = side ? rem - nt0 : rem;
+  const int L = g.L[side], wf = g.wf[side];
+  const int l0 = t_idx * RT;
+  const int nvalid = min(RT, L - l0);
+  const float* mem = p.mem[side] + (size_t)n * L * C;
+  const size_t row_base = (size_t)g.row0[side] + (size_t)n * L + l0;
+  Range rg;
+  const int halo0 = l0 - wf - 1, nhalo = RT + 2 * (wf + 1);
+  const int hrow = tid / TPR, hpart = tid % TPR;
+  // att[l'] = memory[l'] . hs for the halo rows; the rows' pieces stay in registers for the staging pass
+  // when the halo fits three passes of 64 rows (it does up to wf = 63)
+  constexpr int NPASS = (HALO_MAX_ROWS + RT - 1) / RT;   // 3
+  f32x4 hv[F4];
+  {
+    const f32x4* hsp = reinterpret_cast<const f32x4*>(p.hs[side] + (size_t)n * C) + hpart;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int nv = min(TM, nvalid - 32 * mt);      // valid rows of this 32-row slot (<= 0: none)
-    if (nv <= 0) break;                            // (workgroup-uniform)
-    float sum = 0.f;
+    for (int i = 0; i < F4; ++i) hv[i] = hsp[i * TPR];
+  }
+#pragma unroll 1
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int hr = ps * RT + hrow;
+    const int l = min(max(halo0 + hr, 0), L - 1);  // clamped: out-of-image rows are zeroed in the staging pass
+    const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)l * C) + hpart;
+    float d = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, half);
-      if (row < nv) {
-        p.conv_out[(row_base + 32 * mt + row) * C + c] = acc[mt][r];
-        sum += acc[mt][r];
-      }
+    for (int i = 0; i < F4; ++i) {
+      const f32x4 v = mp[i * TPR];
+      d += (v[0] * hv[i][0] + v[1] * hv[i][1]) + (v[2] * hv[i][2] + v[3] * hv[i][3]);
     }
-    // 8 channels of a group = lanes with equal (lane&31)>>3, both halves
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    sum += __shfl_xor(sum, 4, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum / (float)(nv * 8);
-    float m2 = 0.f;
+    d = sum8(d);
+    if (hpart == 0 && hr < nhalo) att_s[hr] = d;
+  }
+  if (tid < RT) {   // x-border masks of the tile's output rows
+    const int l = l0 + tid, x = l - (l / wf) * wf;
+    mask_s[tid] = x != 0 ? 1.0f : 0.0f;             // dx = -1 taps
+    mask_s[RT + tid] = x != wf - 1 ? 1.0f : 0.0f;   // dx = +1 taps
+  }
+  __syncthreads();
+  {
+    float m = 0.f;
+    for (int i = tid; i < nhalo; i += THREADS) m = fmaxf(m, fabsf(att_s[i]));
+    m = wave_max(m);
+    if (lane == 0) attmax_s[wave] = m;
+  }
+  __syncthreads();
+  float att_scale = 1.0f, att_unscale = 1.0f;
+  {
+    float m = attmax_s[0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (crow(r, half) < nv) { const float d = acc[mt][r] - mean; m2 += d * d; }
-    m2 += __shfl_xor(m2, 1, 64);
-    m2 += __shfl_xor(m2, 2, 64);
-    m2 += __shfl_xor(m2, 4, 64);
-    m2 += __shfl_xor(m2, 32, 64);
-    if ((lane & 39) == 0) {  // lane&7 == 0 and half == 0
-      float* dst = p.gn_part + ((size_t)(slot0 + mt) * GN_GROUPS + (c >> 3)) * 2;
-      dst[0] = mean;
-      dst[1] = m2;
+    for (int i = 1; i < THREADS / 64; ++i) m = fmaxf(m, attmax_s[i]);
+    if (m > 0.f && m < INFINITY) {
+      const int e = ilogbf(m) + 1;          // 2^e > m
+      att_scale = ldexpf(1.0f, -e);
+      att_unscale = ldexpf(1.0f, e);
     }
   }
+  _Float16* const hi0 = planes;
+  _Float16* const lo0 = planes + HALO_MAX_ROWS * LDAH;
+  WStream2T<MODE, ROWS> ws;
+  ws.set_rows(nvalid);
+  ws.set_lane(lane);
+  constexpr size_t TAP_UNITS = (size_t)C * C / 8;
+  // tap sequence: dx = -1 (dy = -1, 0, 1), dx = 0, dx = +1;  tap id = 3 (dy + 1) + (dx + 1)
+  auto tap_of = [](int k) { return 3 * (k % 3) + k / 3; };
+  ws.template prime<C, 0>(p.w.conv_w + tap_of(0) * TAP_UNITS, p.w.conv_w_l + tap_of(0) * TAP_UNITS, wave, 0, lane);
+  {  // the halo, once: att-scaled split planes, zero rows outside the image
+    const PlanesT<MODE> H(hi0, lo0, &rg);
+#pragma unroll 1
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int hr = ps * RT + hrow;
+      if (hr < nhalo) {
+        const int l = halo0 + hr;
+        const bool in = l >= 0 && l < L;
+        const float att = in ? att_s[hr] * att_scale : 0.f;
+        const f32x4* mp = reinterpret_cast<const f32x4*>(mem + (size_t)min(max(l, 0), L - 1) * C) + hpart;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) H.put4(hr, 4 * (i * TPR + hpart), mp[i * TPR] * att);
+      }
+    }
+  }
+  __syncthreads();
+  f32x16 acc[2] = {f32x16{0}, f32x16{0}}, accR[2] = {f32x16{0}, f32x16{0}};
+  auto window = [&](int k) {   // the planes as tap k sees them: first row = output row 0 shifted by dy wf + dx
+    const int dy = k % 3 - 1, dx = k / 3 - 1;
+    const int shift = (wf + 1) + dy * wf + dx;
+    return PlanesT<MODE>(hi0 + shift * LDAH, lo0 + shift * LDAH, &rg);
+  };
+  auto run = [&](int k, f32x16 (&a)[2], auto HAS_NEXT_) {
+    constexpr bool HAS_NEXT = decltype(HAS_NEXT_)::value;
+    const int t = tap_of(k), tn = tap_of(HAS_NEXT ? k + 1 : k);
+    ws.template gemm<C, 0, HAS_NEXT, C>(window(k), p.w.conv_w + t * TAP_UNITS, p.w.conv_w_l + t * TAP_UNITS, wave, 0, lane,
+                                        a, p.w.conv_w + tn * TAP_UNITS, p.w.conv_w_l + tn * TAP_UNITS, wave, 0);
+  };
+#pragma unroll 1
+  for (int k = 0; k < 3; ++k) run(k, acc, std::true_type{});          // dx = -1
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] *= mask_s[32 * mt + crow(r, half)];
+#pragma unroll 1
+  for (int k = 3; k < 6; ++k) run(k, acc, std::true_type{});          // dx = 0
+#pragma unroll 1
+  for (int k = 6; k < 8; ++k) run(k, accR, std::true_type{});         // dx = +1
+  run(8, accR, std::false_type{});
+  const float bias = p.w.conv_b[32 * wave + col];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc[mt][r] = fmaf(fmaf(accR[mt][r], mask_s[RT + 32 * mt + crow(r, half)], acc[mt][r]), att_unscale, bias);
+  range_report<MODE>(rg, p.flags);
+  heat_conv64_finish(p, acc, g, side, n, t_idx, nvalid, row_base, lane, wave, half, col);
 }
 
 template <int MODE>
@@ -373,10 +520,31 @@ __global__ __launch_bounds__(512) void k_heat_conv64(HeatLaunch p) {
   else heat_conv64_body<MODE, 1>(p, smem, att_s, attmax_s);
 }
 
+template <int MODE>
+__global__ __launch_bounds__(512) void k_heat_conv64h(HeatLaunch p) {
+  __shared__ __attribute__((aligned(16))) _Float16 planes[2 * HALO_MAX_ROWS * LDAH];   // 154 176 B
+  __shared__ float att_s[HALO_MAX_ROWS + 6];
+  __shared__ float mask_s[2 * RT];
+  __shared__ float attmax_s[512 / 64];
+  const Geom& g = p.g;
+  const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
+  const int logical = xcd_remap(blockIdx.x, g.N * (nt0 + nt1));
+  const int rem = logical - (logical / (nt0 + nt1)) * (nt0 + nt1);
+  const int side = rem >= nt0;
+  const int t_idx = side ? rem - nt0 : rem;
+  const int nvalid = min(RT, g.L[side] - t_idx * RT);
+  if (__builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0)) heat_conv64h_body<MODE, 2>(p, planes, att_s, mask_s, attmax_s);
+  else heat_conv64h_body<MODE, 1>(p, planes, att_s, mask_s, attmax_s);
+}
+
 hipError_t launch_heat_conv64(const HeatLaunch& p, int mode, hipStream_t s) {
   if (mode != GM_SPLIT) return hipErrorInvalidValue;
   const int tiles = p.g.N * ((p.g.L[0] + RT - 1) / RT + (p.g.L[1] + RT - 1) / RT);
-  hipLaunchKernelGGL((k_heat_conv64<GM_SPLIT>), dim3(tiles), dim3(512), 0, s, p);
+  // halo-resident form while both token grids are at most HALO_MAX_WF wide (its LDS holds 64 + 2 wf + 2 rows)
+  if (p.g.wf[0] <= HALO_MAX_WF && p.g.wf[1] <= HALO_MAX_WF && !p.force_staged_conv)
+    hipLaunchKernelGGL((k_heat_conv64h<GM_SPLIT>), dim3(tiles), dim3(512), 0, s, p);
+  else
+    hipLaunchKernelGGL((k_heat_conv64<GM_SPLIT>), dim3(tiles), dim3(512), 0, s, p);
   return hipGetLastError();
 }
 

@@ -219,7 +219,9 @@ oetr_status oetr_set_state_prereduce(oetr_handle h, int on);
  * GEMV chain hides behind the conv GEMMs (best for small batches).  2: "direct form" - decoder first,
  * then the conv of memory * att with the nine taps accumulated in registers, 64 token rows per
  * workgroup, no P buffer (best once the 9 x rows x 1 KB of P traffic outweigh the decoder chain;
- * two-plane dtypes only).  0 (default): automatic - direct from 16 000 token rows (N (L1 + L2)) in
+ * two-plane dtypes only; token grids up to 40 wide keep the tile's halo resident in LDS as split planes and
+ * run the nine taps as shifted windows of it, wider grids stage each tap's gathered tile - 3 forces that
+ * second kernel at any width, for measurements).  0 (default): automatic - direct from 16 000 token rows (N (L1 + L2)) in
  * the two-plane dtypes, P form otherwise.  Same arithmetic per product; results agree to fp32
  * summation order (the nine taps are summed in the MFMA accumulator instead of in k_heat_combine).
  * Mutates the handle like the other setters. */
