@@ -231,14 +231,17 @@ def pmc_traffic(kernel_substr):
     return int((2 * out['fetch'] + out['write']) * 1024), ' + '.join(src)
 
 
-def mangled_encoder(tile, mode_id, policy=0):
+def mangled_encoder(tile, mode_id, policy=0, attention='linear'):
     """Substring of the B;A encoder kernel's mangled name in rocprofv3 CSVs."""
     if tile == 64:
         return f'k_encoder64ILb1ELi0ELi{mode_id}ELi{policy}EE'
+    if mode_id == 1 and attention == 'linear':   # two-plane dtypes: the 32-row kernel on the 64-row kernel's body (encoder.hip: k_encoder32m)
+        return f'k_encoder32mILb1ELi0ELi{mode_id}ELi{policy}EE'
     return f'k_encoderILb1ELi0ELi{mode_id}ELi{4 if mode_id == 0 else 8}ELb0ELi{policy}EE'
 
 
-def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload, extra_flop=0, grids=None):
+def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload, extra_flop=0, grids=None,
+                   attention='linear'):
     if not kern or DOMINANT not in kern:
         return None
     launches, total_ms = kern[DOMINANT]
@@ -250,7 +253,9 @@ def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_work
     peak = pipe_peak / cost
     ach = flop / (avg_ms * 1e-3) / 1e12
     block = {
-        'kernel': ('k_encoder64<B,A>' if tile == 64 else 'k_encoder<B,A>') + f' [{precision}]',
+        'kernel': ('k_encoder64<B,A>' if tile == 64 else
+                   'k_encoder32m<B,A>' if precision in ('f32_split_f16', 'f32_split_qk16') and attention == 'linear'
+                   else 'k_encoder<B,A>') + f' [{precision}]',
         'tile_rows': tile, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1),
         'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'peak_basis': basis,
         'executed_mfma_tflops': round(ach * cost, 2),
@@ -265,7 +270,7 @@ def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_work
         block['note'] = ('frac is this kernel ALONE on the chip; its launch has %d workgroups for 256 CUs '
                          '(one per CU), the overlapped streams fill the rest - the chip-level figure is '
                          'hot_path_frac_of_mfma_peak' % wgs)
-    traffic, src = (pmc_traffic(mangled_encoder(tile, MODE_ID[precision], POLICY_ID.get(precision, 0)))
+    traffic, src = (pmc_traffic(mangled_encoder(tile, MODE_ID[precision], POLICY_ID.get(precision, 0), attention))
                     if standard_workload else (None, None))
     block['traffic'] = traffic
     if traffic is not None:
@@ -804,7 +809,7 @@ def main():
     if 'trace_overlap_shape' in main_res:
         kern, t_s = main_res['trace_overlap_shape']
         rb = roofline_block(kern, args.precision, tokens, tile_overlap or 32, args.steps, t_s, standard, extra_flop,
-                            grids=(n, hf * hf, hf2 * hf2))
+                            grids=(n, hf * hf, hf2 * hf2), attention=args.attention)
         if rb:
             out['roofline'] = rb
             out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
@@ -812,7 +817,7 @@ def main():
     if 'trace_serial_shape' in main_res:
         kern, t_s = main_res['trace_serial_shape']
         rb = roofline_block(kern, args.precision, tokens, 64 if args.precision in POLICY_ID else (args.enc_tile or 32), args.steps, t_s, standard, extra_flop,
-                            grids=(n, hf * hf, hf2 * hf2))
+                            grids=(n, hf * hf, hf2 * hf2), attention=args.attention)
         if rb:
             out['serial']['roofline'] = rb
             out['serial']['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
