@@ -144,6 +144,7 @@ struct oetr_ctx {
   int device = 0;
   int mode = GM_SPLIT;  // GEMM mode GM_* (common.h) of the oetr_dtype
   int kv_prereduce = -1; // oetr_set_state_prereduce (-1 = auto)
+  int dec_split = 0;     // oetr_set_decoder_split: 0 auto, 1 one workgroup per image, 4 four (decoder.hip: decoder_body4)
   int tail_mode = 0;     // oetr_set_tail_mode: 0 auto, 1 P form (decoder || conv-P, combine), 2 direct (decoder, conv)
   int policy = 0;       // precision policy (SitePolicy<>) of the oetr_dtype: 1 = OETR_DTYPE_F32_SPLIT_QK16
   int enc_tile = 0;    // 0 = auto, 32, 64 (oetr_set_encoder_tile)
@@ -292,6 +293,7 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.img_w[0] = p.img_w[1] = 0;
   p.flags = w.flags;
   p.force_staged_conv = h->tail_mode == 3;
+  p.convp_split = 1;
   return p;
 }
 
@@ -321,6 +323,16 @@ DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w) {
   d.tgt1 = h->dec_tgt1; d.qkv1 = h->dec_qkv1;
   d.att0_part = w.att0; d.z0_part = w.z0; d.dkv1 = w.dkv1; d.dks1 = w.dks1;
   d.hs = w.hs;
+  // Four workgroups per image while 2N x 4 of them take at most a quarter of the CUs: the
+  // exchanging workgroups of up to four forwards in flight on one device (one per stream)
+  // are then resident together whatever the dispatch order - they wait for each other
+  // (decoder.hip: exchange_sum).  More images: the chain hides behind the conv GEMMs anyway.
+  const bool fits = 2 * g.N <= DEC_SPLIT_MAX_IMAGES && 2 * g.N * DEC_SPLIT_K * 4 <= h->num_cus;
+  d.ksplit = (h->dec_split == DEC_SPLIT_K || (h->dec_split == 0 && fits)) && 2 * g.N <= DEC_SPLIT_MAX_IMAGES
+                 ? DEC_SPLIT_K : 1;
+  d.flags = w.flags;
+  d.xch_epoch = w.flags + STATUS_EPOCH_WORD;
+  d.xch = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w.flags) + STATUS_XCH_OFFSET);
   d.tbuf = nullptr;
   d.dbg = 0;
 #ifdef OETR_PHASE_TIMING
@@ -465,6 +477,7 @@ oetr_status oetr_create(const oetr_weights* w, oetr_dtype dtype, int device, oet
   if (!w || !out) return fail(OETR_ERR_BAD_ARG, "oetr_create: NULL argument");
   if (w->struct_size != sizeof(oetr_weights) || w->abi_version != OETR_ABI_VERSION)
     return fail(OETR_ERR_BAD_ARG, "oetr_create: oetr_weights size/ABI mismatch");
+  static_assert(OETR_WORKSPACE_STATUS_BYTES == STATUS_BYTES && OETR_FLAG_EXCHANGE == FLAG_EXCHANGE, "status block");
   static_assert(OETR_DTYPE_F32 == GM_F32 && OETR_DTYPE_F32_SPLIT_F16 == GM_SPLIT &&
                     OETR_DTYPE_F16 == GM_F16 && OETR_DTYPE_BF16 == GM_BF16, "oetr_dtype == GM_*");
   if (dtype != OETR_DTYPE_F32 && dtype != OETR_DTYPE_F32_SPLIT_F16 && dtype != OETR_DTYPE_F16 &&
@@ -1295,6 +1308,14 @@ oetr_status oetr_set_tail_mode(oetr_handle h, int mode) {
   if (mode >= 2 && h->mode != GM_SPLIT)
     return fail(OETR_ERR_UNSUPPORTED, "the direct 64-row heat-map conv is built for the two-plane dtypes (F32_SPLIT_F16, F32_SPLIT_QK16)");
   h->tail_mode = mode;
+  return OETR_OK;
+}
+
+oetr_status oetr_set_decoder_split(oetr_handle h, int k) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_decoder_split: NULL handle");
+  if (k != 0 && k != 1 && k != DEC_SPLIT_K)
+    return fail(OETR_ERR_BAD_ARG, "oetr_set_decoder_split: 0 (auto), 1 or 4 workgroups per image");
+  h->dec_split = k;
   return OETR_OK;
 }
 

@@ -392,6 +392,14 @@ __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
 // represented (|x| >= 65520 rounds to inf; NaN counts too).  The host reads the word with
 // oetr_query_flags() / oetr_read_flags_async().  Weights are checked at create.
 constexpr uint32_t FLAG_F16_RANGE = 1u;   // == OETR_FLAG_F16_RANGE
+constexpr uint32_t FLAG_EXCHANGE = 2u;    // == OETR_FLAG_EXCHANGE (decoder.hip: exchange_sum)
+// Status block of a workspace (include/oetr_hip.h: OETR_WORKSPACE_STATUS_BYTES, zeroed by
+// oetr_workspace_init): word 0 = flags; words 16..31 = per-image call counters of the split
+// decoder; from byte 256 its exchange granules [16 images][5][4][256] x 8 bytes.
+constexpr int DEC_SPLIT_K = 4, DEC_SPLIT_MAX_IMAGES = 16, DEC_SPLIT_EXCHANGES = 5;
+constexpr size_t STATUS_EPOCH_WORD = 16, STATUS_XCH_OFFSET = 256,
+                 STATUS_XCH_BYTES = (size_t)DEC_SPLIT_MAX_IMAGES * DEC_SPLIT_EXCHANGES * DEC_SPLIT_K * 256 * 8,
+                 STATUS_BYTES = STATUS_XCH_OFFSET + STATUS_XCH_BYTES;
 constexpr float F16_MAX = 65504.0f;
 constexpr bool gm_f16_range(int m) { return m == GM_SPLIT || m == GM_F16; }
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -1200,6 +1208,10 @@ struct DecLaunch {
   const float* dkv1;       // [ntiles][8192]
   const float* dks1;       // [ntiles][256]
   float* hs;               // [2N][256]
+  int ksplit;              // workgroups per image: 1, or OETR_DEC_SPLIT_K with the three fields below
+  unsigned long long* xch; // [2N][5 exchanges][4][256] {tag, value} granules (workspace status block)
+  unsigned* xch_epoch;     // [2N] call counters = tags (workspace status block)
+  uint32_t* flags;         // the workspace's status word (OETR_FLAG_EXCHANGE)
   long long* tbuf;         // OETR_PHASE_TIMING builds only
   int dbg;                 // OETR_ABLATE builds only
 };
@@ -1234,6 +1246,7 @@ struct HeatLaunch {
   int img_w[2];
   uint32_t* flags;         // the handle's status word (FLAG_F16_RANGE)
   int force_staged_conv;   // direct form: k_heat_conv64 (per-tap staging) even where the halo-resident form fits
+  int convp_split;         // conv-P work items per 64-token tile: 1 or 3 (conv_p.h), set by launch_decoder_convp
 };
 hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s);
 // 64 token rows per workgroup, two-plane mode only: the direct conv of the forward path for large batches

@@ -60,17 +60,18 @@ __device__ __forceinline__ void conv_p_body(const HeatLaunch& p, float* __restri
 // workgroup) feeds two MFMA row tiles, and the weight stream runs ahead from tap to
 // tap.  Tiles are 64 consecutive tokens of one image: tile index over
 // N x (ceil(L0/64) + ceil(L1/64)), pair-major like the encoder's.
-// The nine taps of a tile are shared by CONVP_SPLIT workgroups (adjacent in the grid: the tile's
-// rows are staged by each, from L2): three times as many, shorter work items - at 8 pairs
-// 336 instead of 112, which fill the chip next to the decoder's 16 workgroups.
-#ifndef OETR_CONVP_SPLIT
-#define OETR_CONVP_SPLIT 1   // 3: measured slower (decoder_convp 53.5 -> 58.6 us: the decoder chain, the critical path of that launch, slows down under the extra streaming workgroups)
-#endif
-constexpr int CONVP_SPLIT = OETR_CONVP_SPLIT, CONVP_TAPS = 9 / CONVP_SPLIT;
+// The nine taps of a tile are shared by p.convp_split = 1 or 3 workgroups (adjacent in the grid:
+// the tile's rows are staged by each, from L2).  3 = three times as many, shorter work items: at
+// 8 pairs 336 instead of 112.  Measured on MI355X (round 4): beside the ONE-workgroup-per-image
+// decoder, whose 50-us chain is that launch's critical path, they only slow it down (53.5 -> 57.4
+// us); beside the four-workgroup decoder (25 us) the conv items ARE the critical path, and three
+// per tile take the launch from 49.6 to 41.6 us at 8 pairs @640x640, 47 -> 27.5 at 4 pairs, 45.5 ->
+// 25.7 at one (nine per tile: 48.7 / 36.8 / 26.6 - the staging of the tile per item).
 template <int MODE>
 __device__ __forceinline__ void conv_p_body64(const HeatLaunch& p, float* __restrict__ P, int item,
                                               float* smem) {
   static_assert(16 % WStream2T<MODE>::D == 0, "tap loop below assumes a ring phase of 0 after every GEMM");
+  const int CONVP_SPLIT = p.convp_split, CONVP_TAPS = 9 / CONVP_SPLIT;
   constexpr int THREADS = 512, TPR = THREADS / RT, F4 = 64 / TPR;
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

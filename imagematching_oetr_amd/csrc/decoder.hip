@@ -409,6 +409,292 @@ __device__ __forceinline__ void decoder_body(const DecLaunch& p, int img, float*
   PHASE_STAMP(p, 9);
 }
 
+// ---------------------------------------------------------------------------
+// The same chain on DEC_K = 4 workgroups per image (round 4).  One CU streams its
+// image's 3.9 MB of fp32 weights at the 45-50 B/clk its L1 fills at = 37-41 us of the
+// 50-us chain; four CUs stream a quarter each.  The stages alternate between
+//   column split: every workgroup holds the full input vector and produces its own
+//                 quarter of the outputs (a head pair / an FFN slab) - nothing to exchange;
+//   row split:    the next stage takes that quarter as its input rows and produces a
+//                 partial of all 256 outputs - one all-reduce of 256 floats per image,
+// so of the nine GEMV stages five end in an exchange (S1 S3 S5 S7 S9) and the attention
+// pieces in between run per head pair: the layer-1 memory state is reduced and kept by
+// quarters too.  Every workgroup ends each exchange with the same tgt (the four partials
+// are added in workgroup order by everyone), LayerNorms are computed redundantly.
+//
+// Exchange = MI355X_MICROARCH.md "handoff-1to1" / cdna_hip_programming.md Guideline 16 R2:
+// the data is the flag - 8-byte {tag, value} granules written by ONE agent-scope (sc1)
+// store each and polled with agent-scope loads; no fence, no flag word.  The tag is the
+// image's call counter, kept in the workspace's status block (zeroed by
+// oetr_workspace_init together with the granule region): read by every workgroup of the
+// image at its start and incremented by workgroup 0 after the last exchange - by then
+// all four have read it - so graph replays, which repeat the kernel arguments, still see a
+// fresh tag per call, and no per-call memset sits on the serial path.
+// Residency: the host picks this form only while 2N * DEC_K <= a quarter of the CUs
+// (api.hip: decoder_split), the decoder workgroups lead the grid, and a poll that
+// outlasts DEC_SPIN_LIMIT of wall clock raises OETR_FLAG_EXCHANGE in the status word and
+// moves on (the call's outputs are then invalid, like an operand-range overflow).
+constexpr int DEC_K = DEC_SPLIT_K;
+constexpr int XCH_STAGES = DEC_SPLIT_EXCHANGES;
+constexpr long long DEC_SPIN_LIMIT = 200000;   // wall_clock64 ticks (100 MHz): 2 ms
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+struct DecSmem4 {
+  static constexpr int KV = 0, PARTS = KV + 2 * HD * HD, VEC = PARTS + 3 * 2048, SLAB = VEC + 4 * C,
+                       TOTAL = SLAB + 64 * 3 + 192 + 128;
+};
+
+// weight fetches of one stage: KPER float4 per thread into w[B0 ..]
+//  rows<KS>: rows [j*KS, (j+1)*KS) of Wt[in][256]; thread = (k-chunk tid/64 of KS/8 rows, output float4 tid%64)
+template <int KS, int B0>
+__device__ __forceinline__ void issue_rows(const float* __restrict__ Wt, int j, int tid, f32x4 (&w)[16]) {
+  constexpr int KPER = KS / 8;
+  const f32x4* src = reinterpret_cast<const f32x4*>(Wt) + (size_t)(j * KS + (tid >> 6) * KPER) * (C / 4) + (tid & 63);
+#pragma unroll
+  for (int i = 0; i < KPER; ++i) w[B0 + i] = src[i * (C / 4)];
+  __builtin_amdgcn_sched_barrier(0);
+}
+//  cols<NS, LD>: columns [j*NS, (j+1)*NS) of Wt[256][LD]; thread = (k-chunk tid/(NS/4), output float4 tid%(NS/4))
+template <int NS, int LD, int B0>
+__device__ __forceinline__ void issue_cols(const float* __restrict__ Wt, int j, int tid, f32x4 (&w)[16]) {
+  constexpr int NO4 = NS / 4, KCH = 512 / NO4, KPER = C / KCH;
+  const f32x4* src = reinterpret_cast<const f32x4*>(Wt) + (size_t)((tid / NO4) * KPER) * (LD / 4) + j * NO4 + tid % NO4;
+#pragma unroll
+  for (int i = 0; i < KPER; ++i) w[B0 + i] = src[i * (LD / 4)];
+  __builtin_amdgcn_sched_barrier(0);
+}
+// partial products: part[kc][256] (rows) / part[kc][NS] (cols)
+template <int KS, int B0>
+__device__ __forceinline__ void fma_rows(const f32x4 (&w)[16], const float* x_s, float* part_s, int tid) {
+  constexpr int KPER = KS / 8;
+  const int kc = tid >> 6;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KPER; ++i) acc += w[B0 + i] * x_s[kc * KPER + i];
+  *reinterpret_cast<f32x4*>(part_s + kc * C + 4 * (tid & 63)) = acc;
+}
+template <int NS, int B0>
+__device__ __forceinline__ void fma_cols(const f32x4 (&w)[16], const float* x_s, float* part_s, int tid) {
+  constexpr int NO4 = NS / 4, KCH = 512 / NO4, KPER = C / KCH;
+  const int kc = tid / NO4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KPER; ++i) acc += w[B0 + i] * x_s[kc * KPER + i];
+  *reinterpret_cast<f32x4*>(part_s + kc * NS + 4 * (tid % NO4)) = acc;
+}
+template <int KCH, int NS>
+__device__ __forceinline__ float collect(const float* part_s, int o) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < KCH; ++c) s += part_s[c * NS + o];
+  return s;
+}
+
+// Sum of `mine` over the image's DEC_K workgroups, element tid of 256 (threads 0..255, whole
+// waves); the same value - same order of additions - in every workgroup.  LEADER_ONLY: the
+// last exchange, only workgroup 0 needs the sum.
+template <bool LEADER_ONLY>
+__device__ __forceinline__ float exchange_sum(const DecLaunch& p, int img, int stage, int j, unsigned tag,
+                                              float mine, int tid) {
+  gu64* slot = (gu64*)p.xch + ((size_t)(img * XCH_STAGES + stage) * DEC_K) * C + tid;
+  __hip_atomic_store(slot + j * C, ((unsigned long long)tag << 32) | __float_as_uint(mine), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  if (LEADER_ONLY && j != 0) return 0.f;
+  float v[DEC_K];
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 0;; ++spins) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < DEC_K; ++k) {
+      const unsigned long long x = __hip_atomic_load(slot + k * C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v[k] = k == j ? mine : __uint_as_float((unsigned)x);
+      ok &= k == j || (unsigned)(x >> 32) == tag;
+    }
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 63) == 63 && wall_clock64() - t0 > DEC_SPIN_LIMIT) {
+      if ((tid & 63) == 0) atomicOr(p.flags, FLAG_EXCHANGE);
+      break;
+    }
+  }
+  static_assert(DEC_K == 4, "fixed summation order below");
+  return (v[0] + v[1]) + (v[2] + v[3]);
+}
+
+__device__ __forceinline__ void decoder_body4(const DecLaunch& p, int img, int j, float* smem) {
+  using M = DecSmem4;
+  float* kv_s = smem + M::KV;      // [2 heads][d][v], layer 1, heads 2j and 2j + 1
+  float* part_s = smem + M::PARTS;
+  float *tgt = smem + M::VEC, *t2 = tgt + C, *qk = tgt + 2 * C, *qe = tgt + 3 * C;
+  float *att = smem + M::SLAB, *ksum = att + 64, *vq = att + 128, *qkv_s = att + 192, *hdn_s = qkv_s + 192;
+  constexpr int T = 512;
+
+  const Geom& g = p.g;
+  const int tid = threadIdx.x;
+  const int side = img >= g.N, n = side ? img - g.N : img;
+  const int L = g.L[side], nts = g.nt[side];
+  const int slot0 = g.tile0[side] + n * nts;
+  const DecLayerDev& w0 = p.layer[0];
+  const DecLayerDev& w1 = p.layer[1];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned tag = p.xch_epoch[img] + 1;   // never 0; workgroup 0 stores it back at the end
+
+  f32x4 wa[16], wb[16];   // two stages of weights in flight
+  issue_rows<64, 0>(w0.cross.wm_t, j, tid, wa);      // S1
+  issue_cols<128, FF, 0>(w0.w1_t, j, tid, wb);       // S2
+  PHASE_STAMP(p, 0);
+
+  // ---- this quarter of the image's tile partials: two heads of the layer-1 memory state
+  // -> LDS, 64 columns of the layer-0 partial messages -> att
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.dkv1) + (size_t)slot0 * (KV_FLOATS / 4) + j * T + tid;
+    const int c = 64 * j + (tid & 63), hh = c >> 5;
+    f32x4 sacc = zero4;
+    float ks = 0.f, a0 = 0.f, z0 = 0.f;
+    constexpr int R = 8;   // tiles per round trip
+    for (int ti0 = 0; ti0 < nts; ti0 += R) {
+      f32x4 a[R];
+      float kt[R], av[R], zv[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const size_t ti = min(ti0 + u, nts - 1);
+        a[u] = src[ti * (KV_FLOATS / 4)];
+        if (tid < 64) {
+          kt[u] = p.dks1[(slot0 + ti) * C + c];
+          av[u] = p.att0_part[(slot0 + ti) * C + c];
+          zv[u] = p.z0_part[(slot0 + ti) * NH + hh];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+        if (ti0 + u < nts) {
+          sacc += a[u];
+          if (tid < 64) { ks += kt[u]; a0 += av[u]; z0 += zv[u]; }
+        }
+    }
+    {
+      const int ln = tid & 63, q = (tid >> 6) & 3, hl = tid >> 8;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) kv_s[(hl * HD + (jj + 8 * q + 4 * (ln >> 5))) * HD + (ln & 31)] = sacc[jj];
+    }
+    if (tid < 64) {
+      ksum[tid] = ks;
+      att[tid] = a0 * (1.0f / (z0 + ATTN_EPS)) * (float)L;
+    }
+    if (tid < C) {
+      tgt[tid] = p.tgt1[side * C + tid];
+      qe[tid] = p.qe[side][tid];
+    }
+  }
+  __syncthreads();
+
+  PHASE_STAMP(p, 1);
+  // S1: tgt += Wm_c0 . att0                                   (rows: this head pair's att0)
+  fma_rows<64, 0>(wa, att, part_s, tid);
+  issue_rows<128, 0>(w0.w2_t, j, tid, wa);            // S3
+  __syncthreads();
+  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 0, j, tag, collect<8, C>(part_s, tid), tid);
+  __syncthreads();
+  PHASE_STAMP(p, 2);
+  // S2: hdn = relu(W1_0 . LN3(tgt))                           (columns: this FFN slab)
+  ln_vec(tgt, w0.n3w, w0.n3b, t2, nullptr, nullptr, tid);
+  fma_cols<128, 0>(wb, t2, part_s, tid);
+  issue_cols<64, C, 0>(w1.self_attn.wq_t, j, tid, wb);   // S4 q, k
+  issue_cols<64, C, 8>(w1.self_attn.wk_t, j, tid, wb);
+  __syncthreads();
+  if (tid < 128) hdn_s[tid] = fmaxf(collect<16, 128>(part_s, tid), 0.f);
+  __syncthreads();
+  PHASE_STAMP(p, 3);
+  // S3: tgt += W2_0 . hdn                                     (rows: this FFN slab)
+  fma_rows<128, 0>(wa, hdn_s, part_s, tid);
+  issue_cols<64, C, 0>(w1.self_attn.wv_t, j, tid, wa);   // S4 v
+  issue_rows<64, 8>(w1.self_attn.wm_t, j, tid, wa);      // S5
+  __syncthreads();
+  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 1, j, tag, collect<8, C>(part_s, tid), tid);
+  __syncthreads();
+
+  PHASE_STAMP(p, 4);
+  // S4: layer 1 self-attention, this head pair: q | k | v from LN1(tgt)
+  ln_vec(tgt, w1.n1w, w1.n1b, t2, nullptr, nullptr, tid);
+  fma_cols<64, 0>(wb, t2, part_s, tid);
+  fma_cols<64, 8>(wb, t2, part_s + 2048, tid);
+  issue_cols<64, C, 0>(w1.cross.wq_t, j, tid, wb);       // S6
+  issue_rows<64, 8>(w1.cross.wm_t, j, tid, wb);          // S7
+  fma_cols<64, 0>(wa, t2, part_s + 4096, tid);
+  __syncthreads();
+  if (tid < 192) {
+    const int m = tid >> 6, o = tid & 63;
+    const float v = collect<32, 64>(part_s + 2048 * m, o) + p.qkv1[side * 3 * C + m * C + 64 * j + o];
+    qkv_s[tid] = m < 2 ? elu1(v) : v;   // phi(q), phi(k) once per element; v as is
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // L = S = 1 linear attention (values / v_length with v_length = 1)
+    const int hl = tid >> 5;
+    const float vval = qkv_s[128 + tid] / 1.0f;
+    float z = 0.f, sa = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) {
+      const float fq = qkv_s[hl * HD + d], fk = qkv_s[64 + hl * HD + d];
+      z += fq * fk;
+      sa += fq * (fk * vval);
+    }
+    att[tid] = sa * (1.0f / (z + ATTN_EPS)) * 1.0f;
+  }
+  __syncthreads();
+  PHASE_STAMP(p, 5);
+  // S5: tgt += Wm_s1 . att
+  fma_rows<64, 8>(wa, att, part_s, tid);
+  issue_cols<128, FF, 0>(w1.w1_t, j, tid, wa);           // S8
+  __syncthreads();
+  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 2, j, tag, collect<8, C>(part_s, tid), tid);
+  __syncthreads();
+  PHASE_STAMP(p, 6);
+  // S6: layer 1 cross-attention, this head pair
+  ln_vec(tgt, w1.n2w, w1.n2b, t2, qe, qk, tid);
+  fma_cols<64, 0>(wb, qk, part_s, tid);
+  __syncthreads();
+  if (tid < 64) vq[tid] = elu1(collect<32, 64>(part_s, tid) + w1.cross.bq[64 * j + tid]);
+  __syncthreads();
+  if (tid < 64) {
+    const int hl = tid >> 5, v = tid & 31;
+    float z = 0.f, sacc = 0.f;
+#pragma unroll 4
+    for (int d = 0; d < HD; ++d) {
+      const float fq = vq[hl * HD + d];
+      z += fq * ksum[hl * HD + d];
+      sacc += fq * kv_s[(hl * HD + d) * HD + v];
+    }
+    att[tid] = sacc * (1.0f / (z + ATTN_EPS)) * (float)L;
+  }
+  __syncthreads();
+  PHASE_STAMP(p, 7);
+  // S7: tgt += Wm_c1 . att
+  fma_rows<64, 8>(wb, att, part_s, tid);
+  issue_rows<128, 0>(w1.w2_t, j, tid, wb);               // S9
+  __syncthreads();
+  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 3, j, tag, collect<8, C>(part_s, tid), tid);
+  __syncthreads();
+  PHASE_STAMP(p, 8);
+  // S8/S9: ReLU MLP
+  ln_vec(tgt, w1.n3w, w1.n3b, t2, nullptr, nullptr, tid);
+  fma_cols<128, 0>(wa, t2, part_s, tid);
+  __syncthreads();
+  if (tid < 128) hdn_s[tid] = fmaxf(collect<16, 128>(part_s, tid), 0.f);
+  __syncthreads();
+  fma_rows<128, 0>(wb, hdn_s, part_s, tid);
+  __syncthreads();
+  if (tid < C) {
+    const float s = exchange_sum<true>(p, img, 4, j, tag, collect<8, C>(part_s, tid), tid);
+    if (j == 0) {
+      p.hs[(size_t)img * C + tid] = tgt[tid] + s;
+      if (tid == 0) p.xch_epoch[img] = tag;
+    }
+  }
+  PHASE_STAMP(p, 9);
+}
+
 #ifndef OETR_DEC_THREADS
 #define OETR_DEC_THREADS 512   // measured equal to 1024 (the chain is L1-rate bound)
 #endif
@@ -417,26 +703,36 @@ __global__ __launch_bounds__(T) void k_decoder(DecLaunch p) {
   __shared__ __attribute__((aligned(16))) float smem[DecSmem<T>::TOTAL];
   decoder_body<T>(p, blockIdx.x, smem);
 }
+__global__ __launch_bounds__(512) void k_decoder4(DecLaunch p) {
+  __shared__ __attribute__((aligned(16))) float smem[DecSmem4::TOTAL];
+  decoder_body4(p, blockIdx.x / DEC_K, blockIdx.x % DEC_K, smem);
+}
 
 hipError_t launch_decoder(const DecLaunch& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_decoder<OETR_DEC_THREADS>, dim3(2 * p.g.N), dim3(OETR_DEC_THREADS), 0, s, p);
+  if (p.ksplit == DEC_K)
+    hipLaunchKernelGGL(k_decoder4, dim3(2 * p.g.N * DEC_K), dim3(512), 0, s, p);
+  else
+    hipLaunchKernelGGL(k_decoder<OETR_DEC_THREADS>, dim3(2 * p.g.N), dim3(OETR_DEC_THREADS), 0, s, p);
   return hipGetLastError();
 }
 
-// Decoder (blocks [0, 2N)) and conv P tiles (blocks [2N, 2N + ntiles)) in one
-// launch: the decoder occupies 2N CUs for ~50 us while the P GEMMs fill the rest
-// of the chip; decoder blocks come first in the grid so they are dispatched first.
+// Decoder (blocks [0, 2N * ksplit)) and conv P tiles (the blocks behind them) in one
+// launch: the decoder occupies 2N (x 4) CUs while the P GEMMs fill the rest of the chip;
+// decoder blocks come first in the grid so they are dispatched first.
 template <int MODE, bool T64>
 __global__ __launch_bounds__(512) void k_decoder_convp(DecLaunch d, HeatLaunch h, float* P) {
   constexpr int TILE = T64 ? R_FLOATS : TILE_FLOATS;
+  static_assert(DecSmem4::TOTAL <= DecSmem<512>::TOTAL, "decoder LDS");
   constexpr int LDS_FLOATS = DecSmem<512>::TOTAL > TILE ? DecSmem<512>::TOTAL : TILE;
   __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
-  const int nd = 2 * d.g.N;
+  const int nd = 2 * d.g.N * d.ksplit;
 #ifdef OETR_ROLE_ABL   // timing experiments only: 1 = decoder workgroups only, 2 = conv-P only
   if ((OETR_ROLE_ABL == 1) != ((int)blockIdx.x < nd)) return;
 #endif
-  if ((int)blockIdx.x < nd) decoder_body<512>(d, blockIdx.x, smem);
-  else if constexpr (T64) conv_p_body64<MODE>(h, P, blockIdx.x - nd, smem);
+  if ((int)blockIdx.x < nd) {
+    if (d.ksplit == DEC_K) decoder_body4(d, blockIdx.x / DEC_K, blockIdx.x % DEC_K, smem);
+    else decoder_body<512>(d, blockIdx.x, smem);
+  } else if constexpr (T64) conv_p_body64<MODE>(h, P, blockIdx.x - nd, smem);
   else conv_p_body<MODE>(h, P, blockIdx.x - nd, smem);
 }
 
@@ -444,15 +740,17 @@ __global__ __launch_bounds__(512) void k_decoder_convp(DecLaunch d, HeatLaunch h
 #define OETR_CONVP64 1   // 0: the round-1 rule (64-token conv-P tiles only when the encoder runs 64-token tiles)
 #endif
 template <int MODE>
-static hipError_t launch_decoder_convp_mode(const DecLaunch& d, const HeatLaunch& h, float* P,
+static hipError_t launch_decoder_convp_mode(const DecLaunch& d, const HeatLaunch& h0, float* P,
                                             hipStream_t s) {
-  // conv-P work items: in the 16-bit-plane modes 64-token tiles (x CONVP_SPLIT tap groups)
+  // conv-P work items: in the 16-bit-plane modes 64-token tiles (x convp_split tap groups)
   // whatever tile the encoder runs - P is indexed by row; fewer, longer workgroups leave the
-  // decoder chain, this launch's critical path, more of the L2 (52.0 vs 53.5 us) -
-  // else TM-token tiles (h.g)
+  // one-workgroup decoder chain, then this launch's critical path, more of the L2 (52.0 vs
+  // 53.5 us) - else TM-token tiles (h.g).  Three items per tile beside the split decoder (conv_p.h).
+  HeatLaunch h = h0;
   const bool t64 = gm_half(MODE) && (OETR_CONVP64 || d.g.ntiles != h.g.ntiles);
-  const int ptiles = t64 ? CONVP_SPLIT * h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT) : h.g.ntiles;
-  const dim3 grid(2 * d.g.N + ptiles);
+  h.convp_split = t64 && d.ksplit == DEC_K ? 3 : 1;
+  const int ptiles = t64 ? h.convp_split * h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT) : h.g.ntiles;
+  const dim3 grid(2 * d.g.N * d.ksplit + ptiles);
   if constexpr (gm_half(MODE)) {
     if (t64) {
       hipLaunchKernelGGL((k_decoder_convp<MODE, true>), grid, dim3(512), 0, s, d, h, P);

@@ -67,8 +67,10 @@ class _CropInfo(C.Structure):
                 ('ratio', (C.c_double * 2) * 2), ('sbox', (C.c_float * 4) * 2)]
 
 
-ABI_VERSION = 2
-WORKSPACE_STATUS_BYTES = 256   # OETR_WORKSPACE_STATUS_BYTES: the status block that opens a workspace
+ABI_VERSION = 3
+# OETR_WORKSPACE_STATUS_BYTES: the block that opens a workspace - status word, the split decoder's
+# call counters and exchange granules; zero it once (oetr_workspace_init), the library owns it after
+WORKSPACE_STATUS_BYTES = 256 + 16 * 5 * 4 * 256 * 8
 EXPORTS = (
     'oetr_last_error', 'oetr_abi_version', 'oetr_create', 'oetr_destroy',
     'oetr_workspace_bytes', 'oetr_forward', 'oetr_forward_stages',
@@ -83,9 +85,11 @@ EXPORTS = (
     'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel',
     'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens',
     'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async',
-    'oetr_set_state_prereduce', 'oetr_set_tail_mode', 'oetr_overlap_frame', 'oetr_read_overlap_image')
+    'oetr_set_state_prereduce', 'oetr_set_tail_mode', 'oetr_set_decoder_split', 'oetr_overlap_frame', 'oetr_read_overlap_image')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
+FLAG_EXCHANGE = 2    # OETR_FLAG_EXCHANGE: the split decoder's workgroups were not resident together
+FLAG_INVALID = FLAG_F16_RANGE | FLAG_EXCHANGE   # either bit: that call's outputs are invalid
 
 
 def hot_path_keys():
@@ -195,6 +199,8 @@ def load_library(path=None):
     lib.oetr_set_state_prereduce.argtypes = [vp, i]
     lib.oetr_set_tail_mode.restype = i
     lib.oetr_set_tail_mode.argtypes = [vp, i]
+    lib.oetr_set_decoder_split.restype = i
+    lib.oetr_set_decoder_split.argtypes = [vp, i]
     lib.oetr_neck_create.restype = i
     lib.oetr_neck_create.argtypes = [C.POINTER(_NeckWeights), i, C.POINTER(vp)]
     lib.oetr_neck_destroy.restype = None
@@ -501,6 +507,12 @@ class HotPathEngine:
         2 'direct form' (decoder, then the 64-row conv with the taps accumulated in registers, no P
         buffer: large batches; two-plane precisions only)."""
         _check(self.lib, self.lib.oetr_set_tail_mode(self._h, int(mode)), 'oetr_set_tail_mode')
+
+    def set_decoder_split(self, k):
+        """``oetr_set_decoder_split``: workgroups per image of the decoder chain - 0 automatic (4
+        while 2N x 4 workgroups take at most a quarter of the CUs, else 1), 1, or 4 (four
+        workgroups exchange five 256-float all-reduces per image inside the launch)."""
+        _check(self.lib, self.lib.oetr_set_decoder_split(self._h, int(k)), 'oetr_set_decoder_split')
 
     def query_flags(self, clear=True):
         """Status word of the CURRENT STREAM's workspace (``oetr_query_flags``): synchronises

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from . import losses
 
 from .backbone import PatchMerging, PositionEncodingSine, ResnetEncoder
-from .hip_engine import (FLAG_F16_RANGE, HotPathEngine, NeckEngine, OetrRangeError,
+from .hip_engine import (FLAG_F16_RANGE, FLAG_INVALID, HotPathEngine, NeckEngine, OetrRangeError,
                          hot_path_keys, neck_keys)
 
 
@@ -173,7 +173,7 @@ class OETR(nn.Module):
         if self.hip_neck and x.is_cuda:
             eng = self.neck_engine()
             feat = eng.forward(x)
-            if self.hip_on_overflow != 'ignore' and eng.query_flags() & FLAG_F16_RANGE:
+            if self.hip_on_overflow != 'ignore' and eng.query_flags() & FLAG_INVALID:
                 if self.hip_on_overflow == 'raise':
                     raise OetrRangeError('backbone features exceed the f16 range of the HIP neck')
                 return self._neck_torch(x)      # exact fp32 route (torch/MIOpen)
@@ -266,6 +266,8 @@ class OETR(nn.Module):
                                          precision=self.hip_precision,
                                          enc_tile=self.hip_enc_tile,
                                          attention=self.hip_attention)
+            if self.hip_precision == 'f32':     # no status check on this route: wait for nobody
+                self._engine.set_decoder_split(1)
             self._engine_key = key
         return self._engine
 
@@ -278,6 +280,7 @@ class OETR(nn.Module):
         if self._engine_f32 is None:
             self._engine_f32 = HotPathEngine(self.hot_path_state(), device=main.device,
                                              precision='f32', attention=self.hip_attention)
+            self._engine_f32.set_decoder_split(1)    # the re-run route waits for nobody (FLAG_EXCHANGE)
         return self._engine_f32
 
     def neck_engine(self):
@@ -399,7 +402,7 @@ class OETR(nn.Module):
         nodes writing pinned host words): call after synchronising a replay.  A captured batch
         cannot be re-run from here, so a tripped word raises ``OetrRangeError`` whatever
         ``hip_on_overflow`` says (except 'ignore': nothing was captured)."""
-        tripped = any(t.value() & FLAG_F16_RANGE for t in self._graph_tickets)
+        tripped = any(t.value() & FLAG_INVALID for t in self._graph_tickets)
         if tripped:
             raise OetrRangeError('a batch replayed from a HIP graph overflowed the f16 operand range: '
                                  're-submit it eagerly (exact-fp32 re-run) or use hip_precision "f32"')
@@ -413,7 +416,7 @@ class OETR(nn.Module):
         self._graph_tickets = []
 
     def _settle(self, boxes, tickets, rerun):
-        if not any(t.value() & FLAG_F16_RANGE for t in tickets):
+        if not any(t.value() & FLAG_INVALID for t in tickets):
             return boxes
         good = rerun()              # raises under hip_on_overflow == 'raise'
         for dst, src in zip(boxes, good):
@@ -453,7 +456,7 @@ class OETR(nn.Module):
         """Immediate (synchronising) form: the re-run route of a tripped fused batch."""
         eng = self.engine()
         boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2)
-        if eng.precision in eng.F16_RANGE and eng.query_flags() & FLAG_F16_RANGE:
+        if eng.precision in eng.F16_RANGE and eng.query_flags() & FLAG_INVALID:
             boxes = self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2)
         return boxes
 
@@ -485,7 +488,7 @@ class OETR(nn.Module):
             eng = self.engine()
             st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True)
             if self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE \
-                    and eng.query_flags() & FLAG_F16_RANGE:
+                    and eng.query_flags() & FLAG_INVALID:
                 if self.hip_on_overflow == 'raise':
                     raise OetrRangeError('a GEMM operand reached |x| >= 65504; use hip_precision "f32"')
                 eng = self.exact_engine()

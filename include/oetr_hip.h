@@ -38,8 +38,11 @@ extern "C" {
 
 /* 2: the status word moved from the handle into the workspace (oetr_query_flags takes the
  *    workspace; oetr_workspace_init, oetr_read_flags_async are new), oetr_linear_attention takes
- *    a workspace, OETR_DTYPE_F32_SPLIT_QK16 */
-#define OETR_ABI_VERSION 2
+ *    a workspace, OETR_DTYPE_F32_SPLIT_QK16
+ * 3: the status block of a workspace grew from 256 bytes to OETR_WORKSPACE_STATUS_BYTES (the split
+ *    decoder's call counters and exchange granules live there: oetr_set_decoder_split);
+ *    OETR_FLAG_EXCHANGE */
+#define OETR_ABI_VERSION 3
 #define OETR_D_MODEL 256
 #define OETR_N_HEAD 8
 #define OETR_N_ENC 8 /* self,cross x4  - reference src/models/transformer.py:295 */
@@ -172,8 +175,17 @@ void oetr_destroy(oetr_handle h);
  *                        largest f16, and is handled exactly by the split).  The outputs of
  *                        that call are INVALID.  Re-run
  *                        with a handle created as OETR_DTYPE_F32 or OETR_DTYPE_BF16.
+ *   OETR_FLAG_EXCHANGE   the four workgroups of an image's decoder chain (oetr_set_decoder_split)
+ *                        did not all become resident within 2 ms - more forwards in flight on
+ *                        the device than the automatic rule allows for, or a forced split on a
+ *                        busy device.  The outputs of that call are INVALID.  Re-run with
+ *                        oetr_set_decoder_split(h, 1).
  * oetr_workspace_init   zeroes the status block (enqueued on `stream`); call it once after
- *                       allocating a workspace (or zero the first 256 bytes yourself).
+ *                       allocating a workspace (or zero the first OETR_WORKSPACE_STATUS_BYTES
+ *                       yourself).  Besides the status word the block holds the split decoder's
+ *                       per-image call counters (words 16..31) and its exchange granules (from
+ *                       byte 256: [16 images][5 exchanges][4 workgroups][256] x 8 bytes): they must
+ *                       start from zero and are the library's from then on.
  * oetr_query_flags      copies the word to *flags (host), optionally clears it, and
  *                       SYNCHRONISES `stream` (the one call of this library that does):
  *                       ordered after every forward call enqueued on that stream before.
@@ -186,7 +198,8 @@ void oetr_destroy(oetr_handle h);
  * Weights are range-checked by oetr_create (OETR_ERR_UNSUPPORTED).  Nothing like this exists
  * in the fp32 reference; it guards the reduced-range operand formats. */
 #define OETR_FLAG_F16_RANGE 1u
-#define OETR_WORKSPACE_STATUS_BYTES 256
+#define OETR_FLAG_EXCHANGE 2u
+#define OETR_WORKSPACE_STATUS_BYTES (256 + 16 * 5 * 4 * 256 * 8)
 oetr_status oetr_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 oetr_status oetr_query_flags(oetr_handle h, void *workspace, void *stream,
                              uint32_t *flags, int clear);
@@ -226,6 +239,20 @@ oetr_status oetr_set_state_prereduce(oetr_handle h, int on);
  * summation order (the nine taps are summed in the MFMA accumulator instead of in k_heat_combine).
  * Mutates the handle like the other setters. */
 oetr_status oetr_set_tail_mode(oetr_handle h, int mode);
+
+/* Workgroups per image of the single-query decoder chain (TransformerDecoder, reference
+ * src/models/transformer.py:224-284: nine 256-wide GEMV stages per image, latency bound: one CU
+ * streams an image's 3.9 MB of fp32 weights at its L1 fill rate).  4: four workgroups per image -
+ * each streams a quarter of every stage's weights, the stages alternate between a split of the
+ * outputs and a split of the inputs, and five 256-float all-reduces per image travel between the
+ * four workgroups INSIDE the launch as tagged 8-byte granules in the workspace's status block
+ * (no fence, no flag).  The four workgroups wait for each other, so they must be resident together:
+ * automatic (0, default) picks 4 only while 2N x 4 workgroups take at most a quarter of the
+ * device's CUs (N <= 8 on MI355X: up to four forwards in flight on four streams are then safe
+ * whatever the dispatch order) and 1 otherwise; a wait that outlasts 2 ms sets
+ * OETR_FLAG_EXCHANGE instead of hanging.  1: one workgroup per image (rounds 1-3).  Results
+ * differ between 1 and 4 in fp32 summation order only.  Mutates the handle like the other setters. */
+oetr_status oetr_set_decoder_split(oetr_handle h, int workgroups_per_image);
 
 /* Attention core of the eight encoder layers.  The reference builds
  * QueryTransformer(attention_mode='linear') (src/model.py:82-84; the config knob

@@ -116,6 +116,7 @@ def test_module_reruns_an_overflowing_full_attention_batch_in_exact_fp32(gpu):
     b1, b2 = model.boxes_from_features(*dev, (256, 320), (320, 256))
     model.hip_flush()
     exact = pkg.HotPathEngine(w, device=gpu, precision='f32', attention='full')
+    exact.set_decoder_split(1)     # as the module's re-run route (waits for nobody)
     e1, e2 = exact.forward(*dev, (256, 320), (320, 256))
     assert torch.equal(b1, e1) and torch.equal(b2, e2) and torch.isfinite(b1).all()
     assert model._engine_f32 is not None and model._engine_f32.attention == 'full'

@@ -20,16 +20,18 @@ torch.set_grad_enabled(False)
 
 
 def _engine(w, gpu, precision):
-    """'prec' = every size-dependent rule automatic; 'prec@tile' = the encoder tile AND the form of the
-    tail pinned (direct form, what batches of this size run): with the rules pinned a pair's boxes do not
-    depend on the batch around it, bit for bit - the automatic rules (64-row tiles once the grid exceeds
-    the chip, direct tail from 16 000 token rows) trade that for speed and change the fp32 summation
-    order only."""
+    """'prec' = every size-dependent rule automatic; 'prec@tile' = the encoder tile, the form of the
+    tail (direct form, what batches of this size run) AND the decoder's workgroups per image pinned:
+    with the rules pinned a pair's boxes do not depend on the batch around it, bit for bit - the
+    automatic rules (64-row tiles once the grid exceeds the chip, direct tail from 16 000 token rows,
+    four decoder workgroups per image up to 8 pairs) trade that for speed and change the fp32
+    summation order only."""
     from imagematching_oetr_amd import HotPathEngine
     prec, _, tile = precision.partition('@')
     eng = HotPathEngine(w, device=gpu, precision=prec, enc_tile=int(tile) if tile else None)
     if tile:
         eng.set_tail_mode(2)
+        eng.set_decoder_split(1)
     return eng
 
 

@@ -40,11 +40,25 @@ def model():
                           ('f32_split_f16', 64, 100, 'full', 0),     # (tile request ignored by the all-pairs mode: 32 rows)
                           ('f32', 32, 20, 'full', 0)])
 def test_forward_is_a_function_of_its_inputs(model, precision, tile, rounds, attention, prereduce):
+    _interleaved(model, precision, tile, rounds, attention, prereduce, 0)
+
+
+@pytest.mark.parametrize('split', [1, 4])
+def test_forward_is_a_function_of_its_inputs_decoder_split(model, split):
+    """The decoder chain pinned to one workgroup per image (rounds 1-3) and to four (round 4: in-launch
+    all-reduces as tagged granules - every workgroup adds the four partials in the same order); the
+    automatic rule, which the cases above run, picks four for these batch sizes."""
+    _interleaved(model, 'f32_split_f16', 64, 150, 'linear', 0, split)
+
+
+def _interleaved(model, precision, tile, rounds, attention, prereduce, split):
     dev = torch.device('cuda', 0)
     eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision=precision, enc_tile=tile,
                             attention=attention)
     if prereduce:
         eng.set_state_prereduce(prereduce)
+    if split:
+        eng.set_decoder_split(split)
     gen = torch.Generator().manual_seed(1)
     cases = []
     for n, h1, w1, h2, w2 in SHAPES:
@@ -67,6 +81,7 @@ def test_forward_is_a_function_of_its_inputs(model, precision, tile, rounds, att
             if bad:
                 differing.append((rnd, SHAPES[ci], bad, float((out['box1'] - refs[ci]['box1']).abs().max())))
     assert not differing, f'{len(differing)} of {runs} forwards differ from the first of their shape: {differing[:5]}'
+    assert eng.query_flags() == 0
 
 
 def test_neck_is_a_function_of_its_inputs():

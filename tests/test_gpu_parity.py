@@ -491,3 +491,74 @@ def test_direct_tail_edge_grids(gpu):
             assert maxerr(out['logits' + s], ref['logits' + s]) <= TOL['logits'], (h1, w1, h2, w2, s)
             assert maxerr(out['cxy' + s], ref['cxy' + s]) <= TOL['cxy'], (h1, w1, h2, w2, s)
             assert maxerr(out['box' + s], ref['box' + s]) <= TOL['box'], (h1, w1, h2, w2, s)
+
+
+@pytest.mark.parametrize('precision', ['f32_split_f16', 'f32'])
+@pytest.mark.parametrize('path', HOT, ids=lambda p: p.split('hot_')[-1][:-4])
+def test_decoder_split_forms_match_the_goldens(path, precision, gpu):
+    """``oetr_set_decoder_split``: the decoder chain on one workgroup per image and on four (quarter
+    of every stage's weights each, five in-launch all-reduces as tagged granules) give the reference's
+    hs and boxes within the golden tolerances, agree with each other to fp32 summation order, leave
+    the status word clean; the automatic rule picks four for these batch sizes."""
+    from imagematching_oetr_amd import HotPathEngine
+    from tests.test_oracle_golden import load_hot_case
+    g, w, f1, f2 = load_hot_case(path)
+    im1, im2 = tuple(int(v) for v in g['img1']), tuple(int(v) for v in g['img2'])
+    dev = [t.to(gpu) for t in (f1, f2, orc.position_table(*g['grid1']), orc.position_table(*g['grid2']))]
+    eng = HotPathEngine(orc.make_hot_weights(int(g['weight_seed']), sharpen=bool(g['sharpen'])), device=gpu,
+                        precision=precision)
+    outs = {}
+    for k in (0, 1, 4):
+        eng.set_decoder_split(k)
+        for _ in range(3):          # repeated calls: the granules' tags advance per call
+            outs[k] = eng.forward(*dev, im1, im2, stages=True)
+        assert eng.query_flags() == 0
+        for s in ('1', '2'):
+            assert maxerr(outs[k]['hs' + s], g['hs' + s]) <= TOL['hs'], (k, s)
+            assert maxerr(outs[k]['box' + s], g['box' + s]) <= TOL['box'], (k, s)
+    for s in ('1', '2'):
+        assert torch.equal(outs[0]['hs' + s], outs[4]['hs' + s])       # auto = four at these sizes
+        assert maxerr(outs[1]['hs' + s], outs[4]['hs' + s]) <= 0.1 * TOL['hs']
+        assert maxerr(outs[1]['box' + s], outs[4]['box' + s]) <= 0.2 * TOL['box']
+    with pytest.raises(Exception):
+        eng.set_decoder_split(2)
+
+
+def test_split_decoder_on_concurrent_streams(gpu):
+    """Four forwards in flight on four streams (what the automatic rule allows for): the exchanging
+    workgroups of all of them are resident together - every batch returns the serial boxes bit for bit
+    and no status word carries OETR_FLAG_EXCHANGE.  Also a shape change in between (tags are per image
+    slot, not per shape) and a batch too large for the split (falls back to one workgroup per image)."""
+    from imagematching_oetr_amd import HotPathEngine
+    w = orc.make_hot_weights(5, sharpen=True)
+    eng = HotPathEngine(w, device=gpu)
+    cases = []
+    for n, hf in ((8, 20), (3, 13), (8, 20)):
+        f1, f2 = orc.make_features(91, n, hf, hf).to(gpu), orc.make_features(92, n, hf, hf).to(gpu)
+        p = orc.position_table(hf, hf).to(gpu)
+        cases.append((f1, f2, p, p, (hf * 32, hf * 32), (hf * 32, hf * 32)))
+    refs = [[t.clone() for t in eng.forward(*c)] for c in cases]
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(4)]
+    torch.cuda.synchronize()
+    bad = 0
+    for rnd in range(40):
+        outs = []
+        for si, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                ci = (rnd + si) % len(cases)
+                outs.append((ci, eng.forward(*cases[ci])))
+        for s, (ci, o) in zip(streams, outs):
+            s.synchronize()
+            bad += int(not (torch.equal(o[0], refs[ci][0]) and torch.equal(o[1], refs[ci][1])))
+    flags = 0
+    for s in streams:
+        with torch.cuda.stream(s):
+            flags |= eng.query_flags()
+    assert bad == 0 and flags == 0, (bad, flags)
+    # 12 pairs = 24 images > 16: the split form does not apply, forcing it is ignored
+    f1, f2 = orc.make_features(93, 12, 10, 10).to(gpu), orc.make_features(94, 12, 10, 10).to(gpu)
+    p = orc.position_table(10, 10).to(gpu)
+    a = eng.forward(f1, f2, p, p, (320, 320), (320, 320), stages=True)
+    eng.set_decoder_split(4)
+    b = eng.forward(f1, f2, p, p, (320, 320), (320, 320), stages=True)
+    assert torch.equal(a['hs1'], b['hs1']) and torch.equal(a['box2'], b['box2']) and eng.query_flags() == 0

@@ -306,6 +306,7 @@ def test_module_reruns_an_overflowing_batch_in_exact_fp32(gpu, defer):
         assert model._pending is not None
         model.hip_flush()
     exact = pkg.HotPathEngine(w, device=gpu, precision='f32')
+    exact.set_decoder_split(1)     # as the module's re-run route (waits for nobody)
     e1, e2 = exact.forward(*dev, (256, 320), (320, 256))
     assert torch.equal(b1, e1) and torch.equal(b2, e2) and torch.isfinite(b1).all()
     # ... which is NOT what the overflowing default mode produced
@@ -339,6 +340,7 @@ def test_deferred_check_settles_one_call_later(gpu):
     ok1, ok2 = model.boxes_from_features(*good, (256, 320), (320, 256))       # settles the first
     assert model._engine_f32 is not None
     exact = pkg.HotPathEngine(w, device=gpu, precision='f32')
+    exact.set_decoder_split(1)     # as the module's re-run route (waits for nobody)
     e1, e2 = exact.forward(*dev, (256, 320), (320, 256))
     assert torch.equal(bad1, e1) and torch.equal(bad2, e2)
     model.hip_flush()

@@ -26,6 +26,8 @@ for name in names:
                                       enc_tile=int(os.environ.get('TILE', 0)) or None)
 if os.environ.get('TAILMODE'):
     for e in engines.values(): e.set_tail_mode(int(os.environ['TAILMODE']))
+if os.environ.get('DECSPLIT'):
+    for e in engines.values(): e.set_decoder_split(int(os.environ['DECSPLIT']))
 if os.environ.get('PREREDUCE'):
     for e in engines.values(): e.set_state_prereduce(int(os.environ['PREREDUCE']))
 hw = (hf * 32, hf * 32)
