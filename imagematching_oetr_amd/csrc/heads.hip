@@ -8,10 +8,12 @@
 //                (9 taps x [32 tok x 256] . [256 x 256] on f32 MFMA, the tap
 //                tile gathered+scaled on the fly, double-buffered in LDS),
 //                + bias, per-tile GroupNorm partial moments.
-//  k_heat_final: one workgroup per image: combine the GroupNorm moments
-//                (Chan), normalise + ReLU + 1x1 conv -> logits, softmax over
-//                the image's tokens, soft-argmax -> centre (x, y).
-//  k_size_reg  : sigmoid(W2 relu(W1 hs) + b2).
+//  k_heat_logits: one workgroup per 32-token tile: combine the image's GroupNorm
+//                moments (Chan), normalise + ReLU + 1x1 conv -> logits.
+//  k_heat_final: one workgroup per image: softmax over the image's tokens,
+//                soft-argmax -> centre (x, y); forward path: + box from tlbr.
+//  size_reg_body / k_size_reg: sigmoid(W2 relu(W1 hs) + b2) - on the forward path as
+//                extra workgroups of the launch behind the decoder.
 //  k_boxes     : centre -+ extents, clamped to the image.
 #include "common.h"
 
@@ -195,6 +197,49 @@ hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s) {
 // other of two plane regions while this tap's GEMM runs; every weight fragment feeds two MFMA row
 // tiles (WStream2T), the weight stream runs from tap to tap.  One conv_out tile and the GroupNorm
 // moments of its two 32-row slots leave the workgroup - no P.
+// Size regression of one image (reference src/model.py:188-191: sigmoid(W2 relu(W1 hs) + b2)), 512
+// threads: the forward path runs it as 2N extra workgroups of the launch that follows the decoder
+// (k_heat_combine / k_heat_conv64 / k_heat_conv64h) - it needs hs only, and inside k_heat_final it
+// was 4.6 us of that one-workgroup-per-image kernel's serial chain.  tlbr -> p.tlbr[side][4 n ..].
+__device__ __forceinline__ void size_reg_body(const HeatLaunch& p, int img, float* smem) {
+  float *h_s = smem, *hid_part = smem + C, *hid_s = smem + 3 * C;
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int side = img >= g.N, n = side ? img - g.N : img;
+  const int kc = tid >> 8, o = tid & (C - 1);
+  const float* wsrc = p.w.tlbr0_t + (size_t)(kc * 128) * C + o;
+  float wv[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) wv[k] = wsrc[(size_t)k * C];
+  if (tid < C) h_s[tid] = p.hs[side][(size_t)n * C + tid];
+  __syncthreads();
+  float a = 0.f;
+#pragma unroll
+  for (int k0 = 0; k0 < 128; k0 += 32) {
+    float wn[32];
+    if (k0 + 32 < 128) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wn[k] = wsrc[(size_t)(k0 + 32 + k) * C];
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a += wv[k] * h_s[kc * 128 + k0 + k];
+    if (k0 + 32 < 128) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wv[k] = wn[k];
+    }
+  }
+  hid_part[kc * C + o] = a;
+  __syncthreads();
+  if (tid < C) hid_s[tid] = fmaxf(hid_part[tid] + hid_part[C + tid], 0.f);
+  __syncthreads();
+  if (wave < 4) {
+    const f32x4 w2 = reinterpret_cast<const f32x4*>(p.w.tlbr2_w + wave * C)[lane];
+    const f32x4 hv = reinterpret_cast<const f32x4*>(hid_s)[lane];
+    const float d = wave_sum((w2[0] * hv[0] + w2[1] * hv[1]) + (w2[2] * hv[2] + w2[3] * hv[3]));
+    if (lane == 0) p.tlbr[side][4 * n + wave] = 1.0f / (1.0f + expf(-(d + p.w.tlbr2_b[wave])));
+  }
+}
+
 // conv output + per-(32-row slot, group) moments for GroupNorm of a 64-row tile's accumulators
 __device__ __forceinline__ void heat_conv64_finish(const HeatLaunch& p, const f32x16 (&acc)[2], const Geom& g, int side, int n,
                                                    int t_idx, int nvalid, size_t row_base, int lane, int wave, int half, int col) {
@@ -511,6 +556,7 @@ __global__ __launch_bounds__(512) void k_heat_conv64(HeatLaunch p) {
   __shared__ float attmax_s[512 / 64];
   const Geom& g = p.g;
   const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
+  if ((int)blockIdx.x >= g.N * (nt0 + nt1)) return size_reg_body(p, blockIdx.x - g.N * (nt0 + nt1), smem);
   const int logical = xcd_remap(blockIdx.x, g.N * (nt0 + nt1));
   const int rem = logical - (logical / (nt0 + nt1)) * (nt0 + nt1);
   const int side = rem >= nt0;
@@ -528,6 +574,8 @@ __global__ __launch_bounds__(512) void k_heat_conv64h(HeatLaunch p) {
   __shared__ float attmax_s[512 / 64];
   const Geom& g = p.g;
   const int nt0 = (g.L[0] + RT - 1) / RT, nt1 = (g.L[1] + RT - 1) / RT;
+  if ((int)blockIdx.x >= g.N * (nt0 + nt1))
+    return size_reg_body(p, blockIdx.x - g.N * (nt0 + nt1), reinterpret_cast<float*>(planes));
   const int logical = xcd_remap(blockIdx.x, g.N * (nt0 + nt1));
   const int rem = logical - (logical / (nt0 + nt1)) * (nt0 + nt1);
   const int side = rem >= nt0;
@@ -541,10 +589,11 @@ hipError_t launch_heat_conv64(const HeatLaunch& p, int mode, hipStream_t s) {
   if (mode != GM_SPLIT) return hipErrorInvalidValue;
   const int tiles = p.g.N * ((p.g.L[0] + RT - 1) / RT + (p.g.L[1] + RT - 1) / RT);
   // halo-resident form while both token grids are at most HALO_MAX_WF wide (its LDS holds 64 + 2 wf + 2 rows)
+  // + one size-regression workgroup per image behind the tiles (size_reg_body)
   if (p.g.wf[0] <= HALO_MAX_WF && p.g.wf[1] <= HALO_MAX_WF && !p.force_staged_conv)
-    hipLaunchKernelGGL((k_heat_conv64h<GM_SPLIT>), dim3(tiles), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((k_heat_conv64h<GM_SPLIT>), dim3(tiles + 2 * p.g.N), dim3(512), 0, s, p);
   else
-    hipLaunchKernelGGL((k_heat_conv64<GM_SPLIT>), dim3(tiles), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((k_heat_conv64<GM_SPLIT>), dim3(tiles + 2 * p.g.N), dim3(512), 0, s, p);
   return hipGetLastError();
 }
 
@@ -557,6 +606,7 @@ __global__ __launch_bounds__(512) void k_heat_combine(HeatLaunch p, const float*
   __shared__ float att_s[TM + 2 * (100 + 1) + 6];
   const Geom& g = p.g;
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= g.ntiles) return size_reg_body(p, blockIdx.x - g.ntiles, out_s);
   const int logical = xcd_remap(blockIdx.x, g.ntiles);
   const int per = g.nt[0] + g.nt[1];
   const int n = logical / per;
@@ -650,7 +700,7 @@ __global__ __launch_bounds__(512) void k_heat_combine(HeatLaunch p, const float*
 }
 
 hipError_t launch_heat_combine(const HeatLaunch& h, const float* P, hipStream_t s) {
-  hipLaunchKernelGGL(k_heat_combine, dim3(h.g.ntiles), dim3(512), 0, s, h, P);
+  hipLaunchKernelGGL(k_heat_combine, dim3(h.g.ntiles + 2 * h.g.N), dim3(512), 0, s, h, P);   // + size regression per image
   return hipGetLastError();
 }
 
@@ -668,74 +718,102 @@ __device__ __forceinline__ float block_reduce(float v, float* red_s, int tid, bo
   return r;
 }
 
-__global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
-  __shared__ float logit_s[MAX_TOKENS];
+// GroupNorm + ReLU + 1x1 conv -> logits of one 32-token tile (reference src/model.py:65-77, :165-168).
+// One workgroup per TILE (round 4; rounds 1-3 ran this inside k_heat_final, one workgroup per IMAGE:
+// 400 KB of conv_out through one CU in seven dependent passes = 9 of that kernel's 18.8 us at 400
+// tokens, 16 of 26.8 at 1024).  Every workgroup folds its image's per-tile moments itself (Chan et al.,
+// 16 interleaved chunks of tiles per group, then the 16 partial results in chunk order - the same
+// arithmetic in every workgroup of the image); its own rows are in flight meanwhile.
+__global__ __launch_bounds__(512) void k_heat_logits(HeatLaunch p) {
+  __shared__ float fold_s[16 * GN_GROUPS * 3];
   __shared__ float gmean_s[GN_GROUPS], grstd_s[GN_GROUPS];
-  __shared__ float red_s[FIN_THREADS / 64];
   const Geom& g = p.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int img = blockIdx.x;
-  const int side = img >= g.N, n = side ? img - g.N : img;
-  const int L = g.L[side], wf = g.wf[side], nts = g.nt[side];
+  const int tid = threadIdx.x;
+  const int logical = xcd_remap(blockIdx.x, g.ntiles);
+  const int per = g.nt[0] + g.nt[1];
+  const int n = logical / per;
+  const int rem = logical - n * per;
+  const int side = rem >= g.nt[0];
+  const int t_idx = side ? rem - g.nt[0] : rem;
+  const int L = g.L[side], nts = g.nt[side];
   const int slot0 = g.tile0[side] + n * nts;
   const size_t row0 = (size_t)g.row0[side] + (size_t)n * L;
-
-  // Chan et al. combination of (count, mean, M2) over the tiles, per group.  The
-  // partials are fetched first (one thread per (tile, group) pair, all loads in
-  // flight together), then 32 threads fold them in tile order.
-  __shared__ float gnp_s[320 * GN_GROUPS * 2];  // up to 313 tiles (100x100 tokens)
-  for (int i = tid; i < nts * GN_GROUPS * 2; i += FIN_THREADS)
-    gnp_s[i] = p.gn_part[(size_t)slot0 * GN_GROUPS * 2 + i];
-  __syncthreads();
-  if (tid < GN_GROUPS) {
+  const int part = tid & 15, l = t_idx * TM + (tid >> 4);
+  const f32x4* row = reinterpret_cast<const f32x4*>(p.conv_out + (row0 + min(l, L - 1)) * C) + part;
+  f32x4 v[4], gw[4], gb[4], ow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = row[i * 16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f4 = i * 16 + part;  // float4 index -> channels 4*f4 .. 4*f4+3, group f4 >> 1
+    gw[i] = reinterpret_cast<const f32x4*>(p.w.gn_w)[f4];
+    gb[i] = reinterpret_cast<const f32x4*>(p.w.gn_b)[f4];
+    ow[i] = reinterpret_cast<const f32x4*>(p.w.out_w)[f4];
+  }
+  {
+    const int grp = tid & 31, ch = tid >> 5;
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int ti = 0; ti < nts; ++ti) {
+    for (int ti = ch; ti < nts; ti += 16) {
       const float nb = 8.f * (float)min(TM, L - ti * TM);
-      const float mb = gnp_s[(ti * GN_GROUPS + tid) * 2], m2b = gnp_s[(ti * GN_GROUPS + tid) * 2 + 1];
+      const float* src = p.gn_part + ((size_t)(slot0 + ti) * GN_GROUPS + grp) * 2;
+      const float mb = src[0], m2b = src[1];
       const float tot = cnt + nb, delta = mb - mean;
       mean += delta * (nb / tot);
       m2 += m2b + delta * delta * (cnt * nb / tot);
       cnt = tot;
     }
+    float* dst = fold_s + (ch * GN_GROUPS + grp) * 3;
+    dst[0] = cnt; dst[1] = mean; dst[2] = m2;
+  }
+  __syncthreads();
+  if (tid < GN_GROUPS) {
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int ch = 0; ch < 16; ++ch) {
+      const float* src = fold_s + (ch * GN_GROUPS + tid) * 3;
+      const float nb = src[0];
+      if (nb > 0.f) {
+        const float tot = cnt + nb, delta = src[1] - mean;
+        mean += delta * (nb / tot);
+        m2 += src[2] + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+      }
+    }
     gmean_s[tid] = mean;
     grstd_s[tid] = 1.0f / sqrtf(m2 / cnt + GN_EPS);
   }
   __syncthreads();
-
-  {  // logits: 16 threads per token row (64 rows per pass), DPP row sums
-    const int part = tid & 15, rsub = tid >> 4;
-    f32x4 gw[4], gb[4], ow[4];
-    float mu[4], rs[4];
+  float d = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f4 = i * 16 + part;  // float4 index -> channels 4*f4 .. 4*f4+3, group f4 >> 1
-      gw[i] = reinterpret_cast<const f32x4*>(p.w.gn_w)[f4];
-      gb[i] = reinterpret_cast<const f32x4*>(p.w.gn_b)[f4];
-      ow[i] = reinterpret_cast<const f32x4*>(p.w.out_w)[f4];
-      mu[i] = gmean_s[f4 >> 1];
-      rs[i] = grstd_s[f4 >> 1];
-    }
-    const float ob = p.w.out_b[0];
-    for (int l0 = 0; l0 < L; l0 += FIN_THREADS / 16) {
-      const int l = l0 + rsub;
-      const f32x4* row = reinterpret_cast<const f32x4*>(p.conv_out + (row0 + min(l, L - 1)) * C) + part;
-      float d = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int grp = (i * 16 + part) >> 1;
+    const f32x4 y = (v[i] - gmean_s[grp]) * grstd_s[grp] * gw[i] + gb[i];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 y = (row[i * 16] - mu[i]) * rs[i] * gw[i] + gb[i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d += fmaxf(y[j], 0.f) * ow[i][j];
-      }
-      d = sum8(d);
-      d += dpp_mov<0x140>(d);  // row_mirror: the other 8 lanes of the 16
-      if (part == 0 && l < L) { logit_s[l] = d + ob; p.logits[row0 + l] = d + ob; }
-    }
+    for (int j = 0; j < 4; ++j) d += fmaxf(y[j], 0.f) * ow[i][j];
   }
-  __syncthreads();
+  d = sum8(d);
+  d += dpp_mov<0x140>(d);  // row_mirror: the other 8 lanes of the 16
+  if (part == 0 && l < L) p.logits[row0 + l] = d + p.w.out_b[0];
+}
 
-  // softmax over the image's tokens + soft-argmax (model.py:173-184)
+// Softmax over an image's logits, soft-argmax -> centre (reference src/model.py:173-184); on the
+// forward path also the box from the size regression's tlbr (model.py:188-191, models/utils.py:16-28).
+__global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
+  __shared__ float logit_s[MAX_TOKENS];
+  __shared__ float red_s[FIN_THREADS / 64];
+  const Geom& g = p.g;
+  const int tid = threadIdx.x;
+  const int img = blockIdx.x;
+  const int side = img >= g.N, n = side ? img - g.N : img;
+  const int L = g.L[side], wf = g.wf[side];
+  const size_t row0 = (size_t)g.row0[side] + (size_t)n * L;
+  float tl = 0.f;
+  if (p.box[side] && tid < 4) tl = p.tlbr[side][4 * n + tid];
   float mx = -INFINITY;
-  for (int l = tid; l < L; l += FIN_THREADS) mx = fmaxf(mx, logit_s[l]);
+  for (int l = tid; l < L; l += FIN_THREADS) {
+    const float v = p.logits[row0 + l];
+    logit_s[l] = v;
+    mx = fmaxf(mx, v);
+  }
   mx = block_reduce(mx, red_s, tid, true);
   float se = 0.f;
   for (int l = tid; l < L; l += FIN_THREADS) se += expf(logit_s[l] - mx);
@@ -755,35 +833,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
     p.cxy[side][2 * n + 1] = sy;
   }
   if (!p.box[side]) return;
-
-  // ---- fused tail of the forward path: size regression + box (model.py:188-191,
-  // models/utils.py:16-28) for this image, saving two launches.
-  __shared__ float h_s[C], hid_part[4][C], hid_s[C], tl_s[4];
-  if (tid < C) h_s[tid] = p.hs[side][(size_t)n * C + tid];
-  __syncthreads();
-  {
-    const int kc = tid >> 8, o = tid & (C - 1);
-    float a = 0.f;
-#pragma unroll
-    for (int k0 = 0; k0 < 64; k0 += 32) {
-      float wv[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) wv[k] = p.w.tlbr0_t[(kc * 64 + k0 + k) * C + o];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) a += wv[k] * h_s[kc * 64 + k0 + k];
-    }
-    hid_part[kc][o] = a;
-  }
-  __syncthreads();
-  if (tid < C)
-    hid_s[tid] = fmaxf((hid_part[0][tid] + hid_part[1][tid]) + (hid_part[2][tid] + hid_part[3][tid]), 0.f);
-  __syncthreads();
-  if (wave < 4) {
-    const f32x4 wv = reinterpret_cast<const f32x4*>(p.w.tlbr2_w + wave * C)[lane];
-    const f32x4 hv = reinterpret_cast<const f32x4*>(hid_s)[lane];
-    float d = wave_sum((wv[0] * hv[0] + wv[1] * hv[1]) + (wv[2] * hv[2] + wv[3] * hv[3]));
-    if (lane == 0) tl_s[wave] = 1.0f / (1.0f + expf(-(d + p.w.tlbr2_b[wave])));
-  }
+  __shared__ float tl_s[4];
+  if (tid < 4) tl_s[tid] = tl;
   __syncthreads();
   if (tid == 0) {
     const float mh = (float)p.img_h[side], mw = (float)p.img_w[side];
@@ -793,12 +844,11 @@ __global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
     box[1] = fminf(fmaxf(sy - t, 0.f), mh);
     box[2] = fminf(fmaxf(sx + r, 0.f), mw);
     box[3] = fminf(fmaxf(sy + b, 0.f), mh);
-    if (p.tlbr[side])
-      for (int j = 0; j < 4; ++j) p.tlbr[side][4 * n + j] = tl_s[j];
   }
 }
 
 hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_heat_logits, dim3(p.g.ntiles), dim3(512), 0, s, p);
   hipLaunchKernelGGL(k_heat_final, dim3(2 * p.g.N), dim3(FIN_THREADS), 0, s, p);
   return hipGetLastError();
 }
