@@ -115,6 +115,10 @@ def parse_args(argv=None):
     ap.add_argument('--kernel', default=None, choices=[None, 'full_attention'],
                     help='micro-benchmark of one stand-alone kernel instead of the hot path')
     ap.add_argument('--L', type=int, default=1024, help='--kernel full_attention: tokens per image')
+    ap.add_argument('--decoder-split-overlap', type=int, default=0, choices=[0, 1, 4],
+                    help='oetr_set_decoder_split for the overlapped (multi-stream) run (0 = the library rule; A/Bs)')
+    ap.add_argument('--decoder-split', type=int, default=0, choices=[0, 1, 4],
+                    help='oetr_set_decoder_split for the serial run (0 = the library rule; A/Bs)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the short driver-timed regions of BASELINE configs[2] / [3] / [4] (N=1, default '
                          'workload only; about 20 s)')
@@ -730,6 +734,7 @@ def main():
         eng.set_encoder_tile(args.enc_tile)
         warm(eng, 1)
         eng.set_encoder_tile(tile_overlap)
+        eng.set_decoder_split(args.decoder_split_overlap if n_streams > 1 else args.decoder_split)
         warm(eng, n_streams)
         res['overlap'] = repeated(eng, n_streams)            # -> value (no instrumentation)
         if not args.no_trace:
@@ -738,6 +743,7 @@ def main():
             # library's per-kernel HIP events recorded on its launch stream
             res['trace_overlap_shape'] = traced(eng)
         eng.set_encoder_tile(args.enc_tile)
+        eng.set_decoder_split(args.decoder_split)
         res['serial'] = repeated(eng, 1) if n_streams > 1 else res['overlap']
         if not args.no_trace and with_serial_trace and tile_overlap != (args.enc_tile or 0):
             res['trace_serial_shape'] = traced(eng)

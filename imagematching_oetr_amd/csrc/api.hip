@@ -183,7 +183,7 @@ long long* g_tbuf = nullptr;
 #endif
 
 struct Workspace {
-  float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *hs,
+  float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *sm_part, *hs,
       *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *kvr[2], *ksr[2];
   unsigned* red_cnt;   // arrival counters of the in-launch state reduction: [OETR_N_ENC][2N], zeroed per call
   uint32_t* flags;   // the workspace's status word (first 256 bytes: shape-independent position)
@@ -246,6 +246,7 @@ Workspace carve(const Geom& g, void* base, bool attn_full = false) {
   w.dkv1 = take(nt * KV_FLOATS); w.dks1 = take(nt * C);
   w.conv_out = take(rows * C);
   w.gn_part = take(nt * 32 * 2);
+  w.sm_part = take(nt * 4);
   w.hs = take((size_t)2 * g.N * C);
   w.logits = take(rows);
   w.cxy = take((size_t)2 * g.N * 2);
@@ -285,6 +286,7 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.hs[0] = hs1; p.hs[1] = hs2;
   p.conv_out = w.conv_out;
   p.gn_part = w.gn_part;
+  p.sm_part = w.sm_part;
   p.logits = w.logits;
   p.cxy[0] = cxy1; p.cxy[1] = cxy2;
   p.img_h[0] = img_h1; p.img_h[1] = img_h2;
@@ -316,19 +318,34 @@ struct Scoped {
   } while (0)
 
 // Encoder (+ decoder) shared by forward and feature_correlation.
-DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w) {
+DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, bool beside_convp = false) {
   DecLaunch d;
   d.g = encoder_geom(g, encoder_tile_rows(h, g));  // partials are per ENCODER tile
   for (int i = 0; i < 2; ++i) { d.layer[i] = h->dec[i]; d.qe[i] = h->qe[i]; }
   d.tgt1 = h->dec_tgt1; d.qkv1 = h->dec_qkv1;
   d.att0_part = w.att0; d.z0_part = w.z0; d.dkv1 = w.dkv1; d.dks1 = w.dks1;
   d.hs = w.hs;
-  // Four workgroups per image while 2N x 4 of them take at most a quarter of the CUs: the
-  // exchanging workgroups of up to four forwards in flight on one device (one per stream)
-  // are then resident together whatever the dispatch order - they wait for each other
-  // (decoder.hip: exchange_sum).  More images: the chain hides behind the conv GEMMs anyway.
-  const bool fits = 2 * g.N <= DEC_SPLIT_MAX_IMAGES && 2 * g.N * DEC_SPLIT_K * 4 <= h->num_cus;
-  d.ksplit = (h->dec_split == DEC_SPLIT_K || (h->dec_split == 0 && fits)) && 2 * g.N <= DEC_SPLIT_MAX_IMAGES
+  // Four workgroups per image (decoder.hip: decoder_body4) where that shortens the STEP, measured on
+  // MI355X (profiles/r4_decoder_split.txt):
+  //  * the decoder as a launch of its own (direct tail, feature_correlation): the chain is exposed,
+  //    47.6 -> 24.8 us = -3.5 % of a serial step at 8 pairs 640 vs 1280 - taken while the 2N x 4
+  //    workgroups are at most a quarter of the CUs: the exchanging workgroups of up to four forwards
+  //    in flight on one device (one per stream) are then resident together whatever the dispatch
+  //    order - they wait for each other (exchange_sum);
+  //  * beside the conv-P GEMMs (P form): taken while the decoder's workgroups and the conv items
+  //    (three per 64-token tile then, conv_p.h) fit the chip in ONE round: 1 pair 45.5 -> 25.7 us,
+  //    4 pairs 47 -> 27.5, -6...8 % of a serial step.  At 8 pairs @640x640 (400 workgroups) the launch
+  //    does get shorter, 52.5 -> 42.6 us, but the eight encoder launches around it each get 1 us
+  //    LONGER - the busier launch costs the chip its clock - and the step stays where it was
+  //    (358 vs 361 us) while three overlapped streams lose 2.5 %: one workgroup per image there.
+  const int images = 2 * g.N;
+  bool fits = images <= DEC_SPLIT_MAX_IMAGES && images * DEC_SPLIT_K * 4 <= h->num_cus;
+  if (fits && beside_convp) {
+    const int tiles64 = g.N * ((g.L[0] + RT - 1) / RT + (g.L[1] + RT - 1) / RT);
+    const int items = gm_half(h->mode) ? 3 * tiles64 : g.ntiles;
+    fits = images * DEC_SPLIT_K + items <= h->num_cus;
+  }
+  d.ksplit = (h->dec_split == DEC_SPLIT_K || (h->dec_split == 0 && fits)) && images <= DEC_SPLIT_MAX_IMAGES
                  ? DEC_SPLIT_K : 1;
   d.flags = w.flags;
   d.xch_epoch = w.flags + STATUS_EPOCH_WORD;
@@ -765,7 +782,7 @@ oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
     TRACED(h, s, K_DECODER, launch_decoder(dec_launch(h, g, w), s));
     TRACED(h, s, K_HEAT_CONV, launch_heat_conv64(hp, h->mode, s));
   } else {
-    TRACED(h, s, K_DEC_CONVP, launch_decoder_convp(dec_launch(h, g, w), hp, w.convp, h->mode, s));
+    TRACED(h, s, K_DEC_CONVP, launch_decoder_convp(dec_launch(h, g, w, true), hp, w.convp, h->mode, s));
     TRACED(h, s, K_HEAT_COMBINE, launch_heat_combine(hp, w.convp, s));
   }
   TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));  // + size regression + boxes

@@ -1237,6 +1237,7 @@ struct HeatLaunch {
   const float* hs[2];      // per side hs [N][256]
   float* conv_out;         // [rows][256]
   float* gn_part;          // [ntiles][32][2]  (mean, M2) per tile & group
+  float* sm_part;          // [ntiles][4]  (max, sum e, sum e x, sum e y) softmax partials per tile
   float* logits;           // [rows]
   float* cxy[2];           // [N][2] per side
   int img_h[2];

@@ -705,19 +705,6 @@ hipError_t launch_heat_combine(const HeatLaunch& h, const float* P, hipStream_t 
 }
 
 // ---------------------------------------------------------------------------
-constexpr int FIN_THREADS = 1024;
-
-__device__ __forceinline__ float block_reduce(float v, float* red_s, int tid, bool is_max) {
-  v = is_max ? wave_max(v) : wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) red_s[tid >> 6] = v;
-  __syncthreads();
-  float r = red_s[0];
-#pragma unroll
-  for (int i = 1; i < FIN_THREADS / 64; ++i) r = is_max ? fmaxf(r, red_s[i]) : r + red_s[i];
-  return r;
-}
-
 // GroupNorm + ReLU + 1x1 conv -> logits of one 32-token tile (reference src/model.py:65-77, :165-168).
 // One workgroup per TILE (round 4; rounds 1-3 ran this inside k_heat_final, one workgroup per IMAGE:
 // 400 KB of conv_out through one CU in seven dependent passes = 9 of that kernel's 18.8 us at 400
@@ -753,14 +740,23 @@ __global__ __launch_bounds__(512) void k_heat_logits(HeatLaunch p) {
   {
     const int grp = tid & 31, ch = tid >> 5;
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int ti = ch; ti < nts; ti += 16) {
-      const float nb = 8.f * (float)min(TM, L - ti * TM);
-      const float* src = p.gn_part + ((size_t)(slot0 + ti) * GN_GROUPS + grp) * 2;
-      const float mb = src[0], m2b = src[1];
-      const float tot = cnt + nb, delta = mb - mean;
-      mean += delta * (nb / tot);
-      m2 += m2b + delta * delta * (cnt * nb / tot);
-      cnt = tot;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2* src = reinterpret_cast<const f32x2*>(p.gn_part) + (size_t)slot0 * GN_GROUPS + grp;
+    for (int t0 = ch; t0 < nts; t0 += 64) {   // four of this chunk's tiles per round trip
+      f32x2 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = src[(size_t)min(t0 + 16 * u, nts - 1) * GN_GROUPS];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ti = t0 + 16 * u;
+        if (ti < nts) {
+          const float nb = 8.f * (float)min(TM, L - ti * TM);
+          const float tot = cnt + nb, delta = q[u][0] - mean;
+          mean += delta * (nb / tot);
+          m2 += q[u][1] + delta * delta * (cnt * nb / tot);
+          cnt = tot;
+        }
+      }
     }
     float* dst = fold_s + (ch * GN_GROUPS + grp) * 3;
     dst[0] = cnt; dst[1] = mean; dst[2] = m2;
@@ -792,53 +788,70 @@ __global__ __launch_bounds__(512) void k_heat_logits(HeatLaunch p) {
   }
   d = sum8(d);
   d += dpp_mov<0x140>(d);  // row_mirror: the other 8 lanes of the 16
-  if (part == 0 && l < L) p.logits[row0 + l] = d + p.w.out_b[0];
+  d += p.w.out_b[0];
+  __shared__ float logit_s[TM];
+  if (part == 0) {
+    logit_s[tid >> 4] = l < L ? d : -INFINITY;
+    if (l < L) p.logits[row0 + l] = d;
+  }
+  __syncthreads();
+  // this tile's share of the image's softmax / soft-argmax (model.py:173-184), relative to the tile's
+  // own maximum: (max, sum e, sum e x, sum e y) - k_heat_final merges the tiles of an image
+  if (tid < 64) {
+    const int lt = t_idx * TM + (tid & 31);
+    const float v = tid < TM ? logit_s[tid] : -INFINITY;
+    const float m = wave_max(v);
+    const float e = v > -INFINITY ? expf(v - m) : 0.f;
+    const int wf = g.wf[side];
+    const int y = lt / wf, x = lt - y * wf;
+    const float stride = (float)(p.img_h[side] / g.hf[side]);
+    const float se = wave_sum(e);
+    const float sx = wave_sum(e * (((float)x + 0.5f) * stride));
+    const float sy = wave_sum(e * (((float)y + 0.5f) * stride));
+    if (tid == 0) {
+      float* dst = p.sm_part + (size_t)(slot0 + t_idx) * 4;
+      dst[0] = m; dst[1] = se; dst[2] = sx; dst[3] = sy;
+    }
+  }
 }
 
-// Softmax over an image's logits, soft-argmax -> centre (reference src/model.py:173-184); on the
-// forward path also the box from the size regression's tlbr (model.py:188-191, models/utils.py:16-28).
-__global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
-  __shared__ float logit_s[MAX_TOKENS];
-  __shared__ float red_s[FIN_THREADS / 64];
+// Softmax over an image's tokens + soft-argmax -> centre (reference src/model.py:173-184) from the
+// per-tile partials of k_heat_logits (one wave per image: lanes merge their tiles in tile order,
+// then across the wave); on the forward path also the box from the size regression's tlbr
+// (model.py:188-191, models/utils.py:16-28).
+__global__ __launch_bounds__(64) void k_heat_final(HeatLaunch p) {
   const Geom& g = p.g;
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x;
   const int img = blockIdx.x;
   const int side = img >= g.N, n = side ? img - g.N : img;
-  const int L = g.L[side], wf = g.wf[side];
-  const size_t row0 = (size_t)g.row0[side] + (size_t)n * L;
+  const int nts = g.nt[side];
+  const float* part = p.sm_part + (size_t)(g.tile0[side] + n * nts) * 4;
   float tl = 0.f;
-  if (p.box[side] && tid < 4) tl = p.tlbr[side][4 * n + tid];
-  float mx = -INFINITY;
-  for (int l = tid; l < L; l += FIN_THREADS) {
-    const float v = p.logits[row0 + l];
-    logit_s[l] = v;
-    mx = fmaxf(mx, v);
+  if (p.box[side] && lane < 4) tl = p.tlbr[side][4 * n + lane];
+  float m = -INFINITY, se = 0.f, sx = 0.f, sy = 0.f;
+  for (int ti = lane; ti < nts; ti += 64) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(part + 4 * ti);
+    const float mn = fmaxf(m, q[0]);
+    const float a = expf(m - mn), b = expf(q[0] - mn);   // (m = -inf before the first tile: a = 0)
+    se = se * a + q[1] * b;
+    sx = sx * a + q[2] * b;
+    sy = sy * a + q[3] * b;
+    m = mn;
   }
-  mx = block_reduce(mx, red_s, tid, true);
-  float se = 0.f;
-  for (int l = tid; l < L; l += FIN_THREADS) se += expf(logit_s[l] - mx);
-  se = block_reduce(se, red_s, tid, false);
-  const float stride = (float)(p.img_h[side] / g.hf[side]);
-  float sx = 0.f, sy = 0.f;
-  for (int l = tid; l < L; l += FIN_THREADS) {
-    const float pr = expf(logit_s[l] - mx) / se;
-    const int y = l / wf, x = l - y * wf;
-    sx += pr * (((float)x + 0.5f) * stride);
-    sy += pr * (((float)y + 0.5f) * stride);
-  }
-  sx = block_reduce(sx, red_s, tid, false);
-  sy = block_reduce(sy, red_s, tid, false);
-  if (tid == 0) {
+  const float mx = wave_max(m);
+  const float sc = expf(m - mx);                          // lanes without a tile: exp(-inf) = 0
+  se = wave_sum(se * sc);
+  sx = wave_sum(sx * sc) / se;
+  sy = wave_sum(sy * sc) / se;
+  if (lane == 0) {
     p.cxy[side][2 * n] = sx;
     p.cxy[side][2 * n + 1] = sy;
   }
   if (!p.box[side]) return;
-  __shared__ float tl_s[4];
-  if (tid < 4) tl_s[tid] = tl;
-  __syncthreads();
-  if (tid == 0) {
+  const float t0 = __shfl(tl, 0, 64), t1 = __shfl(tl, 1, 64), t2 = __shfl(tl, 2, 64), t3 = __shfl(tl, 3, 64);
+  if (lane == 0) {
     const float mh = (float)p.img_h[side], mw = (float)p.img_w[side];
-    const float t = tl_s[0] * mh, l = tl_s[1] * mw, b = tl_s[2] * mh, r = tl_s[3] * mw;
+    const float t = t0 * mh, l = t1 * mw, b = t2 * mh, r = t3 * mw;
     float* box = p.box[side] + 4 * n;
     box[0] = fminf(fmaxf(sx - l, 0.f), mw);
     box[1] = fminf(fmaxf(sy - t, 0.f), mh);
@@ -849,7 +862,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_heat_final(HeatLaunch p) {
 
 hipError_t launch_heat_final(const HeatLaunch& p, hipStream_t s) {
   hipLaunchKernelGGL(k_heat_logits, dim3(p.g.ntiles), dim3(512), 0, s, p);
-  hipLaunchKernelGGL(k_heat_final, dim3(2 * p.g.N), dim3(FIN_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_heat_final, dim3(2 * p.g.N), dim3(64), 0, s, p);
   return hipGetLastError();
 }
 

@@ -283,8 +283,19 @@ def test_properties_at_bench_size(gpu, engines, precision):
     """N=8, 640x640 (BASELINE configs[1]), both encoder workgroup shapes:
     size-independent properties.  Pairs are independent, so permuting / slicing the
     batch permutes / slices the boxes bit-exactly; swapping the two sides with the
-    query embeddings untouched is NOT symmetric, so only per-side checks are made."""
+    query embeddings untouched is NOT symmetric, so only per-side checks are made.
+    (Bit-exact batch independence holds with the size-dependent rules pinned: the decoder's
+    workgroups per image here - automatic would be 1 at 8 pairs and 4 for the 3-pair slice.)"""
     eng = engines(3, True, precision)
+    for split in (1, 4):
+        eng.set_decoder_split(split)
+        try:
+            _properties_at_bench_size(eng, gpu)
+        finally:
+            eng.set_decoder_split(0)
+
+
+def _properties_at_bench_size(eng, gpu):
     n = 8
     f1, f2 = orc.make_features(41, n, 20, 20).to(gpu), orc.make_features(42, n, 20, 20).to(gpu)
     p = orc.position_table(20, 20).to(gpu)
@@ -499,7 +510,8 @@ def test_decoder_split_forms_match_the_goldens(path, precision, gpu):
     """``oetr_set_decoder_split``: the decoder chain on one workgroup per image and on four (quarter
     of every stage's weights each, five in-launch all-reduces as tagged granules) give the reference's
     hs and boxes within the golden tolerances, agree with each other to fp32 summation order, leave
-    the status word clean; the automatic rule picks four for these batch sizes."""
+    the status word clean; the automatic rule picks four for these batch sizes (decoder workgroups +
+    conv items fit the chip in one round)."""
     from imagematching_oetr_amd import HotPathEngine
     from tests.test_oracle_golden import load_hot_case
     g, w, f1, f2 = load_hot_case(path)
@@ -532,6 +544,7 @@ def test_split_decoder_on_concurrent_streams(gpu):
     from imagematching_oetr_amd import HotPathEngine
     w = orc.make_hot_weights(5, sharpen=True)
     eng = HotPathEngine(w, device=gpu)
+    eng.set_decoder_split(4)     # (the automatic rule keeps 8 pairs @640 on one workgroup per image: forced here)
     cases = []
     for n, hf in ((8, 20), (3, 13), (8, 20)):
         f1, f2 = orc.make_features(91, n, hf, hf).to(gpu), orc.make_features(92, n, hf, hf).to(gpu)
@@ -558,6 +571,7 @@ def test_split_decoder_on_concurrent_streams(gpu):
     # 12 pairs = 24 images > 16: the split form does not apply, forcing it is ignored
     f1, f2 = orc.make_features(93, 12, 10, 10).to(gpu), orc.make_features(94, 12, 10, 10).to(gpu)
     p = orc.position_table(10, 10).to(gpu)
+    eng.set_decoder_split(1)
     a = eng.forward(f1, f2, p, p, (320, 320), (320, 320), stages=True)
     eng.set_decoder_split(4)
     b = eng.forward(f1, f2, p, p, (320, 320), (320, 320), stages=True)
