@@ -22,8 +22,14 @@ for case in range(ncase):
         pr, _, tile = prec.partition('@')
         engines[key] = pkg.HotPathEngine(w, device=dev, precision=pr, enc_tile=int(tile) if tile else None)
     eng = engines[key]
-    n = rng.randrange(1, 6)
-    g1 = (rng.randrange(1, 41), rng.randrange(1, 41))
+    # size-dependent rules: automatic or pinned at random (tail form, decoder workgroups per image, state pre-reduction)
+    tail = rng.choice([0, 0, 1, 2, 3]) if prec != 'f32' else rng.choice([0, 1])
+    split = rng.choice([0, 0, 1, 4])
+    pre = rng.choice([-1, -1, 0, 1, 2])
+    eng.set_tail_mode(tail); eng.set_decoder_split(split); eng.set_state_prereduce(pre)
+    n = rng.randrange(1, 10)
+    big = 61 if rng.random() < 0.15 else 41
+    g1 = (rng.randrange(1, big), rng.randrange(1, big))
     g2 = (rng.randrange(1, 41), rng.randrange(1, 41))
     f1, f2 = orc.make_features(1000 + case, n, *g1), orc.make_features(2000 + case, n, *g2)
     p1, p2 = orc.position_table(*g1), orc.position_table(*g2)
@@ -43,5 +49,8 @@ for case in range(ncase):
             msgs.append(f'iou{s}={iou.tolist()}')
     status = 'OK ' if not msgs else 'BAD'
     bad += bool(msgs)
-    print(f'{status} case {case}: n={n} {g1} {g2} w{wseed}{"s" if sharp else ""} {prec} ' + ' '.join(msgs), flush=True)
+    fl = eng.query_flags()
+    if fl:
+        msgs.append(f'flags={fl}'); status = 'BAD'; bad += 1
+    print(f'{status} case {case}: n={n} {g1} {g2} w{wseed}{"s" if sharp else ""} {prec} tail={tail} split={split} pre={pre} ' + ' '.join(msgs), flush=True)
 print(f'{bad} bad of {ncase}')
