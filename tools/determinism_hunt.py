@@ -20,6 +20,8 @@ if len(sys.argv) > 4:
     hip_engine._lib = hip_engine.load_library(str(REPO / 'tools' / 'variants' / sys.argv[4] / 'liboetr_hip.so'))
 eng = pkg.HotPathEngine(w, device=dev, precision=prec, enc_tile=tile, attention=os.environ.get('HUNT_ATTENTION', 'linear'))
 if os.environ.get('HUNT_PREREDUCE'): eng.set_state_prereduce(int(os.environ['HUNT_PREREDUCE']))
+if os.environ.get('HUNT_DECSPLIT'): eng.set_decoder_split(int(os.environ['HUNT_DECSPLIT']))
+if os.environ.get('HUNT_TAILMODE'): eng.set_tail_mode(int(os.environ['HUNT_TAILMODE']))
 shapes = [(2, 20, 20, 20, 20), (8, 20, 20, 20, 20), (2, 10, 10, 6, 20), (3, 25, 25, 25, 25), (1, 32, 32, 32, 32)]
 if os.environ.get('HUNT_SHAPES'):
     shapes = [shapes[int(i)] for i in os.environ['HUNT_SHAPES'].split(',')]
@@ -35,7 +37,7 @@ def run(c, k=8, fill=''):
     if fill:
         ws = eng._current_ws()
         if ws is not None:
-            body = ws.view(torch.float32)[64:]     # (the status word lives in the first 256 bytes)
+            body = ws.view(torch.float32)[hip_engine.WORKSPACE_STATUS_BYTES // 4:]     # (behind the status block: the library's own)
             if fill == 'zero': body.zero_()
             elif fill == 'nan': body.fill_(float('nan'))
             elif fill == 'big': body.fill_(3.0e4)
