@@ -24,6 +24,8 @@ OETR_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup
 OETR_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --workload mixed --steps 10 --warmup 3 --precision f32_split_qk16 2>> $OUT/bench.err | grep '^{' > $OUT/bench_gloo2_mixed.json
 OETR_BENCH_FORCE_PG=1 timeout 300 python bench.py --workload mixed --steps 10 --warmup 3 --precision f32_split_qk16 2>> $OUT/bench.err | grep '^{' > $OUT/bench_rccl_world1_mixed.json
 timeout 600 python tools/trunk_autocast.py > $OUT/trunk_autocast.txt 2>> $OUT/bench.err
+# decoder chain on one / four workgroups per image: per-kernel events, serial steps, differences, concurrent streams
+timeout 600 python tools/decoder_split_ab.py > $OUT/decoder_split_ab.txt 2>> $OUT/bench.err
 for L in 1024 4096; do
   timeout 200 python bench.py --kernel full_attention --L $L --steps 20 --warmup 3 --repeats 5 > $OUT/full_attention_L$L.json 2>> $OUT/bench.err
 done
