@@ -117,6 +117,11 @@ def parse_args(argv=None):
     ap.add_argument('--L', type=int, default=1024, help='--kernel full_attention: tokens per image')
     ap.add_argument('--decoder-split-overlap', type=int, default=0, choices=[0, 1, 4],
                     help='oetr_set_decoder_split for the overlapped (multi-stream) run (0 = the library rule; A/Bs)')
+    ap.add_argument('--tail-mode-overlap', type=int, default=2, choices=[0, 1, 2, 3],
+                    help='oetr_set_tail_mode for the overlapped (multi-stream) run, two-plane precisions: 2 = direct form '
+                         '(decoder, then the 64-row conv: fewest CU-microseconds - no P buffer, no combine - which is what '
+                         'counts when other streams fill the chip; +2.4 %% at 8 pairs @640x640), 0 = the library rule '
+                         '(latency: P form below 16 000 token rows)')
     ap.add_argument('--decoder-split', type=int, default=0, choices=[0, 1, 4],
                     help='oetr_set_decoder_split for the serial run (0 = the library rule; A/Bs)')
     ap.add_argument('--no-other-configs', action='store_true',
@@ -461,6 +466,7 @@ def other_configs(args, device, pkg):
         L1, L2 = hf * hf, hf2 * hf2
         eff_tile = tile or (64 if n_streams > 1 else 0)     # like `value`: 64-row tiles while batches overlap
         eng.set_encoder_tile(eff_tile)
+        eng.set_tail_mode(args.tail_mode_overlap if n_streams > 1 else 0)   # ... and the direct tail
 
         def region(ns, k):
             torch.cuda.synchronize()
@@ -473,6 +479,7 @@ def other_configs(args, device, pkg):
         region(n_streams, 2)
         over = statistics.median(region(n_streams, steps) for _ in range(5))
         eng.set_encoder_tile(tile)                           # serial: the forced tile, or the library's choice
+        eng.set_tail_mode(0)
         region(1, 2)
         ser = statistics.median(region(1, steps) for _ in range(5))
         eng.set_encoder_tile(eff_tile)
@@ -484,6 +491,7 @@ def other_configs(args, device, pkg):
         rec = {'pairs_per_s': round(n * steps / over, 1), 'ms_per_step': round(over / steps * 1e3, 4),
                'serial_pairs_per_s': round(n * steps / ser, 1), 'steps': steps, 'streams': n_streams,
                'precision': prec, 'encoder_tile_rows': eff_tile or 'auto',
+               'tail_mode_overlapped': args.tail_mode_overlap if n_streams > 1 else 0,
                'hot_path_frac_of_mfma_peak': round(n * steps / over * pair_gflop / 1e3 / (pipe_peak / cost), 4)}
         used_tile = eff_tile or 64      # (auto on one stream picks 64 rows whenever the 32-row grid exceeds the chip)
         rb = roofline_block(kern, prec, n * (L1 + L2), used_tile, steps, t_tr, False, 0, grids=(n, L1, L2))
@@ -735,6 +743,8 @@ def main():
         warm(eng, 1)
         eng.set_encoder_tile(tile_overlap)
         eng.set_decoder_split(args.decoder_split_overlap if n_streams > 1 else args.decoder_split)
+        if n_streams > 1 and half and precision != 'f16' and precision != 'bf16':
+            eng.set_tail_mode(args.tail_mode_overlap)
         warm(eng, n_streams)
         res['overlap'] = repeated(eng, n_streams)            # -> value (no instrumentation)
         if not args.no_trace:
@@ -744,6 +754,8 @@ def main():
             res['trace_overlap_shape'] = traced(eng)
         eng.set_encoder_tile(args.enc_tile)
         eng.set_decoder_split(args.decoder_split)
+        if half and precision != 'f16' and precision != 'bf16':
+            eng.set_tail_mode(0)
         res['serial'] = repeated(eng, 1) if n_streams > 1 else res['overlap']
         if not args.no_trace and with_serial_trace and tile_overlap != (args.enc_tile or 0):
             res['trace_serial_shape'] = traced(eng)
@@ -799,6 +811,9 @@ def main():
                    'pairs_per_gpu': n, 'global_pairs': n_total,
                    'streams': n_streams,
                    'encoder_tile_rows': tile_overlap or 'auto',
+                   'tail_mode': ({0: 'library rule', 1: 'P form', 2: 'direct form (throughput setting for overlapped streams)',
+                                  3: 'direct form, per-tap staging'}[args.tail_mode_overlap]
+                                 if n_streams > 1 and args.precision in ('f32_split_f16', 'f32_split_qk16') else 'library rule'),
                    'tokens_per_image': hf * hf,
                    'parallelism': f'pairs sharded over {world} rank(s); '
                                   'all-gather of boxes only'},
