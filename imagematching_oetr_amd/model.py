@@ -155,6 +155,9 @@ class OETR(nn.Module):
         self.hip_trunk_dtype = None
         #: run the trunk in channels_last memory format (MIOpen's NHWC kernels)
         self.hip_trunk_channels_last = False
+        #: stages of the trunk ('layer0' .. 'layer3') that STAY fp32 under hip_trunk_dtype: the drift of
+        #: an autocast trunk is not spread evenly over the stages (profiles/r4_trunk_autocast.txt)
+        self.hip_trunk_fp32_stages = ()
         self._engine = None
         self._engine_key = None
         self._engine_f32 = None
@@ -195,9 +198,23 @@ class OETR(nn.Module):
         if self.hip_trunk_dtype is None:
             return self.backbone(images).contiguous()
         dt = {'float16': torch.float16, 'bfloat16': torch.bfloat16}[self.hip_trunk_dtype]
-        with torch.autocast('cuda', dtype=dt):
-            out = self.backbone(images)
-        return out.float().contiguous()
+        if not self.hip_trunk_fp32_stages:
+            with torch.autocast('cuda', dtype=dt):
+                out = self.backbone(images)
+            return out.float().contiguous()
+        # stage by stage (the same sequence as ResnetEncoder.forward, reference backbone.py:159-174)
+        bb = self.backbone
+        x = images.permute(0, 3, 1, 2).contiguous()
+        if bb.cfg.NORM_INPUT:
+            x = (x - 0.45) / 0.225
+        stages = ['layer0', 'layer1', 'layer2'] + {'layer3': ['layer3'], 'layer4': ['layer3', 'layer4']}.get(bb.cfg.BACKBONE.LAYER, [])
+        for name in stages:
+            if name in self.hip_trunk_fp32_stages:
+                x = getattr(bb, name)(x.float())
+            else:
+                with torch.autocast('cuda', dtype=dt):
+                    x = getattr(bb, name)(x)
+        return x.float().contiguous()
 
     def feature_extraction(self, image1, image2, mask1=None, mask2=None):
         """Reference ``src/model.py:109-130``.  Same-sized image batches go through
