@@ -13,14 +13,17 @@ def test_trunk_options(gpu):
     torch.manual_seed(0)
     model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval().to(gpu)
     img = torch.rand(2, 128, 160, 3, device=gpu)
+    def close(a, b):      # (MIOpen may pick another convolution algorithm from one call to the next: fp32 rounding only)
+        return float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
     with torch.no_grad():
+        model.trunk(img)
         ref = model.trunk(img)                              # defaults: the reference's fp32 sequence
-        assert torch.equal(ref, model.backbone(img)) and ref.dtype == torch.float32
+        assert close(ref, model.backbone(img)) and ref.dtype == torch.float32
         # every stage pinned to fp32 under an autocast setting = the stage-by-stage path of trunk(),
-        # which must be the reference's sequence (backbone.py:159-174): same tensor, bit for bit
+        # which must be the reference's sequence (backbone.py:159-174): the same tensor
         model.hip_trunk_dtype = 'float16'
         model.hip_trunk_fp32_stages = ('layer0', 'layer1', 'layer2', 'layer3')
-        assert torch.equal(model.trunk(img), ref)
+        assert close(model.trunk(img), ref)
         # autocast changes the numbers a little, never the shape / dtype / finiteness
         for stages in ((), ('layer2', 'layer3'), ('layer0',)):
             model.hip_trunk_fp32_stages = stages
@@ -28,7 +31,7 @@ def test_trunk_options(gpu):
             assert out.shape == ref.shape and out.dtype == torch.float32 and out.is_contiguous()
             assert torch.isfinite(out).all()
             rel = float((out - ref).abs().max() / ref.abs().max())
-            assert 0 < rel < 2e-2, (stages, rel)
+            assert 1e-4 < rel < 2e-2, (stages, rel)
         # fewer 16-bit stages, less drift
         model.hip_trunk_fp32_stages = ()
         all16 = float((model.trunk(img) - ref).abs().mean())
