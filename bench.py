@@ -122,6 +122,8 @@ def parse_args(argv=None):
                          '(decoder, then the 64-row conv: fewest CU-microseconds - no P buffer, no combine - which is what '
                          'counts when other streams fill the chip; +2.4 %% at 8 pairs @640x640), 0 = the library rule '
                          '(latency: P form below 16 000 token rows)')
+    ap.add_argument('--prereduce-overlap', type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help='oetr_set_state_prereduce for the overlapped run (-1 = the library rule; A/Bs)')
     ap.add_argument('--decoder-split', type=int, default=0, choices=[0, 1, 4],
                     help='oetr_set_decoder_split for the serial run (0 = the library rule; A/Bs)')
     ap.add_argument('--no-other-configs', action='store_true',
@@ -745,6 +747,8 @@ def main():
         eng.set_decoder_split(args.decoder_split_overlap if n_streams > 1 else args.decoder_split)
         if n_streams > 1 and half and precision != 'f16' and precision != 'bf16':
             eng.set_tail_mode(args.tail_mode_overlap)
+        if n_streams > 1 and eng.attention == 'linear':
+            eng.set_state_prereduce(args.prereduce_overlap)
         warm(eng, n_streams)
         res['overlap'] = repeated(eng, n_streams)            # -> value (no instrumentation)
         if not args.no_trace:
@@ -756,6 +760,8 @@ def main():
         eng.set_decoder_split(args.decoder_split)
         if half and precision != 'f16' and precision != 'bf16':
             eng.set_tail_mode(0)
+        if eng.attention == 'linear':
+            eng.set_state_prereduce(-1)
         res['serial'] = repeated(eng, 1) if n_streams > 1 else res['overlap']
         if not args.no_trace and with_serial_trace and tile_overlap != (args.enc_tile or 0):
             res['trace_serial_shape'] = traced(eng)
