@@ -711,7 +711,7 @@ hipError_t launch_heat_combine(const HeatLaunch& h, const float* P, hipStream_t 
 // tokens, 16 of 26.8 at 1024).  Every workgroup folds its image's per-tile moments itself (Chan et al.,
 // 16 interleaved chunks of tiles per group, then the 16 partial results in chunk order - the same
 // arithmetic in every workgroup of the image); its own rows are in flight meanwhile.
-__global__ __launch_bounds__(512) void k_heat_logits(HeatLaunch p) {
+__global__ __launch_bounds__(512, 8) void k_heat_logits(HeatLaunch p) {
   __shared__ float fold_s[16 * GN_GROUPS * 3];
   __shared__ float gmean_s[GN_GROUPS], grstd_s[GN_GROUPS];
   const Geom& g = p.g;
@@ -727,15 +727,15 @@ __global__ __launch_bounds__(512) void k_heat_logits(HeatLaunch p) {
   const size_t row0 = (size_t)g.row0[side] + (size_t)n * L;
   const int part = tid & 15, l = t_idx * TM + (tid >> 4);
   const f32x4* row = reinterpret_cast<const f32x4*>(p.conv_out + (row0 + min(l, L - 1)) * C) + part;
-  f32x4 v[4], gw[4], gb[4], ow[4];
+  f32x4 v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = row[i * 16];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int f4 = i * 16 + part;  // float4 index -> channels 4*f4 .. 4*f4+3, group f4 >> 1
-    gw[i] = reinterpret_cast<const f32x4*>(p.w.gn_w)[f4];
-    gb[i] = reinterpret_cast<const f32x4*>(p.w.gn_b)[f4];
-    ow[i] = reinterpret_cast<const f32x4*>(p.w.out_w)[f4];
+  // GroupNorm affine + 1x1 conv weights: through LDS (held in registers across the fold they cost the
+  // kernel a workgroup per CU: 96 VGPRs -> 2 workgroups of 8 waves; now 4)
+  __shared__ __attribute__((aligned(16))) float aff_s[3 * C];
+  if (tid < 3 * C / 4) {
+    const float* srcp = tid < C / 4 ? p.w.gn_w : tid < C / 2 ? p.w.gn_b : p.w.out_w;
+    reinterpret_cast<f32x4*>(aff_s)[tid] = reinterpret_cast<const f32x4*>(srcp)[tid & (C / 4 - 1)];
   }
   {
     const int grp = tid & 31, ch = tid >> 5;
@@ -781,10 +781,12 @@ __global__ __launch_bounds__(512) void k_heat_logits(HeatLaunch p) {
   float d = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int grp = (i * 16 + part) >> 1;
-    const f32x4 y = (v[i] - gmean_s[grp]) * grstd_s[grp] * gw[i] + gb[i];
+    const int f4 = i * 16 + part, grp = f4 >> 1;  // float4 index -> channels 4*f4 .. 4*f4+3, group f4 >> 1
+    const f32x4 gw = reinterpret_cast<const f32x4*>(aff_s)[f4], gb = reinterpret_cast<const f32x4*>(aff_s + C)[f4],
+                ow = reinterpret_cast<const f32x4*>(aff_s + 2 * C)[f4];
+    const f32x4 y = (v[i] - gmean_s[grp]) * grstd_s[grp] * gw + gb;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d += fmaxf(y[j], 0.f) * ow[i][j];
+    for (int j = 0; j < 4; ++j) d += fmaxf(y[j], 0.f) * ow[j];
   }
   d = sum8(d);
   d += dpp_mov<0x140>(d);  // row_mirror: the other 8 lanes of the 16
