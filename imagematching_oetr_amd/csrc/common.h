@@ -63,6 +63,34 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// Write-through 16-byte store (round 4): `buffer_store_dwordx4 ... sc1` from a wave-uniform base.
+// A plain store leaves its line dirty in the XCD's L2 until the end-of-kernel release writes every
+// dirty line back at once - the launch boundary then costs its fixed ~1.5 us PLUS dirty bytes /
+// ~6 TB/s (MI355X_MICROARCH.md, price-list row "boundary": ~20 MB of residual rows, phi(Q)
+// fragments and partial states per encoder launch at 8 pairs = ~3 us exposed at each of the eight
+// boundaries).  An sc1 store leaves L2 as it is issued, under the kernel's own compute, and the
+// boundary is down to its fixed part; the price is that the line is dropped from L2, so the next
+// launch reads it from the Infinity Cache instead.  OETR_WT is the set of encoder outputs stored
+// this way (bit 0: residual rows x, 1: phi(Q) fragments, 2: partial linear-attention states);
+// same values to the same addresses either way - results are bit-identical.  Measured
+// (profiles/r4_wt_stores.txt, one-process A/B, serial step): all three -1.8 % at 32 pairs @1024x1024,
+// -1.4 % at 8 pairs 640x640 vs 1280x1280, -0.5 % at 8 pairs @640x640, +0.7 % at one pair; overlapped
+// throughput within the noise (+0.8 % at 8 pairs @640x640) - i.e. the flush is a small part of what a
+// boundary costs here; shipped because it is free and never worse beyond the noise.
+#ifndef OETR_WT
+#define OETR_WT 7
+#endif
+template <bool WT>
+__device__ __forceinline__ void store16(float* base_uniform, unsigned byte_off, const f32x4& v) {
+  if constexpr (WT) {
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rs, (int)byte_off, 0, 16 /* sc1 */);
+  } else {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base_uniform) + byte_off) = v;
+  }
+}
+
 // Arithmetic of the GEMM-shaped stages (values == oetr_dtype in include/oetr_hip.h).
 // Everything that is not a GEMM operand (LayerNorm, phi, normalisers, softmax,
 // residual stream, accumulators) is fp32 in every mode.

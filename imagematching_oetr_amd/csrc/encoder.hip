@@ -931,7 +931,7 @@ __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     f32x4 o = {kv[4 * q], kv[4 * q + 1], kv[4 * q + 2], kv[4 * q + 3]};
-    dst[q * 64 + (unsigned)lane] = o;
+    store16<(OETR_WT & 4) != 0>(reinterpret_cast<float*>(dst), (q * 64 + (unsigned)lane) * 16u, o);
   }
   if (lane < 32) (ks_out + (size_t)slot * C + wave * HD)[(unsigned)lane] = ksum;
 }
@@ -1238,8 +1238,8 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     for (int i = 0; i < RTW / 8; ++i) {
       const int r = wave + 8 * i;   // (scalar: a wave-uniform branch, an SGPR row address)
       if (r < nvalid)
-        reinterpret_cast<f32x4*>(p.x + (row_base + r) * C)[(unsigned)lane] =
-            *reinterpret_cast<const f32x4*>(Xf + r * LDA + 4 * lane);
+        store16<(OETR_WT & 1) != 0>(p.x + (row_base + r) * C, 16u * (unsigned)lane,
+                                    *reinterpret_cast<const f32x4*>(Xf + r * LDA + 4 * lane));
     }
     PHASE_STAMP(p, 8);
     if (TAIL == 2) { range_report<MODE>(rg, p.flags); return; }
@@ -1325,15 +1325,18 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
           if constexpr (pr % 2 == 0) { qhi[0] = __builtin_bit_cast(uint32_t, a); qhi[1] = __builtin_bit_cast(uint32_t, b); }
           else {
             qhi[2] = __builtin_bit_cast(uint32_t, a); qhi[3] = __builtin_bit_cast(uint32_t, b);
-            qf[(mt * 4 + pr / 2) * 64 + (unsigned)lane] = __builtin_bit_cast(f32x4, qhi);
+            store16<(OETR_WT & 2) != 0>(reinterpret_cast<float*>(qf), ((mt * 4 + pr / 2) * 64 + (unsigned)lane) * 16u,
+                                        __builtin_bit_cast(f32x4, qhi));
           }
         } else {
           uint32_t h, l;
           cvt_planes2<GM_SPLIT>(a, b, h, l, rg);
           qhi[j] = h; qlo[j] = l;
           if constexpr (j == 3) {
-            qf[(mt * 4 + 2 * s2) * 64 + (unsigned)lane] = __builtin_bit_cast(f32x4, qhi);
-            qf[(mt * 4 + 2 * s2 + 1) * 64 + (unsigned)lane] = __builtin_bit_cast(f32x4, qlo);
+            store16<(OETR_WT & 2) != 0>(reinterpret_cast<float*>(qf), ((mt * 4 + 2 * s2) * 64 + (unsigned)lane) * 16u,
+                                        __builtin_bit_cast(f32x4, qhi));
+            store16<(OETR_WT & 2) != 0>(reinterpret_cast<float*>(qf), ((mt * 4 + 2 * s2 + 1) * 64 + (unsigned)lane) * 16u,
+                                        __builtin_bit_cast(f32x4, qlo));
           }
         }
       };
