@@ -296,7 +296,19 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.flags = w.flags;
   p.force_staged_conv = h->tail_mode == 3;
   p.convp_split = 1;
+  p.mask[0] = p.mask[1] = nullptr;
   return p;
+}
+
+// forward_dummy's masks: both or neither, and only in the arithmetic they are built for
+oetr_status check_masks(const oetr_ctx* h, const float* mask1, const float* mask2, bool encoder) {
+  if (!mask1 && !mask2) return OETR_OK;
+  if (!mask1 || !mask2) return fail(OETR_ERR_BAD_ARG, "masks: pass both mask1 and mask2, or neither");
+  if (encoder && (h->mode != GM_SPLIT || h->policy != 0 || h->attn_full))
+    return fail(OETR_ERR_UNSUPPORTED, "masks: built for OETR_DTYPE_F32_SPLIT_F16 with linear attention "
+                                      "(the reference's FullAttention turns a masked query row into NaN, "
+                                      "linear_attention.py:74-81)");
+  return OETR_OK;
 }
 
 // Brackets one kernel launch with two events when a trace is attached.
@@ -361,7 +373,8 @@ DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, bool 
 oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, const float* feat1,
                             const float* feat2, const float* pos1, const float* pos2,
                             int enc_layers, hipStream_t s, bool with_decoder = true,
-                            bool resident = false) {
+                            bool resident = false, const float* mask1 = nullptr,
+                            const float* mask2 = nullptr) {
   // resident: the caller (oetr_forward_tokens) already holds token-major features and
   // position tables in the workspace (oetr_token_buffers) - no transpose launch
   EncLaunch p;
@@ -385,6 +398,7 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   }
 #endif
   p.x = w.x; p.qp = w.qp; p.pos = w.pos;
+  p.mask[0] = mask1; p.mask[1] = mask2;
   p.flags = w.flags;
   p.attn_full = h->attn_full;
   p.policy = h->policy;
@@ -731,9 +745,11 @@ oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
                          int wf1, int hf2, int wf2, int img_h1, int img_w1, int img_h2,
                          int img_w2, void* workspace, size_t workspace_bytes,
                          float* box1, float* box2, const oetr_stage_outputs* st,
-                         void* stream, bool resident) {
+                         void* stream, bool resident, const float* mask1 = nullptr,
+                         const float* mask2 = nullptr) {
   if (!h || (!resident && (!feat1 || !feat2 || !pos1 || !pos2)))
     return fail(OETR_ERR_BAD_ARG, "oetr_forward: NULL handle/input");
+  if (oetr_status mrc = check_masks(h, mask1, mask2, true)) return mrc;
   int enc_layers = OETR_N_ENC;
   if (st) {
     if (st->struct_size != sizeof(oetr_stage_outputs))
@@ -754,7 +770,8 @@ oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
   oetr_status rc = check_ws(g, workspace, workspace_bytes, &w, h->attn_full);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, enc_layers, s, /*with_decoder=*/false, resident);
+  rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, enc_layers, s, /*with_decoder=*/false, resident,
+                       mask1, mask2);
   if (rc) return rc;
   const size_t r1 = (size_t)g.N * g.L[0], r2 = (size_t)g.N * g.L[1];
   if (st) {
@@ -770,6 +787,7 @@ oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
   float* tl2 = w.tlbr + 4 * g.N;
   HeatLaunch hp = heat_launch(h, g, w, w.x, w.x + r1 * C, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
   hp.tlbr[0] = tl1; hp.tlbr[1] = tl2;
+  hp.mask[0] = mask1; hp.mask[1] = mask2;
   hp.box[0] = box1; hp.box[1] = box2;
   hp.img_w[0] = img_w1; hp.img_w[1] = img_w2;
   // Small batches: decoder || P_tap = W_tap.memory in one launch (the decoder chain, 50 us on 2N CUs, hides
@@ -808,6 +826,17 @@ oetr_status oetr_forward_stages(oetr_handle h, const float* feat1, const float* 
                                 void* stream) {
   return forward_impl(h, feat1, feat2, pos1, pos2, n_pairs, hf1, wf1, hf2, wf2, img_h1, img_w1,
                       img_h2, img_w2, workspace, workspace_bytes, box1, box2, st, stream, false);
+}
+
+oetr_status oetr_forward_masked(oetr_handle h, const float* feat1, const float* feat2,
+                                const float* pos1, const float* pos2, const float* mask1,
+                                const float* mask2, int n_pairs, int hf1, int wf1, int hf2, int wf2,
+                                int img_h1, int img_w1, int img_h2, int img_w2, void* workspace,
+                                size_t workspace_bytes, float* box1, float* box2,
+                                const oetr_stage_outputs* st, void* stream) {
+  return forward_impl(h, feat1, feat2, pos1, pos2, n_pairs, hf1, wf1, hf2, wf2, img_h1, img_w1,
+                      img_h2, img_w2, workspace, workspace_bytes, box1, box2, st, stream, false,
+                      mask1, mask2);
 }
 
 oetr_status oetr_token_buffers(oetr_handle h, int n_pairs, int hf1, int wf1, int hf2, int wf2,
@@ -851,8 +880,20 @@ oetr_status oetr_feature_correlation(oetr_handle h, const float* feat1, const fl
                                      int wf1, int hf2, int wf2, void* workspace,
                                      size_t workspace_bytes, float* hs1, float* hs2,
                                      float* memory1, float* memory2, void* stream) {
+  return oetr_feature_correlation_masked(h, feat1, feat2, pos1, pos2, nullptr, nullptr, n_pairs, hf1, wf1,
+                                         hf2, wf2, workspace, workspace_bytes, hs1, hs2, memory1,
+                                         memory2, stream);
+}
+
+oetr_status oetr_feature_correlation_masked(oetr_handle h, const float* feat1, const float* feat2,
+                                            const float* pos1, const float* pos2, const float* mask1,
+                                            const float* mask2, int n_pairs, int hf1, int wf1, int hf2,
+                                            int wf2, void* workspace, size_t workspace_bytes,
+                                            float* hs1, float* hs2, float* memory1, float* memory2,
+                                            void* stream) {
   if (!h || !feat1 || !feat2 || !pos1 || !pos2 || !hs1 || !hs2 || !memory1 || !memory2)
     return fail(OETR_ERR_BAD_ARG, "oetr_feature_correlation: NULL argument");
+  if (oetr_status mrc = check_masks(h, mask1, mask2, true)) return mrc;
   Geom g;
   if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g))
     return fail(OETR_ERR_BAD_SHAPE, "invalid shape");
@@ -860,7 +901,7 @@ oetr_status oetr_feature_correlation(oetr_handle h, const float* feat1, const fl
   oetr_status rc = check_ws(g, workspace, workspace_bytes, &w, h->attn_full);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if ((rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, OETR_N_ENC, s))) return rc;
+  if ((rc = run_correlation(h, g, w, feat1, feat2, pos1, pos2, OETR_N_ENC, s, true, false, mask1, mask2))) return rc;
   const size_t r1 = (size_t)g.N * g.L[0], r2 = (size_t)g.N * g.L[1];
   if ((rc = copy_out(memory1, w.x, r1 * C, s))) return rc;
   if ((rc = copy_out(memory2, w.x + r1 * C, r2 * C, s))) return rc;
@@ -873,8 +914,20 @@ oetr_status oetr_center_estimation(oetr_handle h, const float* hs1, const float*
                                    int hf1, int wf1, int hf2, int wf2, int img_h1, int img_h2,
                                    void* workspace, size_t workspace_bytes, float* cxy1,
                                    float* cxy2, void* stream) {
+  return oetr_center_estimation_masked(h, hs1, hs2, memory1, memory2, nullptr, nullptr, n_pairs, hf1, wf1,
+                                       hf2, wf2, img_h1, img_h2, workspace, workspace_bytes, cxy1, cxy2,
+                                       stream);
+}
+
+oetr_status oetr_center_estimation_masked(oetr_handle h, const float* hs1, const float* hs2,
+                                          const float* memory1, const float* memory2,
+                                          const float* mask1, const float* mask2, int n_pairs, int hf1,
+                                          int wf1, int hf2, int wf2, int img_h1, int img_h2,
+                                          void* workspace, size_t workspace_bytes, float* cxy1,
+                                          float* cxy2, void* stream) {
   if (!h || !hs1 || !hs2 || !memory1 || !memory2 || !cxy1 || !cxy2)
     return fail(OETR_ERR_BAD_ARG, "oetr_center_estimation: NULL argument");
+  if (oetr_status mrc = check_masks(h, mask1, mask2, false)) return mrc;
   Geom g;
   if (!make_geom(n_pairs, hf1, wf1, hf2, wf2, &g))
     return fail(OETR_ERR_BAD_SHAPE, "invalid shape");
@@ -885,6 +938,7 @@ oetr_status oetr_center_estimation(oetr_handle h, const float* hs1, const float*
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HeatLaunch hp = heat_launch(h, g, w, memory1, memory2, hs1, hs2, cxy1, cxy2, img_h1, img_h2);
+  hp.mask[0] = mask1; hp.mask[1] = mask2;
   TRACED(h, s, K_HEAT_CONV, launch_heat_conv(hp, h->mode, s));
   TRACED(h, s, K_HEAT_FINAL, launch_heat_final(hp, s));
   return OETR_OK;

@@ -1205,6 +1205,10 @@ struct EncLaunch {
   const float* feat_nchw[2];
   const float* pos_nchw[2];
   float* pos_out;        // = pos, writable (the token-major table the n == 0 tiles fill in)
+  // forward_dummy's optional masks (reference src/model.py:229): per side [N][L] floats, a token's
+  // value multiplies its phi(Q) row where it is a query and its phi(K) / V rows where it is a source
+  // (linear_attention.py:37-41).  Both NULL = no masks; otherwise both set (GM_SPLIT, policy 0).
+  const float* mask[2];
 };
 
 // has_b: run phase B (finish a layer); tail: 0 = phase A of next encoder layer,
@@ -1276,6 +1280,8 @@ struct HeatLaunch {
   uint32_t* flags;         // the handle's status word (FLAG_F16_RANGE)
   int force_staged_conv;   // direct form: k_heat_conv64 (per-tap staging) even where the halo-resident form fits
   int convp_split;         // conv-P work items per 64-token tile: 1 or 3 (conv_p.h), set by launch_decoder_convp
+  const float* mask[2];    // forward_dummy's masks per side [N][L] or NULL: logits of tokens with mask == 0
+                           // are filled with -1e9 before the softmax (reference src/model.py:166-171)
 };
 hipError_t launch_heat_conv(const HeatLaunch& p, int mode, hipStream_t s);
 // 64 token rows per workgroup, two-plane mode only: the direct conv of the forward path for large batches

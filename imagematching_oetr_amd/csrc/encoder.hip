@@ -881,10 +881,13 @@ struct E2 {
 };
 
 // phi(K)^T (V/S) and sum phi(K) of a 64-row tile (two MFMA row tiles) for head = wave.
-template <int MODE, int NMT = 2>
+// MASKED (forward_dummy's masks, linear_attention.py:37-41): msk_s[row] = the token's kv_mask value,
+// 0 past the tile's last valid row - it multiplies phi(K) and V where the unmasked form has the
+// row-validity 1 / 0 (an instantiation of its own: the default path's instruction stream is untouched).
+template <int MODE, int NMT = 2, bool MASKED = false>
 __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[NMT], const f32x16 (&accV)[NMT],
                                             int S_len, int nvalid, int half, bool two, f32x16& kv,
-                                            float& ksum, Range& rg) {
+                                            float& ksum, Range& rg, const float* msk_s = nullptr) {
   // Branch-free phi (common.h: elu1, a median) on scalars, a few at a time: unfenced, hipcc
   // schedules all 32 exps at once and spills.  ONE code path with the row masks for every tile
   // (see the file header: no run-time choice between a masked and an unmasked form).
@@ -900,7 +903,9 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[NMT], const f32
     auto row_tile = [&](auto MT_) {
       constexpr int mt = decltype(MT_)::value;
       auto operands = [&](int r, float& k, float& v) {
-        const float m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
+        float m;
+        if constexpr (MASKED) m = msk_s[32 * mt + crow(r, half)];
+        else m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
         const float x = accK[mt][r];
         k = (elu1(x)) * m;
         ksum += k;
@@ -942,7 +947,11 @@ __device__ __forceinline__ void kv_state_write(const f32x16& kv, float ksum, int
 // RTW: token rows of the workgroup, 64 (two MFMA row tiles) or 32 (one: round 4's 32-row encoder,
 // the same body - transposed residual stream, fragment-major phi(Q), epilogues beside MFMAs -
 // with a weight fragment feeding 3 MFMAs instead of 6).
-template <bool HAS_B, int TAIL, int MODE, int POL, int ROWS, int RTW = RT>
+// MASKED: p.mask[side] holds forward_dummy's mask of the side's images, [N][L] floats (src/model.py:229;
+// x_mask / source_mask of every encoder layer, transformer.py:349-358, memory_mask of the decoder,
+// :361-381): phi(Q) rows are multiplied by the token's mask (q_mask), phi(K) and V rows likewise
+// (kv_mask, kv_state_64) - in phase A of every layer and in the decoder preparation.
+template <bool HAS_B, int TAIL, int MODE, int POL, int ROWS, int RTW = RT, bool MASKED = false>
 __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) {
   constexpr int NMT = RTW / 32, THREADS = 512, TPR = THREADS / RTW, F4 = 64 / TPR;
   using L2 = E2<RTW>;
@@ -1265,6 +1274,11 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     }
   }
 
+  // (MASKED: the tile's mask values go where the LayerNorm exchange buffer was - dead after phase B;
+  //  two barriers lie between this store and the first read)
+  if constexpr (MASKED && TAIL != 2) {
+    if (tid < RTW) lnx_s[tid] = tid < nvalid ? p.mask[side][(size_t)n * L + l0 + tid] : 0.f;
+  }
   if (TAIL == 0) {
     // ================= phase A: start layer l+1 =================
     {
@@ -1320,7 +1334,10 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
         constexpr int s2 = pr / 4, j = pr % 4;
         if constexpr (NMT == 1 && CI % 2 == 1) return;
         if (mt == 1 && !two) return;   // (rows 32.. of a one-row-tile workgroup are never read)
-        const float a = elu1(accQ[mt][2 * pr]), b = elu1(accQ[mt][2 * pr + 1]);
+        // (MASKED: q_mask of the lane's token, from the tile's mask values in LDS)
+        const float qmask = MASKED ? lnx_s[32 * mt + col] : 1.0f;
+        const float a = MASKED ? elu1(accQ[mt][2 * pr]) * qmask : elu1(accQ[mt][2 * pr]);
+        const float b = MASKED ? elu1(accQ[mt][2 * pr + 1]) * qmask : elu1(accQ[mt][2 * pr + 1]);
         if constexpr (MODE == GM_BF16) {   // the bf16 build's apply takes f32 fragments: k-group = register quad
           if constexpr (pr % 2 == 0) { qhi[0] = __builtin_bit_cast(uint32_t, a); qhi[1] = __builtin_bit_cast(uint32_t, b); }
           else {
@@ -1348,7 +1365,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     PHASE_STAMP(p, 11);
     f32x16 kv;
     float ksum;
-    kv_state_64<MODE, NMT>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
+    kv_state_64<MODE, NMT, MASKED>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg, lnx_s);
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
     // (the LayerNorm exchange buffer is dead after phase B)
@@ -1390,7 +1407,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
                                                    nullptr, 0, 0);
       f32x16 kv;
       float ksum;
-      kv_state_64<MODE, NMT>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg);
+      kv_state_64<MODE, NMT, MASKED>(accK, accV, L, nvalid, half, ws.two(), kv, ksum, rg, lnx_s);
       if constexpr (dl == 1) {
         kv_state_write(kv, ksum, lane, wave, p.dkv1_out, p.dks1_out, slot);
       } else {
@@ -1417,7 +1434,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
   range_report<MODE>(rg, p.flags);
 }
 
-template <bool HAS_B, int TAIL, int MODE, int POL = 0>
+template <bool HAS_B, int TAIL, int MODE, int POL = 0, bool MASKED = false>
 __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
   __shared__ __attribute__((aligned(16))) float smem[E2<RT>::SMEM];
   if constexpr (gm_planes(MODE) == 2) {
@@ -1431,20 +1448,20 @@ __global__ __launch_bounds__(512) void k_encoder64(EncLaunch p) {
     const int side = rem >= g.nt[0];
     const int t_idx = side ? rem - g.nt[0] : rem;
     const int nvalid = min(RT, g.L[side] - t_idx * RT);
-    if (__builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0)) encoder64_body<HAS_B, TAIL, MODE, POL, 2>(p, smem);
-    else encoder64_body<HAS_B, TAIL, MODE, POL, 1>(p, smem);
+    if (__builtin_amdgcn_readfirstlane(nvalid > 32 ? 1 : 0)) encoder64_body<HAS_B, TAIL, MODE, POL, 2, RT, MASKED>(p, smem);
+    else encoder64_body<HAS_B, TAIL, MODE, POL, 1, RT, MASKED>(p, smem);
   } else {
-    encoder64_body<HAS_B, TAIL, MODE, POL, 0>(p, smem);
+    encoder64_body<HAS_B, TAIL, MODE, POL, 0, RT, MASKED>(p, smem);
   }
 }
 
 // 32 token rows per workgroup on the same body (round 4; two-plane mode): one MFMA row tile, 77.5 KB
 // of LDS.  Replaces k_encoder<..., 8> for the linear-attention split builds - that kernel stays for
 // the exact-fp32 mode (4 waves), the single-plane modes and attention = 'full'.
-template <bool HAS_B, int TAIL, int MODE, int POL = 0>
+template <bool HAS_B, int TAIL, int MODE, int POL = 0, bool MASKED = false>
 __global__ __launch_bounds__(512) void k_encoder32m(EncLaunch p) {
   __shared__ __attribute__((aligned(16))) float smem[E2<TM>::SMEM];
-  encoder64_body<HAS_B, TAIL, MODE, POL, 2, TM>(p, smem);
+  encoder64_body<HAS_B, TAIL, MODE, POL, 2, TM, MASKED>(p, smem);
 }
 
 #ifndef OETR_SPLIT_WAVES
@@ -1457,6 +1474,30 @@ __global__ __launch_bounds__(512) void k_encoder32m(EncLaunch p) {
 template <int MODE>
 static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, hipStream_t s) {
   const dim3 grid(p.g.ntiles);
+  if (p.mask[0] || p.mask[1]) {
+    // forward_dummy's masks: built for the default arithmetic (two planes, every site fp32-class,
+    // linear attention), both tile sizes
+    if constexpr (MODE == GM_SPLIT) {
+      if (!p.mask[0] || !p.mask[1] || p.policy != 0 || p.attn_full) return hipErrorInvalidValue;
+#define OETR_LAUNCHM(B, T)                                                                               \
+  do {                                                                                                   \
+    if (p.tile_rows == RT) hipLaunchKernelGGL((k_encoder64<B, T, MODE, 0, true>), grid, dim3(512), 0, s, p); \
+    else hipLaunchKernelGGL((k_encoder32m<B, T, MODE, 0, true>), grid, dim3(512), 0, s, p);                \
+  } while (0)
+      if (has_b) {
+        if (tail == 0) OETR_LAUNCHM(true, 0);
+        else if (tail == 1) OETR_LAUNCHM(true, 1);
+        else OETR_LAUNCHM(true, 2);
+      } else {
+        if (tail == 0) OETR_LAUNCHM(false, 0);
+        else return hipErrorInvalidValue;
+      }
+#undef OETR_LAUNCHM
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if constexpr (gm_half(MODE)) {
     if (p.tile_rows == RT) {
 #define OETR_LAUNCH64(B, T) hipLaunchKernelGGL((k_encoder64<B, T, MODE>), grid, dim3(512), 0, s, p)

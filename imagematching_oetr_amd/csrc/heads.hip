@@ -791,6 +791,8 @@ __global__ __launch_bounds__(512, 8) void k_heat_logits(HeatLaunch p) {
   d = sum8(d);
   d += dpp_mov<0x140>(d);  // row_mirror: the other 8 lanes of the 16
   d += p.w.out_b[0];
+  // forward_dummy's masks: heatmap.masked_fill_(~mask.bool(), -INF) with INF = 1e9 (model.py:22, :166-171)
+  if (p.mask[side] != nullptr && p.mask[side][(size_t)n * L + min(l, L - 1)] == 0.f) d = -1.0e9f;
   __shared__ float logit_s[TM];
   if (part == 0) {
     logit_s[tid >> 4] = l < L ? d : -INFINITY;

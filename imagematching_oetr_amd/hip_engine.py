@@ -67,7 +67,7 @@ class _CropInfo(C.Structure):
                 ('ratio', (C.c_double * 2) * 2), ('sbox', (C.c_float * 4) * 2)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # OETR_WORKSPACE_STATUS_BYTES: the block that opens a workspace - status word, the split decoder's
 # call counters and exchange granules; zero it once (oetr_workspace_init), the library owns it after
 WORKSPACE_STATUS_BYTES = 256 + 16 * 5 * 4 * 256 * 8
@@ -85,7 +85,8 @@ EXPORTS = (
     'oetr_linear_attention_workspace_bytes', 'oetr_neck_set_conv_kernel',
     'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens',
     'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async',
-    'oetr_set_state_prereduce', 'oetr_set_tail_mode', 'oetr_set_decoder_split', 'oetr_overlap_frame', 'oetr_read_overlap_image')
+    'oetr_set_state_prereduce', 'oetr_set_tail_mode', 'oetr_set_decoder_split', 'oetr_overlap_frame', 'oetr_read_overlap_image',
+    'oetr_forward_masked', 'oetr_feature_correlation_masked', 'oetr_center_estimation_masked')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 FLAG_EXCHANGE = 2    # OETR_FLAG_EXCHANGE: the split decoder's workgroups were not resident together
@@ -170,6 +171,15 @@ def load_library(path=None):
     lib.oetr_center_estimation.restype = i
     lib.oetr_center_estimation.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i,
                                            i, i, vp, sz, vp, vp, vp]
+    # forward_dummy's masks: the same calls with (mask1, mask2) after the position tables / memories
+    lib.oetr_forward_masked.restype = i
+    lib.oetr_forward_masked.argtypes = fwd[:5] + [vp, vp] + fwd[5:] + [C.POINTER(_Stages), vp]
+    lib.oetr_feature_correlation_masked.restype = i
+    lib.oetr_feature_correlation_masked.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i,
+                                                    vp, sz, vp, vp, vp, vp, vp]
+    lib.oetr_center_estimation_masked.restype = i
+    lib.oetr_center_estimation_masked.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i,
+                                                  i, i, vp, sz, vp, vp, vp]
     lib.oetr_size_regression.restype = i
     lib.oetr_size_regression.argtypes = [vp, vp, vp, i, vp, vp, vp]
     lib.oetr_box_tlbr_to_xyxy.restype = i
@@ -572,11 +582,29 @@ class HotPathEngine:
                              f'got {tuple(pos.shape)}')
         return hf, wf
 
+    def _masks(self, mask1, mask2, n, L1, L2):
+        """forward_dummy's optional masks ([N,hf,wf] or [N,L], any numeric / bool dtype, as the
+        reference takes them: src/model.py:229, transformer.py:340-343) -> contiguous float32
+        device tensors [N,L] (or (None, None)).  Both or neither."""
+        if mask1 is None and mask2 is None:
+            return None, None
+        if mask1 is None or mask2 is None:
+            raise ValueError('masks: pass both mask1 and mask2, or neither')
+        out = []
+        for m, L, name in ((mask1, L1, 'mask1'), (mask2, L2, 'mask2')):
+            m = m.to(device=self.device, dtype=torch.float32).reshape(m.shape[0], -1).contiguous()
+            if tuple(m.shape) != (n, L):
+                raise ValueError(f'{name} must have N x hf*wf = {n} x {L} elements, got {tuple(m.shape)}')
+            out.append(m)
+        return out[0], out[1]
+
     # -------------------------------------------------------------- calls
     def forward(self, feat1, feat2, pos1, pos2, img_hw1, img_hw2, stages=None,
-                enc_layers=N_ENC):
+                enc_layers=N_ENC, mask1=None, mask2=None):
         """feats [N,256,hf,wf] + pos [1,256,hf,wf] -> (box1, box2) [N,4].
-        With ``stages=True`` returns a dict of intermediates as well."""
+        With ``stages=True`` returns a dict of intermediates as well.
+        ``mask1`` / ``mask2``: forward_dummy's optional masks at the token grid's resolution
+        (``oetr_forward_masked``; with them ``logits`` holds -1e9 at masked tokens)."""
         feat1, feat2 = _dev(feat1, 'feat1'), _dev(feat2, 'feat2')
         pos1, pos2 = _dev(pos1, 'pos1'), _dev(pos2, 'pos2')
         n = int(feat1.shape[0])
@@ -584,6 +612,7 @@ class HotPathEngine:
             raise ValueError('feat1/feat2 batch sizes differ')
         hf1, wf1 = self._grid(feat1, pos1, 'feat1')
         hf2, wf2 = self._grid(feat2, pos2, 'feat2')
+        mask1, mask2 = self._masks(mask1, mask2, n, hf1 * wf1, hf2 * wf2)
         ws = self.workspace(n, hf1, wf1, hf2, wf2)
         self._pos_loaded.pop(torch.cuda.current_stream(self.device).cuda_stream, None)
         dev = self.device
@@ -593,8 +622,15 @@ class HotPathEngine:
                 pos2.data_ptr(), n, hf1, wf1, hf2, wf2, int(img_hw1[0]),
                 int(img_hw1[1]), int(img_hw2[0]), int(img_hw2[1]),
                 ws.data_ptr(), ws.numel(), box1.data_ptr(), box2.data_ptr()]
+        margs = None
+        if mask1 is not None:
+            margs = args[:5] + [mask1.data_ptr(), mask2.data_ptr()] + args[5:]
         with torch.cuda.device(dev):
             if not stages:
+                if margs is not None:
+                    _check(self.lib, self.lib.oetr_forward_masked(*margs, None, _stream(dev)),
+                           'oetr_forward_masked')
+                    return box1, box2
                 _check(self.lib, self.lib.oetr_forward(*args, _stream(dev)),
                        'oetr_forward')
                 return box1, box2
@@ -615,8 +651,12 @@ class HotPathEngine:
             st.enc_layers = int(enc_layers)
             for k, t in out.items():
                 setattr(st, k, t.data_ptr())
-            _check(self.lib, self.lib.oetr_forward_stages(
-                *args, C.byref(st), _stream(dev)), 'oetr_forward_stages')
+            if margs is not None:
+                _check(self.lib, self.lib.oetr_forward_masked(
+                    *margs, C.byref(st), _stream(dev)), 'oetr_forward_masked')
+            else:
+                _check(self.lib, self.lib.oetr_forward_stages(
+                    *args, C.byref(st), _stream(dev)), 'oetr_forward_stages')
             out['box1'], out['box2'] = box1, box2
             if enc_layers < N_ENC:
                 out = {k: out[k] for k in ('memory1', 'memory2')}
@@ -672,12 +712,13 @@ class HotPathEngine:
                 box1.data_ptr(), box2.data_ptr(), _stream(dev)), 'oetr_forward_tokens')
         return box1, box2
 
-    def feature_correlation(self, feat1, feat2, pos1, pos2):
+    def feature_correlation(self, feat1, feat2, pos1, pos2, mask1=None, mask2=None):
         feat1, feat2 = _dev(feat1, 'feat1'), _dev(feat2, 'feat2')
         pos1, pos2 = _dev(pos1, 'pos1'), _dev(pos2, 'pos2')
         n = int(feat1.shape[0])
         hf1, wf1 = self._grid(feat1, pos1, 'feat1')
         hf2, wf2 = self._grid(feat2, pos2, 'feat2')
+        mask1, mask2 = self._masks(mask1, mask2, n, hf1 * wf1, hf2 * wf2)
         ws = self.workspace(n, hf1, wf1, hf2, wf2)
         self._pos_loaded.pop(torch.cuda.current_stream(self.device).cuda_stream, None)
         dev = self.device
@@ -686,18 +727,20 @@ class HotPathEngine:
         m1 = torch.empty(n, hf1 * wf1, D_MODEL, device=dev)
         m2 = torch.empty(n, hf2 * wf2, D_MODEL, device=dev)
         with torch.cuda.device(dev):
-            _check(self.lib, self.lib.oetr_feature_correlation(
+            _check(self.lib, self.lib.oetr_feature_correlation_masked(
                 self._h, feat1.data_ptr(), feat2.data_ptr(), pos1.data_ptr(),
-                pos2.data_ptr(), n, hf1, wf1, hf2, wf2, ws.data_ptr(),
-                ws.numel(), hs1.data_ptr(), hs2.data_ptr(), m1.data_ptr(),
+                pos2.data_ptr(), mask1.data_ptr() if mask1 is not None else None,
+                mask2.data_ptr() if mask2 is not None else None, n, hf1, wf1, hf2, wf2,
+                ws.data_ptr(), ws.numel(), hs1.data_ptr(), hs2.data_ptr(), m1.data_ptr(),
                 m2.data_ptr(), _stream(dev)), 'oetr_feature_correlation')
         return hs1, hs2, m1, m2
 
     def center_estimation(self, hs1, hs2, memory1, memory2, hf1, wf1, hf2, wf2,
-                          img_h1, img_h2):
+                          img_h1, img_h2, mask1=None, mask2=None):
         hs1, hs2 = _dev(hs1, 'hs1'), _dev(hs2, 'hs2')
         memory1, memory2 = _dev(memory1, 'memory1'), _dev(memory2, 'memory2')
         n = int(hs1.shape[0])
+        mask1, mask2 = self._masks(mask1, mask2, n, hf1 * wf1, hf2 * wf2)
         if memory1.shape != (n, hf1 * wf1, D_MODEL) or \
                 memory2.shape != (n, hf2 * wf2, D_MODEL):
             raise ValueError('memory shapes do not match the token grids')
@@ -705,9 +748,10 @@ class HotPathEngine:
         c1 = torch.empty(n, 2, device=self.device)
         c2 = torch.empty(n, 2, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib, self.lib.oetr_center_estimation(
+            _check(self.lib, self.lib.oetr_center_estimation_masked(
                 self._h, hs1.data_ptr(), hs2.data_ptr(), memory1.data_ptr(),
-                memory2.data_ptr(), n, hf1, wf1, hf2, wf2, int(img_h1),
+                memory2.data_ptr(), mask1.data_ptr() if mask1 is not None else None,
+                mask2.data_ptr() if mask2 is not None else None, n, hf1, wf1, hf2, wf2, int(img_h1),
                 int(img_h2), ws.data_ptr(), ws.numel(), c1.data_ptr(),
                 c2.data_ptr(), _stream(self.device)), 'oetr_center_estimation')
         return c1, c2

@@ -315,28 +315,36 @@ class OETR(nn.Module):
             self._neck_key = key
         return self._neck_engine
 
-    @staticmethod
-    def _no_masks(mask1, mask2):
-        if mask1 is not None or mask2 is not None:
+    def _check_masks(self, mask1, mask2, encoder=True):
+        """forward_dummy's optional masks (reference ``src/model.py:229``; [N,hf,wf] at the token
+        grid's resolution, any numeric / bool dtype): both or neither; the encoder kernels carry
+        them in the default arithmetic with linear attention (``oetr_forward_masked``)."""
+        if mask1 is None and mask2 is None:
+            return False
+        if mask1 is None or mask2 is None:
+            raise ValueError('masks: pass both mask1 and mask2, or neither')
+        if encoder and (self.hip_precision != 'f32_split_f16' or self.hip_attention != 'linear'):
             raise NotImplementedError(
-                'masks are unreachable in the reference pipeline (SURVEY.md '
-                '§3.2) and not implemented by the HIP path')
+                "masks are built for hip_precision='f32_split_f16' with linear attention (the "
+                "reference's FullAttention turns a masked query row into NaN, linear_attention.py:74-81); "
+                f"this model runs hip_precision='{self.hip_precision}', hip_attention='{self.hip_attention}'")
+        return True
 
     # ---------------------------------------------- reference inner seams
     def feature_correlation(self, feat1, feat2, pos1, pos2, mask1=None,
                             mask2=None):
         """Reference ``src/model.py:132-143``: -> hs1, hs2 [N,1,C],
         memory1 [N,L1,C], memory2 [N,L2,C]."""
-        self._no_masks(mask1, mask2)
-        return self.engine().feature_correlation(feat1, feat2, pos1, pos2)
+        self._check_masks(mask1, mask2)
+        return self.engine().feature_correlation(feat1, feat2, pos1, pos2, mask1, mask2)
 
     def center_estimation(self, hs1, hs2, memory1, memory2, hf1, wf1, hf2,
                           wf2, mask1=None, mask2=None):
         """Reference ``src/model.py:145-186``; image heights come from the
         last ``forward_dummy`` call (``self.h1``/``self.h2``) as there."""
-        self._no_masks(mask1, mask2)
+        self._check_masks(mask1, mask2, encoder=False)
         return self.engine().center_estimation(hs1, hs2, memory1, memory2, hf1,
-                                               wf1, hf2, wf2, self.h1, self.h2)
+                                               wf1, hf2, wf2, self.h1, self.h2, mask1, mask2)
 
     def size_regression(self, hs1, hs2):
         """Reference ``src/model.py:188-191``."""
@@ -346,12 +354,16 @@ class OETR(nn.Module):
     @torch.no_grad()
     def forward_dummy(self, image1, image2, mask1=None, mask2=None):
         """Reference ``src/model.py:229-252``: images [N,H,W,3] in [0,1] ->
-        (box1, box2), each [N,4] xyxy pixels."""
-        self._no_masks(mask1, mask2)
+        (box1, box2), each [N,4] xyxy pixels.  ``mask1`` / ``mask2`` [N,hf,wf]: the
+        reference's optional masks at the token grid's resolution (padded batches)."""
+        masked = self._check_masks(mask1, mask2)
         self.hip_flush()          # the previous batch's deferred range check (no-op otherwise)
         h1, w1 = image1.shape[1:3]
         h2, w2 = image2.shape[1:3]
         self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
+        if masked:
+            feat1, feat2, pos1, pos2, _, _, _, _ = self.feature_extraction(image1, image2)
+            return self.boxes_from_features(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), mask1, mask2)
         if self.hip_neck and self.hip_fuse_neck and image1.is_cuda and not self.training:
             # trunk -> HIP neck storing token-major straight into the hot path's workspace
             if image1.shape == image2.shape:
@@ -450,17 +462,24 @@ class OETR(nn.Module):
         if pending is not None:
             self._settle(*pending)
 
-    def boxes_from_features(self, feat1, feat2, pos1, pos2, hw1, hw2):
+    def boxes_from_features(self, feat1, feat2, pos1, pos2, hw1, hw2, mask1=None, mask2=None):
         """Everything after ``feature_extraction`` (reference ``src/model.py:239-252``)
         as one fused HIP call, with the f16 range guard of the chosen precision (deferred
-        like ``forward_dummy``'s under ``hip_defer_check``)."""
+        like ``forward_dummy``'s under ``hip_defer_check``).  With masks a tripped guard
+        raises whatever ``hip_on_overflow`` says: the exact-fp32 kernels carry no masks."""
+        masked = self._check_masks(mask1, mask2)
         self.hip_flush()
         eng = self.engine()
-        boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2)
+        boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
         if self.hip_on_overflow == 'ignore' or eng.precision not in eng.F16_RANGE:
             return boxes
-        return self._range_checked(boxes, [eng.read_flags_async()],
-                                   lambda: self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2))
+        if masked:
+            def rerun():
+                raise OetrRangeError('a GEMM operand reached |x| >= 65504 in a masked batch: the exact-fp32 '
+                                     're-run route carries no masks')
+        else:
+            rerun = lambda: self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2)
+        return self._range_checked(boxes, [eng.read_flags_async()], rerun)
 
     def _exact_boxes(self, feat1, feat2, pos1, pos2, hw1, hw2):
         if self.hip_on_overflow == 'raise':
@@ -493,9 +512,11 @@ class OETR(nn.Module):
                 'OETR.forward(data): the HIP hot path has no backward kernels - wrap the call '
                 'in torch.no_grad() (loss values / metrics), or train with the reference '
                 'PyTorch model and load the checkpoint here (same state-dict keys)')
-        if 'resize_mask1' in data:
-            self._no_masks(data['resize_mask1'], data['resize_mask2'])
         valid = data['overlap_valid']
+        mask1 = mask2 = None
+        if 'resize_mask1' in data:       # reference model.py:256-258
+            mask1, mask2 = data['resize_mask1'][valid], data['resize_mask2'][valid]
+        masked = self._check_masks(mask1, mask2)
         image1, image2 = data['image1'][valid], data['image2'][valid]
         h1, w1 = image1.shape[1:3]
         h2, w2 = image2.shape[1:3]
@@ -503,10 +524,11 @@ class OETR(nn.Module):
         with torch.no_grad():
             feat1, feat2, pos1, pos2, hf1, wf1, hf2, wf2 = self.feature_extraction(image1, image2)
             eng = self.engine()
-            st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True)
+            st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True,
+                             mask1=mask1, mask2=mask2)
             if self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE \
                     and eng.query_flags() & FLAG_INVALID:
-                if self.hip_on_overflow == 'raise':
+                if self.hip_on_overflow == 'raise' or masked:   # (the exact-fp32 kernels carry no masks)
                     raise OetrRangeError('a GEMM operand reached |x| >= 65504; use hip_precision "f32"')
                 eng = self.exact_engine()
                 st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True)
@@ -533,7 +555,7 @@ class OETR(nn.Module):
             if self.cycle:
                 # centres with the two decoder queries swapped (reference model.py:354-356)
                 c1f2, c2f1 = eng.center_estimation(st['hs2'], st['hs1'], st['memory1'], st['memory2'],
-                                                   hf1, wf1, hf2, wf2, h1, h2)
+                                                   hf1, wf1, hf2, wf2, h1, h2, mask1, mask2)
                 _, _, cyc1, cyc2 = losses.obtain_overlap_bbox(c1f2, st['tlbr1'], c2f1, st['tlbr2'],
                                                               (h1, w1), (h2, w2))
                 cycle = F.l1_loss(cyc1[:, :2] / s1, gtc1[:, :2] / s1) + F.l1_loss(cyc2[:, :2] / s2, gtc2[:, :2] / s2)

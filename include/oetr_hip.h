@@ -41,8 +41,10 @@ extern "C" {
  *    a workspace, OETR_DTYPE_F32_SPLIT_QK16
  * 3: the status block of a workspace grew from 256 bytes to OETR_WORKSPACE_STATUS_BYTES (the split
  *    decoder's call counters and exchange granules live there: oetr_set_decoder_split);
- *    OETR_FLAG_EXCHANGE */
-#define OETR_ABI_VERSION 3
+ *    OETR_FLAG_EXCHANGE
+ * 4: forward_dummy's optional masks: oetr_forward_masked, oetr_feature_correlation_masked,
+ *    oetr_center_estimation_masked (new exports; nothing else changed) */
+#define OETR_ABI_VERSION 4
 #define OETR_D_MODEL 256
 #define OETR_N_HEAD 8
 #define OETR_N_ENC 8 /* self,cross x4  - reference src/models/transformer.py:295 */
@@ -319,6 +321,44 @@ oetr_status oetr_forward_stages(oetr_handle h, const float *feat1,
                                 void *workspace, size_t workspace_bytes,
                                 float *box1, float *box2,
                                 const oetr_stage_outputs *stages, void *stream);
+
+/* forward_dummy's optional masks (reference src/model.py:229 `forward_dummy(image1, image2,
+ * mask1=None, mask2=None)`, the training forward's resize_mask1/2, :256-258).  mask1 [N][hf1*wf1],
+ * mask2 [N][hf2*wf2]: device floats at the token grid's resolution (the reference flattens
+ * [N,hf,wf], src/models/transformer.py:340-343).  As in the reference a token's value
+ *   - multiplies its phi(Q) row where the token is a query and its phi(K) and V rows where it is
+ *     a source, in all eight encoder layers (x_mask / source_mask, transformer.py:349-358 ->
+ *     LinearAttention q_mask / kv_mask, src/models/linear_attention.py:37-41; V is still divided
+ *     by the FULL source length, :43-44) and in the decoder's cross-attention (memory_mask,
+ *     transformer.py:361-381; its tgt_mask is None);
+ *   - fills the token's heat-map logit with -1e9 before the softmax where it is 0
+ *     (src/model.py:22, :166-171) - the `logits` stage output then holds the filled values.
+ * Both masks or neither (both NULL = oetr_forward_stages); OETR_ERR_UNSUPPORTED unless the handle
+ * is OETR_DTYPE_F32_SPLIT_F16 with linear attention and no precision policy (the reference's
+ * FullAttention turns a masked query's row into NaN, linear_attention.py:74-81).
+ * `stages` may be NULL.  Same workspace, same enqueue-only behaviour as oetr_forward. */
+oetr_status oetr_forward_masked(oetr_handle h, const float *feat1,
+                                const float *feat2, const float *pos1,
+                                const float *pos2, const float *mask1,
+                                const float *mask2, int n_pairs, int hf1,
+                                int wf1, int hf2, int wf2, int img_h1,
+                                int img_w1, int img_h2, int img_w2,
+                                void *workspace, size_t workspace_bytes,
+                                float *box1, float *box2,
+                                const oetr_stage_outputs *stages, void *stream);
+/* ... and of the two seams: OETR.feature_correlation(feat1, feat2, pos1, pos2, mask1, mask2)
+ * (src/model.py:132-143) and OETR.center_estimation(..., mask1, mask2) (:145-186; the masks
+ * only fill the logits there, any dtype of handle). */
+oetr_status oetr_feature_correlation_masked(
+    oetr_handle h, const float *feat1, const float *feat2, const float *pos1,
+    const float *pos2, const float *mask1, const float *mask2, int n_pairs,
+    int hf1, int wf1, int hf2, int wf2, void *workspace, size_t workspace_bytes,
+    float *hs1, float *hs2, float *memory1, float *memory2, void *stream);
+oetr_status oetr_center_estimation_masked(
+    oetr_handle h, const float *hs1, const float *hs2, const float *memory1,
+    const float *memory2, const float *mask1, const float *mask2, int n_pairs,
+    int hf1, int wf1, int hf2, int wf2, int img_h1, int img_h2, void *workspace,
+    size_t workspace_bytes, float *cxy1, float *cxy2, void *stream);
 
 /* Replaces: OETR.feature_correlation (reference src/model.py:132-143 ->
  * QueryTransformer.forward, src/models/transformer.py:313-383), masks None.

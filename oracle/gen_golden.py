@@ -109,6 +109,33 @@ def gen_attention(out_dir):
     print('attention.npz', len(cases), 'cases')
 
 
+def gen_attention_masked(out_dir):
+    """LinearAttention with q_mask / kv_mask (linear_attention.py:37-41): float 0/1 masks,
+    ~25 % of the positions cleared, image 0 unmasked on the key side."""
+    from src.models.linear_attention import LinearAttention
+    lin = LinearAttention()
+    cases = [(1, 400), (400, 400), (400, 1600), (77, 33)]
+    data = {}
+    for ci, (L, S) in enumerate(cases):
+        g = torch.Generator().manual_seed(1100 + ci)
+        q = (torch.rand(2, L, 8, 32, generator=g) - 0.5) * 4
+        k = (torch.rand(2, S, 8, 32, generator=g) - 0.5) * 4
+        v = (torch.rand(2, S, 8, 32, generator=g) - 0.5) * 2
+        qm = (torch.rand(2, L, generator=g) >= 0.25).float()
+        km = (torch.rand(2, S, generator=g) >= 0.25).float()
+        km[0] = 1.0
+        ol = lin(q, k, v, q_mask=qm, kv_mask=km).reshape(2, L, 256)
+        tag = f'L{L}_S{S}'
+        data[tag + '_seed'] = np.int64(1100 + ci)
+        data[tag + '_in_fp'] = np.stack([fp(q), fp(k), fp(v), fp(qm), fp(km)])
+        data[tag + '_lin'], st = sub(ol)
+        data[tag + '_step'] = np.int64(st)
+        data[tag + '_lin_fp'] = fp(ol)
+    data['cases'] = np.asarray(cases, dtype=np.int64)
+    np.savez_compressed(out_dir / 'attention_masked.npz', **data)
+    print('attention_masked.npz', len(cases), 'cases')
+
+
 def build_reference_model():
     from src.config.default import get_cfg_defaults
     from src.model import build_detectors
@@ -138,6 +165,16 @@ FULL_ATTN_CASES = [
 ]
 
 
+# forward_dummy's optional masks (src/model.py:229; LinearAttention q_mask / kv_mask,
+# linear_attention.py:37-41; memory_mask of the decoder, transformer.py:361-381; the heat map's
+# masked_fill, model.py:166-171): the hot cases' tuple + (mask seed, kind) - oracle.make_masks
+MASK_CASES = [
+    ('s7_20x20_sharp', 7, True, 17, 3, (20, 20), (20, 20), (640, 640), (640, 640), 70, 'pad'),
+    ('s8_15x20_25x10_sharp', 8, True, 18, 3, (15, 20), (25, 10), (480, 640), (800, 320), 71, 'holes'),
+    ('s9_20x20_40x40', 9, False, 19, 2, (20, 20), (40, 40), (640, 640), (1280, 1280), 72, 'pad'),
+]
+
+
 @torch.no_grad()
 def gen_hot(out_dir, model, cases=None, prefix='hot_', full_attention=False):
     from src.models.utils import box_tlbr_to_xyxy
@@ -147,7 +184,12 @@ def gen_hot(out_dir, model, cases=None, prefix='hot_', full_attention=False):
         saved = [layer.attention for layer in model.transformer.encoder]
         for layer in model.transformer.encoder:
             layer.attention = FullAttention()
-    for (tag, wseed, sharp, fseed, n, g1, g2, im1, im2) in (cases or HOT_CASES):
+    for case in (cases or HOT_CASES):
+        (tag, wseed, sharp, fseed, n, g1, g2, im1, im2) = case[:9]
+        mask1 = mask2 = None
+        if len(case) > 9:   # MASK_CASES
+            mask1 = orc.make_masks(case[9], n, *g1, kind=case[10])
+            mask2 = orc.make_masks(case[9] + 100, n, *g2, kind=case[10])
         w = orc.make_hot_weights(wseed, sharpen=sharp)
         missing, unexpected = model.load_state_dict(w, strict=False)
         assert not unexpected, unexpected
@@ -167,7 +209,7 @@ def gen_hot(out_dir, model, cases=None, prefix='hot_', full_attention=False):
         model.h1, model.w1 = im1
         model.h2, model.w2 = im2
         hs1, hs2, m1, m2 = model.feature_correlation(feat1, feat2, pos1, pos2,
-                                                     None, None)
+                                                     mask1, mask2)
         for h in hooks:
             h.remove()
         # heat-map logits via a hook on heatmap_conv (runs for image1, image2)
@@ -175,8 +217,11 @@ def gen_hot(out_dir, model, cases=None, prefix='hot_', full_attention=False):
         hk = model.heatmap_conv.register_forward_hook(
             lambda _m, _i, out: logits.append(out.detach().flatten(1).clone()))
         c1, c2 = model.center_estimation(hs1, hs2, m1, m2, g1[0], g1[1], g2[0],
-                                         g2[1], None, None)
+                                         g2[1], mask1, mask2)
         hk.remove()
+        if mask1 is not None:   # what the softmax sees (model.py:166-171 fills a rearranged copy in place)
+            logits[0] = logits[0].masked_fill(~mask1.flatten(1).bool(), -1e9)
+            logits[1] = logits[1].masked_fill(~mask2.flatten(1).bool(), -1e9)
         t1, t2 = model.size_regression(hs1, hs2)
         b1 = box_tlbr_to_xyxy(c1, t1, max_h=im1[0], max_w=im1[1])
         b2 = box_tlbr_to_xyxy(c2, t2, max_h=im2[0], max_w=im2[1])
@@ -192,6 +237,9 @@ def gen_hot(out_dir, model, cases=None, prefix='hot_', full_attention=False):
                     cxy1=c1.numpy(), cxy2=c2.numpy(), tlbr1=t1.numpy(),
                     tlbr2=t2.numpy(), box1=b1.numpy(), box2=b2.numpy(),
                     memory1_fp=fp(m1), memory2_fp=fp(m2))
+        if mask1 is not None:
+            data.update(mask_seed=np.int64(case[9]), mask_kind=np.str_(case[10]),
+                        mask1=mask1.numpy().astype(np.uint8), mask2=mask2.numpy().astype(np.uint8))
         data['memory1'], data['memory1_step'] = sub(m1)
         data['memory2'], data['memory2_step'] = sub(m2)
         for li in (0, 1):
@@ -499,12 +547,17 @@ def main():
         return gen_train_forward(out_dir, build_reference_model())
     if args.only == 'hot':
         return gen_hot(out_dir, build_reference_model())
+    if args.only == 'mask':
+        gen_attention_masked(out_dir)
+        return gen_hot(out_dir, build_reference_model(), MASK_CASES, 'hotmask_')
     gen_misc(out_dir)
     gen_reader(out_dir)
     gen_crop(out_dir)
     gen_attention(out_dir)
+    gen_attention_masked(out_dir)
     model = build_reference_model()
     gen_hot(out_dir, model)
+    gen_hot(out_dir, model, MASK_CASES, 'hotmask_')
     gen_hot(out_dir, model, FULL_ATTN_CASES, 'fullattn_', True)
     gen_full(out_dir, model)
     gen_neck(out_dir, model)

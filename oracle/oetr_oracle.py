@@ -119,6 +119,23 @@ def make_features(seed, n, hf, wf, scale=1.0):
     return (torch.rand(n, D_MODEL, hf, wf, generator=g) - 0.5) * scale
 
 
+def make_masks(seed, n, hf, wf, kind='pad'):
+    """Synthetic forward_dummy masks [n,hf,wf] (float 0/1) like a padded batch's
+    (``resize_mask``, src/model.py:256-258): kind 'pad' = image i's valid region is
+    its top-left hv x wv corner (hv, wv drawn per image, at least half of the grid,
+    image 0 fully valid); 'holes' = 'pad' with ~10 % of the valid tokens cleared as
+    well (masks need not be rectangles: the reference only multiplies by them)."""
+    g = torch.Generator().manual_seed(int(seed))
+    m = torch.zeros(n, hf, wf)
+    for i in range(n):
+        hv = hf if i == 0 else int(torch.randint((hf + 1) // 2, hf + 1, (1,), generator=g))
+        wv = wf if i == 0 else int(torch.randint((wf + 1) // 2, wf + 1, (1,), generator=g))
+        m[i, :hv, :wv] = 1.0
+    if kind == 'holes':
+        m = m * (torch.rand(n, hf, wf, generator=g) >= 0.1).float()
+    return m
+
+
 def checksum(t):
     """Exact, machine-independent fingerprint of an fp32 tensor: integer sums
     over the IEEE bit patterns (int64 wrap-around arithmetic is associative,
@@ -231,14 +248,20 @@ def position_table(hf, wf, d_model=D_MODEL, dtype=torch.float32):
 # --------------------------------------------------------------------------
 # attention kernels (reference src/models/linear_attention.py)
 # --------------------------------------------------------------------------
-def linear_attention(q, k, v, eps=ATTN_EPS):
-    """q [N,L,H,D], k,v [N,S,H,D] -> [N,L,H,D].  linear_attention.py:22-50
-    with masks None: phi = elu+1 (:12-13), v/S (:44), KV = sum_s phi(k) v
-    (:45), Z = 1/(phi(q).sum_s phi(k) + eps) (:46), out = phi(q) KV Z * S
-    (:47-48)."""
+def linear_attention(q, k, v, eps=ATTN_EPS, q_mask=None, kv_mask=None):
+    """q [N,L,H,D], k,v [N,S,H,D] -> [N,L,H,D].  linear_attention.py:22-50:
+    phi = elu+1 (:12-13), the optional masks q_mask [N,L] / kv_mask [N,S]
+    MULTIPLY phi(q) / phi(k) and v (:37-41 - "set padded position to zero"),
+    v/S with S the full source length (:43-44), KV = sum_s phi(k) v (:45),
+    Z = 1/(phi(q).sum_s phi(k) + eps) (:46), out = phi(q) KV Z * S (:47-48)."""
     S = v.shape[1]
     fq = F.elu(q) + 1
     fk = F.elu(k) + 1
+    if q_mask is not None:
+        fq = fq * q_mask[:, :, None, None]
+    if kv_mask is not None:
+        fk = fk * kv_mask[:, :, None, None]
+        v = v * kv_mask[:, :, None, None]
     vs = v / S
     kv = torch.einsum('nshd,nshv->nhdv', fk, vs)
     z = 1 / (torch.einsum('nlhd,nhd->nlh', fq, fk.sum(dim=1)) + eps)
@@ -265,32 +288,38 @@ def _heads(t):
 # --------------------------------------------------------------------------
 # encoder / decoder (reference src/models/transformer.py)
 # --------------------------------------------------------------------------
-def encoder_layer(x, src, x_pos, s_pos, w, p, attention=linear_attention):
+def encoder_layer(x, src, x_pos, s_pos, w, p, attention=linear_attention,
+                  x_mask=None, source_mask=None):
     """transformer.py:104-142.  q = LN_q(x)+x_pos; k = v = LN_kv(src)+s_pos
     (V also receives the position term, :123-126); bias-free projections;
-    attention; merge; x += msg; x += W2 gelu_erf(W1 LN2(x))."""
+    attention(q_mask=x_mask, kv_mask=source_mask) (:131-136); merge;
+    x += msg; x += W2 gelu_erf(W1 LN2(x))."""
     q = _ln(x, w, p + 'pre_norm_q') + x_pos
     kv = _ln(src, w, p + 'pre_norm_kv') + s_pos
     Q = _heads(F.linear(q, w[p + 'q_proj.weight']))
     K = _heads(F.linear(kv, w[p + 'k_proj.weight']))
     V = _heads(F.linear(kv, w[p + 'v_proj.weight']))
-    msg = attention(Q, K, V).reshape(x.shape)
+    if x_mask is None and source_mask is None:
+        msg = attention(Q, K, V).reshape(x.shape)
+    else:
+        msg = attention(Q, K, V, q_mask=x_mask, kv_mask=source_mask).reshape(x.shape)
     x = x + F.linear(msg, w[p + 'merge.weight'])
     h = F.gelu(F.linear(_ln(x, w, p + 'norm2'), w[p + 'mlp.0.weight']))
     return x + F.linear(h, w[p + 'mlp.2.weight'])
 
 
-def _mha(q, k, v, w, p):
+def _mha(q, k, v, w, p, kv_mask=None):
     """MultiHeadAttention, transformer.py:55-72: biased q/k/v projections,
-    linear attention, bias-free merge."""
+    linear attention (kv_mask: the decoder's memory_mask, :244-249; its q_mask
+    = tgt_mask is always None, :361-381), bias-free merge."""
     Q = _heads(F.linear(q, w[p + 'q_proj.weight'], w[p + 'q_proj.bias']))
     K = _heads(F.linear(k, w[p + 'k_proj.weight'], w[p + 'k_proj.bias']))
     V = _heads(F.linear(v, w[p + 'v_proj.weight'], w[p + 'v_proj.bias']))
-    out = linear_attention(Q, K, V).reshape(q.shape)
+    out = linear_attention(Q, K, V, kv_mask=kv_mask).reshape(q.shape)
     return F.linear(out, w[p + 'merge.weight'])
 
 
-def decoder_layer(tgt, memory, tgt_pos, m_pos, w, p):
+def decoder_layer(tgt, memory, tgt_pos, m_pos, w, p, memory_mask=None):
     """transformer.py:224-255 in eval mode (dropouts are identity):
     self-attention on the query token (q = k = LN1(tgt)+tgt_pos, v = LN1(tgt));
     cross-attention with k = memory+m_pos and v = memory - NO position on v
@@ -300,24 +329,26 @@ def decoder_layer(tgt, memory, tgt_pos, m_pos, w, p):
     tgt = tgt + _mha(qk, qk, t2, w, p + 'self_attn.')
     t2 = _ln(tgt, w, p + 'norm2')
     tgt = tgt + _mha(t2 + tgt_pos, memory + m_pos, memory, w,
-                     p + 'multihead_attn.')
+                     p + 'multihead_attn.', kv_mask=memory_mask)
     t2 = _ln(tgt, w, p + 'norm3')
     t2 = F.linear(F.relu(F.linear(t2, w[p + 'mlp.0.weight'])),
                   w[p + 'mlp.2.weight'])
     return tgt + t2
 
 
-def encoder_stack(x1, x2, p1, p2, w, n_layers=N_ENC, attention=linear_attention):
+def encoder_stack(x1, x2, p1, p2, w, n_layers=N_ENC, attention=linear_attention,
+                  mask1=None, mask2=None):
     """transformer.py:349-358: even layers self, odd layers cross; in a cross
-    layer both images read the other's PRE-update features (:354-356)."""
+    layer both images read the other's PRE-update features (:354-356).
+    mask1 / mask2 [N,L1] / [N,L2] (flattened, :340-343) or None."""
     for i in range(n_layers):
         p = f'transformer.encoder.{i}.'
         if i % 2 == 0:
-            x1 = encoder_layer(x1, x1, p1, p1, w, p, attention)
-            x2 = encoder_layer(x2, x2, p2, p2, w, p, attention)
+            x1 = encoder_layer(x1, x1, p1, p1, w, p, attention, mask1, mask1)
+            x2 = encoder_layer(x2, x2, p2, p2, w, p, attention, mask2, mask2)
         else:
-            y1 = encoder_layer(x1, x2, p1, p2, w, p, attention)
-            y2 = encoder_layer(x2, x1, p2, p1, w, p, attention)
+            y1 = encoder_layer(x1, x2, p1, p2, w, p, attention, mask1, mask2)
+            y2 = encoder_layer(x2, x1, p2, p1, w, p, attention, mask2, mask1)
             x1, x2 = y1, y2
     return x1, x2
 
@@ -328,21 +359,28 @@ def tokens(t_nchw):
 
 
 def feature_correlation(feat1, feat2, pos1, pos2, w, n_enc_layers=N_ENC,
-                        attention=linear_attention):
+                        attention=linear_attention, mask1=None, mask2=None):
     """model.py:132-143 -> QueryTransformer.forward, transformer.py:313-383.
-    Returns hs1, hs2 [N,1,C] and memory1 [N,L1,C], memory2 [N,L2,C]."""
+    Returns hs1, hs2 [N,1,C] and memory1 [N,L1,C], memory2 [N,L2,C].
+    mask1 / mask2 [N,hf,wf] (any numeric type; flattened :340-343): x_mask /
+    source_mask of every encoder layer (:349-358) and memory_mask of the
+    decoder's cross-attention (:361-381)."""
     x1, x2 = tokens(feat1), tokens(feat2)
     p1, p2 = tokens(pos1), tokens(pos2)
     n = x1.shape[0]
-    x1, x2 = encoder_stack(x1, x2, p1, p2, w, n_enc_layers, attention)
+    if mask1 is not None:
+        mask1 = mask1.flatten(1)
+    if mask2 is not None:
+        mask2 = mask2.flatten(1)
+    x1, x2 = encoder_stack(x1, x2, p1, p2, w, n_enc_layers, attention, mask1, mask2)
     hs = []
-    for mem, mpos, qe in ((x1, p1, w['query_embed1.weight']),
-                          (x2, p2, w['query_embed2.weight'])):
+    for mem, mpos, qe, mm in ((x1, p1, w['query_embed1.weight'], mask1),
+                              (x2, p2, w['query_embed2.weight'], mask2)):
         qpos = qe.unsqueeze(0).repeat(n, 1, 1)
         tgt = torch.zeros_like(qpos)
         for i in range(N_DEC):
             tgt = decoder_layer(tgt, mem, qpos, mpos, w,
-                                f'transformer.decoder.layers.{i}.')
+                                f'transformer.decoder.layers.{i}.', mm)
         hs.append(tgt)
     return hs[0], hs[1], x1, x2
 
@@ -380,11 +418,21 @@ def soft_argmax(logits, hf, wf, img_h):
     return (prob * coord).sum(1)                               # [N,2] (x,y)
 
 
+MASK_FILL = -1e9   # model.py:22 (INF = 1e9), :166-171
+
+
+def mask_logits(logits, mask):
+    """model.py:166-171: ``heatmap_flatten.masked_fill_(~mask.flatten(1).bool(), -INF)``."""
+    if mask is None:
+        return logits
+    return logits.masked_fill(~mask.flatten(1).bool(), MASK_FILL)
+
+
 def center_estimation(hs1, hs2, memory1, memory2, hf1, wf1, hf2, wf2,
-                      img_h1, img_h2, w):
-    """model.py:145-186 with masks None."""
-    c1 = soft_argmax(heatmap_logits(hs1, memory1, hf1, wf1, w), hf1, wf1, img_h1)
-    c2 = soft_argmax(heatmap_logits(hs2, memory2, hf2, wf2, w), hf2, wf2, img_h2)
+                      img_h1, img_h2, w, mask1=None, mask2=None):
+    """model.py:145-186."""
+    c1 = soft_argmax(mask_logits(heatmap_logits(hs1, memory1, hf1, wf1, w), mask1), hf1, wf1, img_h1)
+    c2 = soft_argmax(mask_logits(heatmap_logits(hs2, memory2, hf2, wf2, w), mask2), hf2, wf2, img_h2)
     return c1, c2
 
 
@@ -440,9 +488,11 @@ def cast_weights(w, dtype):
 
 @torch.no_grad()
 def hot_path(feat1, feat2, w, img_hw1, img_hw2, pos1=None, pos2=None,
-             return_stages=False, attention=None):
+             return_stages=False, attention=None, mask1=None, mask2=None):
     """feat [N,256,hf,wf] -> (box1, box2) [N,4] xyxy pixels, following
-    OETR.forward_dummy after feature_extraction (model.py:239-252)."""
+    OETR.forward_dummy after feature_extraction (model.py:239-252); mask1 /
+    mask2 [N,hf,wf] = forward_dummy's optional masks (:229).  With masks the
+    `logits` stage holds the filled values (-1e9 at masked tokens)."""
     dtype = feat1.dtype
     hf1, wf1 = feat1.shape[2:]
     hf2, wf2 = feat2.shape[2:]
@@ -451,9 +501,10 @@ def hot_path(feat1, feat2, w, img_hw1, img_hw2, pos1=None, pos2=None,
     if pos2 is None:
         pos2 = position_table(hf2, wf2, dtype=dtype)
     hs1, hs2, m1, m2 = feature_correlation(feat1, feat2, pos1, pos2, w,
-                                           attention=attention or linear_attention)
-    lg1 = heatmap_logits(hs1, m1, hf1, wf1, w)
-    lg2 = heatmap_logits(hs2, m2, hf2, wf2, w)
+                                           attention=attention or linear_attention,
+                                           mask1=mask1, mask2=mask2)
+    lg1 = mask_logits(heatmap_logits(hs1, m1, hf1, wf1, w), mask1)
+    lg2 = mask_logits(heatmap_logits(hs2, m2, hf2, wf2, w), mask2)
     c1 = soft_argmax(lg1, hf1, wf1, img_hw1[0])
     c2 = soft_argmax(lg2, hf2, wf2, img_hw2[0])
     t1, t2 = size_regression(hs1, w), size_regression(hs2, w)

@@ -23,7 +23,7 @@ def header_functions():
 def test_library_exports_every_declared_symbol():
     lib = pkg.load_library()
     names = header_functions()
-    assert len(names) == 43, names
+    assert len(names) == 46, names
     assert set(names) == set(hip_engine.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/oetr_hip.h but not exported'
@@ -93,8 +93,14 @@ def test_product_path_has_no_cpu_fallback():
     img = torch.rand(1, 64, 64, 3)
     with pytest.raises(RuntimeError, match='GPU'):
         model.forward_dummy(img, img)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match='both mask1 and mask2'):      # masks: both or neither
         model.forward_dummy(img, img, mask1=torch.ones(1, 2, 2))
+    with pytest.raises(RuntimeError, match='GPU'):                      # ... and no CPU route with them either
+        model.forward_dummy(img, img, mask1=torch.ones(1, 2, 2), mask2=torch.ones(1, 2, 2))
+    model.hip_precision = 'bf16'
+    with pytest.raises(NotImplementedError, match='masks'):             # built for the default arithmetic
+        model.forward_dummy(img, img, mask1=torch.ones(1, 2, 2), mask2=torch.ones(1, 2, 2))
+    model.hip_precision = 'f32_split_f16'
     with torch.no_grad(), pytest.raises(KeyError):   # training forward: needs the reference's data keys
         model({'image1': img})
     with pytest.raises(ValueError):

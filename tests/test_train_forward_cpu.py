@@ -54,7 +54,12 @@ def test_forward_contract_without_a_gpu():
         with pytest.raises(NotImplementedError, match='no backward'):
             model(data)                   # autograd on: no graph-less losses by accident
     with torch.no_grad():
+        with pytest.raises(RuntimeError):     # masks (reference model.py:256-258) go the same way: no CPU route
+            model.eval()(dict(data, resize_mask1=torch.ones(1, 2, 2), resize_mask2=torch.ones(1, 2, 2)))
+        model.hip_attention = 'full'
         with pytest.raises(NotImplementedError, match='masks'):
             model(dict(data, resize_mask1=torch.ones(1, 2, 2), resize_mask2=torch.ones(1, 2, 2)))
+        model.hip_attention = 'linear'
+        model.train()
         with pytest.raises(RuntimeError):     # CPU tensors: the hot path has no CPU implementation
             model.eval()(data)
