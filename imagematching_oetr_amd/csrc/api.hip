@@ -968,12 +968,20 @@ size_t oetr_linear_attention_workspace_bytes(int n) {
 oetr_status oetr_linear_attention(const float* q, const float* k, const float* v, int n, int L,
                                   int S, float* out, void* workspace, size_t workspace_bytes,
                                   void* stream) {
+  return oetr_linear_attention_masked(q, k, v, nullptr, nullptr, n, L, S, out, workspace, workspace_bytes,
+                                      stream);
+}
+
+oetr_status oetr_linear_attention_masked(const float* q, const float* k, const float* v,
+                                         const float* q_mask, const float* kv_mask, int n, int L, int S,
+                                         float* out, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
   if (!q || !k || !v || !out || n <= 0 || L <= 0 || S <= 0)
     return fail(OETR_ERR_BAD_ARG, "oetr_linear_attention: bad argument");
   if (!workspace || workspace_bytes < oetr_linear_attention_workspace_bytes(n))
     return fail(OETR_ERR_WORKSPACE, "oetr_linear_attention: workspace smaller than "
                                     "oetr_linear_attention_workspace_bytes(n)");
-  HIP_TRY(launch_linear_attention(q, k, v, n, L, S, out, static_cast<float*>(workspace),
+  HIP_TRY(launch_linear_attention(q, k, v, q_mask, kv_mask, n, L, S, out, static_cast<float*>(workspace),
                                   static_cast<hipStream_t>(stream)));
   return OETR_OK;
 }

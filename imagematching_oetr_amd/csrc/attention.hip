@@ -17,8 +17,11 @@ namespace oetr {
 
 // ------------------------------------------------------------------ linear
 // one block per (n, h): KV[d][v] = sum_s phi(K[s,d]) * V[s,v]/S ; Ksum[d]
+// kv_mask [n][S] / q_mask [n][L] (linear_attention.py:37-41) or NULL: a token's value multiplies its
+// phi(K) and V rows / its phi(Q) row (x 1.0f without a mask: the same bits as before)
 __global__ __launch_bounds__(256) void k_lin_state(const float* __restrict__ k,
-                                                   const float* __restrict__ v, int S,
+                                                   const float* __restrict__ v,
+                                                   const float* __restrict__ kv_mask, int S,
                                                    float* __restrict__ state) {
   __shared__ float ks[64][HD + 1], vs[64][HD + 1];
   const int tid = threadIdx.x, nh = blockIdx.x, n = nh / NH, h = nh % NH;
@@ -28,8 +31,9 @@ __global__ __launch_bounds__(256) void k_lin_state(const float* __restrict__ k,
     for (int i = tid; i < 64 * HD; i += 256) {
       const int sl = i >> 5, c = i & 31, s = s0 + sl;
       const size_t off = (((size_t)n * S + s) * NH + h) * HD + c;
-      ks[sl][c] = s < S ? elu1(k[off]) : 0.f;
-      vs[sl][c] = s < S ? v[off] / (float)S : 0.f;
+      const float mk = (kv_mask != nullptr && s < S) ? kv_mask[(size_t)n * S + s] : 1.0f;
+      ks[sl][c] = s < S ? elu1(k[off]) * mk : 0.f;
+      vs[sl][c] = s < S ? (v[off] * mk) / (float)S : 0.f;
     }
     __syncthreads();
     for (int sl = 0; sl < 64; ++sl) {
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(256) void k_lin_state(const float* __restrict__ k,
 
 // one block per (n, h, 64 queries)
 __global__ __launch_bounds__(256) void k_lin_apply(const float* __restrict__ q,
-                                                   const float* __restrict__ state, int L, int S,
+                                                   const float* __restrict__ state,
+                                                   const float* __restrict__ q_mask, int L, int S,
                                                    float* __restrict__ out) {
   __shared__ float kv[HD][HD + 1], ksum[HD];
   const int tid = threadIdx.x, nh = blockIdx.y, n = nh / NH, h = nh % NH;
@@ -60,8 +65,9 @@ __global__ __launch_bounds__(256) void k_lin_apply(const float* __restrict__ q,
   if (l >= L) return;
   const size_t off = (((size_t)n * L + l) * NH + h) * HD;
   float fq[HD], z = 0.f;
+  const float mq = q_mask != nullptr ? q_mask[(size_t)n * L + l] : 1.0f;
 #pragma unroll
-  for (int dd = 0; dd < HD; ++dd) { fq[dd] = elu1(q[off + dd]); z += fq[dd] * ksum[dd]; }
+  for (int dd = 0; dd < HD; ++dd) { fq[dd] = elu1(q[off + dd]) * mq; z += fq[dd] * ksum[dd]; }
   z = 1.0f / (z + ATTN_EPS);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -73,10 +79,11 @@ __global__ __launch_bounds__(256) void k_lin_apply(const float* __restrict__ q,
 }
 
 // `state`: caller-provided n*8 states of 1056 floats between the two kernels
-hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n, int L,
-                                   int S, float* out, float* state, hipStream_t s) {
-  hipLaunchKernelGGL(k_lin_state, dim3(n * NH), dim3(256), 0, s, k, v, S, state);
-  hipLaunchKernelGGL(k_lin_apply, dim3((L + 63) / 64, n * NH), dim3(256), 0, s, q, state, L, S, out);
+hipError_t launch_linear_attention(const float* q, const float* k, const float* v, const float* q_mask,
+                                   const float* kv_mask, int n, int L, int S, float* out, float* state,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL(k_lin_state, dim3(n * NH), dim3(256), 0, s, k, v, kv_mask, S, state);
+  hipLaunchKernelGGL(k_lin_apply, dim3((L + 63) / 64, n * NH), dim3(256), 0, s, q, state, q_mask, L, S, out);
   return hipGetLastError();
 }
 

@@ -1350,8 +1350,9 @@ hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s);
 int neck_conv_rows(int M, int items_per_mt, int num_cus, int max_rows);
 hipError_t launch_neck_out(const NeckOutLaunch& p, hipStream_t s);
 
-hipError_t launch_linear_attention(const float* q, const float* k, const float* v, int n,
-                                   int L, int S, float* out, float* state, hipStream_t s);
+hipError_t launch_linear_attention(const float* q, const float* k, const float* v, const float* q_mask,
+                                   const float* kv_mask, int n, int L, int S, float* out, float* state,
+                                   hipStream_t s);
 hipError_t launch_full_attention(const float* q, const float* k, const float* v, int n,
                                  int L, int S, float* out, hipStream_t s);
 hipError_t launch_full_attention_split(const float* q, const float* k, const float* v, int n,

@@ -86,7 +86,8 @@ EXPORTS = (
     'oetr_token_buffers', 'oetr_forward_tokens', 'oetr_neck_forward_tokens',
     'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async',
     'oetr_set_state_prereduce', 'oetr_set_tail_mode', 'oetr_set_decoder_split', 'oetr_overlap_frame', 'oetr_read_overlap_image',
-    'oetr_forward_masked', 'oetr_feature_correlation_masked', 'oetr_center_estimation_masked')
+    'oetr_forward_masked', 'oetr_feature_correlation_masked', 'oetr_center_estimation_masked',
+    'oetr_linear_attention_masked')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 FLAG_EXCHANGE = 2    # OETR_FLAG_EXCHANGE: the split decoder's workgroups were not resident together
@@ -190,6 +191,8 @@ def load_library(path=None):
     lib.oetr_linear_attention.argtypes = [vp, vp, vp, i, i, i, vp, vp, sz, vp]
     lib.oetr_linear_attention_workspace_bytes.restype = sz
     lib.oetr_linear_attention_workspace_bytes.argtypes = [i]
+    lib.oetr_linear_attention_masked.restype = i
+    lib.oetr_linear_attention_masked.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp, vp, sz, vp]
     lib.oetr_full_attention_split.restype = i
     lib.oetr_full_attention_split.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
     lib.oetr_trace_create.restype = i
@@ -988,10 +991,35 @@ def _attention(fn_name, q, k, v):
     return out
 
 
-def linear_attention(q, k, v):
+def linear_attention(q, k, v, q_mask=None, kv_mask=None):
     """HIP version of reference ``LinearAttention.forward``
-    (``src/models/linear_attention.py:22-50``)."""
-    return _attention('oetr_linear_attention', q, k, v)
+    (``src/models/linear_attention.py:22-50``; ``q_mask`` [N,L] / ``kv_mask`` [N,S] as there,
+    either may be None)."""
+    if q_mask is None and kv_mask is None:
+        return _attention('oetr_linear_attention', q, k, v)
+    lib = load_library()
+    q, k, v = _dev(q, 'q'), _dev(k, 'k'), _dev(v, 'v')
+    n, L, h, d = q.shape
+    S = int(k.shape[1])
+    if (h, d) != (N_HEAD, D_MODEL // N_HEAD) or k.shape != (n, S, h, d) or v.shape != k.shape:
+        raise ValueError('attention expects q [N,L,8,32], k,v [N,S,8,32]')
+    masks = []
+    for m, length, name in ((q_mask, L, 'q_mask'), (kv_mask, S, 'kv_mask')):
+        if m is not None:
+            m = m.to(device=q.device, dtype=torch.float32).contiguous()
+            if tuple(m.shape) != (n, length):
+                raise ValueError(f'{name} must be [{n},{length}], got {tuple(m.shape)}')
+        masks.append(m)
+    out = torch.empty_like(q)
+    ws = torch.empty(lib.oetr_linear_attention_workspace_bytes(n), dtype=torch.uint8, device=q.device)
+    with torch.cuda.device(q.device):
+        _check(lib, lib.oetr_linear_attention_masked(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            masks[0].data_ptr() if masks[0] is not None else None,
+            masks[1].data_ptr() if masks[1] is not None else None,
+            n, L, S, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q.device)),
+            'oetr_linear_attention_masked')
+    return out
 
 
 FULL_ATTENTION_VARIANTS = ('f32', 'f32_split_f16')

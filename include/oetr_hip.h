@@ -43,7 +43,7 @@ extern "C" {
  *    decoder's call counters and exchange granules live there: oetr_set_decoder_split);
  *    OETR_FLAG_EXCHANGE
  * 4: forward_dummy's optional masks: oetr_forward_masked, oetr_feature_correlation_masked,
- *    oetr_center_estimation_masked (new exports; nothing else changed) */
+ *    oetr_center_estimation_masked, oetr_linear_attention_masked (new exports; nothing else changed) */
 #define OETR_ABI_VERSION 4
 #define OETR_D_MODEL 256
 #define OETR_N_HEAD 8
@@ -405,6 +405,14 @@ oetr_status oetr_linear_attention(const float *q, const float *k,
                                   const float *v, int n, int L, int S,
                                   float *out, void *workspace,
                                   size_t workspace_bytes, void *stream);
+
+/* ... with LinearAttention.forward's q_mask [N][L] / kv_mask [N][S] (:37-41; device floats, either
+ * may be NULL as in the reference): a token's value multiplies its phi(Q) row / its phi(K) and V rows. */
+oetr_status oetr_linear_attention_masked(const float *q, const float *k,
+                                         const float *v, const float *q_mask,
+                                         const float *kv_mask, int n, int L,
+                                         int S, float *out, void *workspace,
+                                         size_t workspace_bytes, void *stream);
 
 /* Replaces: FullAttention.forward (reference
  * src/models/linear_attention.py:53-87), no mask/dropout - the optional

@@ -136,3 +136,34 @@ def test_masked_seams_and_module(gpu):
     u1, _ = model.forward_dummy(img1, img2)
     model.hip_flush()
     assert maxerr(u1, b1) > 1e-2        # the masks moved the boxes
+
+
+def test_masked_linear_attention_entry_vs_reference_golden(gpu, golden_dir):
+    """oetr_linear_attention_masked (LinearAttention.forward with q_mask / kv_mask) against the
+    reference's own outputs; either mask alone; no mask = the unmasked entry bit for bit."""
+    from imagematching_oetr_amd import hip_engine
+    g = np.load(golden_dir / 'attention_masked.npz')
+    for (L, S) in g['cases']:
+        tag = f'L{L}_S{S}'
+        gen = torch.Generator().manual_seed(int(g[tag + '_seed']))
+        q = (torch.rand(2, L, 8, 32, generator=gen) - 0.5) * 4
+        k = (torch.rand(2, S, 8, 32, generator=gen) - 0.5) * 4
+        v = (torch.rand(2, S, 8, 32, generator=gen) - 0.5) * 2
+        qm = (torch.rand(2, L, generator=gen) >= 0.25).float()
+        km = (torch.rand(2, S, generator=gen) >= 0.25).float()
+        km[0] = 1.0
+        dq, dk, dv = q.to(gpu), k.to(gpu), v.to(gpu)
+        out = hip_engine.linear_attention(dq, dk, dv, q_mask=qm, kv_mask=km).reshape(2, L, 256)
+        step = int(g[tag + '_step'])
+        ref = torch.from_numpy(g[tag + '_lin'])
+        err = (out[:, ::step].cpu() - ref).abs()
+        assert (err <= 2e-5 + 1e-5 * ref.abs()).all(), f'{tag}: {float(err.max()):.3e}'
+        assert (out[qm.to(gpu) == 0] == 0).all()
+        only_q = hip_engine.linear_attention(dq, dk, dv, q_mask=qm)
+        full = orc.linear_attention(q, k, v, q_mask=qm)
+        assert maxerr(only_q, full) <= 2e-5 * max(1.0, float(full.abs().max()))
+        only_kv = hip_engine.linear_attention(dq, dk, dv, kv_mask=km.bool())
+        fullk = orc.linear_attention(q, k, v, kv_mask=km)
+        assert maxerr(only_kv, fullk) <= 2e-5 * max(1.0, float(fullk.abs().max()))
+        ones = hip_engine.linear_attention(dq, dk, dv, q_mask=torch.ones(2, L), kv_mask=torch.ones(2, S))
+        assert torch.equal(ones, hip_engine.linear_attention(dq, dk, dv))
