@@ -133,15 +133,21 @@ class BoxGatherer:
 
 
 @torch.no_grad()
-def forward_sharded(model, image1, image2, group=None):
+def forward_sharded(model, image1, image2, group=None, mask1=None, mask2=None):
     """``model.forward_dummy`` on this rank's contiguous shard of the batch,
-    then the box all-gather: every rank returns boxes for ALL pairs."""
+    then the box all-gather: every rank returns boxes for ALL pairs.
+    ``mask1`` / ``mask2``: forward_dummy's optional masks [N,hf,wf], sharded with the images."""
     n = image1.shape[0]
     if dist.is_available() and dist.is_initialized():
         lo, hi = shard_bounds(n, dist.get_rank(group), dist.get_world_size(group))
     else:
         lo, hi = 0, n
-    b1, b2 = model.forward_dummy(image1[lo:hi], image2[lo:hi])
+    if mask1 is not None or mask2 is not None:
+        if mask1 is None or mask2 is None:
+            raise ValueError('masks: pass both mask1 and mask2, or neither')
+        b1, b2 = model.forward_dummy(image1[lo:hi], image2[lo:hi], mask1[lo:hi], mask2[lo:hi])
+    else:
+        b1, b2 = model.forward_dummy(image1[lo:hi], image2[lo:hi])
     # forward_dummy defers its f16 range check and corrects a tripped batch IN PLACE later
     # (OETR.hip_defer_check): settle it before the boxes are copied to the other ranks
     flush = getattr(model, 'hip_flush', None)

@@ -175,10 +175,14 @@ class _StubModel:
                 t.copy_(good)
             self._pending = None
 
-    def forward_dummy(self, image1, image2):
+    def forward_dummy(self, image1, image2, mask1=None, mask2=None):
         self.hip_flush()
         m1 = image1.reshape(image1.shape[0], -1).mean(1, keepdim=True)
         m2 = image2.reshape(image2.shape[0], -1).mean(1, keepdim=True)
+        if mask1 is not None:     # masks travel with their pairs: observable in the boxes
+            assert mask1.shape[0] == image1.shape[0] and mask2.shape[0] == image2.shape[0]
+            m1 = m1 + 10.0 * mask1.reshape(mask1.shape[0], -1).float().sum(1, keepdim=True)
+            m2 = m2 + 10.0 * mask2.reshape(mask2.shape[0], -1).float().sum(1, keepdim=True)
         k = torch.arange(4, dtype=torch.float32)
         good = (m1 + k, m2 - k)
         out = tuple(torch.full_like(t, 7.0e4) for t in good)      # "overflowed" until settled
@@ -195,7 +199,10 @@ def _sharded_worker(rank, world, port, n_pairs, q):
         im1 = torch.rand(n_pairs, 6, 5, 3, generator=g)
         im2 = torch.rand(n_pairs, 4, 7, 3, generator=g)
         b1, b2 = forward_sharded(_StubModel(), im1, im2)
-        q.put((rank, b1.tolist(), b2.tolist()))
+        mk1 = (torch.arange(n_pairs * 6).reshape(n_pairs, 2, 3) % 5 > 1)
+        mk2 = (torch.arange(n_pairs * 4).reshape(n_pairs, 2, 2) % 3 > 0)
+        c1, c2 = forward_sharded(_StubModel(), im1, im2, mask1=mk1, mask2=mk2)
+        q.put((rank, b1.tolist(), b2.tolist(), c1.tolist(), c2.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -223,8 +230,14 @@ def test_forward_sharded_world2_gloo(n_pairs):
     e1, e2 = ref.forward_dummy(im1, im2)
     ref.hip_flush()
     assert float(e1.abs().max()) < 100.0      # settled values
-    for rank, b1, b2 in results:
+    mk1 = (torch.arange(n_pairs * 6).reshape(n_pairs, 2, 3) % 5 > 1)
+    mk2 = (torch.arange(n_pairs * 4).reshape(n_pairs, 2, 2) % 3 > 0)
+    f1, f2 = ref.forward_dummy(im1, im2, mk1, mk2)
+    ref.hip_flush()
+    assert not torch.equal(f1, e1)
+    for rank, b1, b2, c1, c2 in results:
         assert torch.equal(torch.tensor(b1), e1) and torch.equal(torch.tensor(b2), e2), rank
+        assert torch.equal(torch.tensor(c1), f1) and torch.equal(torch.tensor(c2), f2), rank   # masked: sharded with the pairs
 
 
 def test_gather_is_identity_without_process_group():
