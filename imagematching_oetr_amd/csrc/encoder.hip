@@ -81,10 +81,11 @@ struct EncCfg {
 // == elu(x)+1 bit for bit) on scalars, four at a time between sched_barriers: as a select
 // hipcc branches per element (with whole-tuple copies when done in place), unfenced it
 // schedules all exps at once and spills.
-template <int MODE>
+// MASKED: see kv_state_64 - msk_s[row] = the token's kv_mask value, 0 past the last valid row.
+template <int MODE, bool MASKED = false>
 __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& accV, bool skip_phi,
                                             int S_len, int nvalid, int half, f32x16& kv,
-                                            float& ksum, Range& rg) {
+                                            float& ksum, Range& rg, const float* msk_s = nullptr) {
   const float inv_len = 1.0f / (float)S_len;
   kv = f32x16{0};
   ksum = 0.f;
@@ -93,7 +94,9 @@ __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& ac
     // r + 1 - phi, row mask, 1/S - are computed while the MFMA of register r runs (a fence per
     // step keeps hipcc from batching the exps; same operations in the same order: same bits).
     auto operands = [&](int r, float& k, float& v) {
-      const float m = crow(r, half) < nvalid ? 1.0f : 0.0f;
+      float m;
+      if constexpr (MASKED) m = msk_s[crow(r, half)];
+      else m = crow(r, half) < nvalid ? 1.0f : 0.0f;
       const float x = accK[r];
       k = (skip_phi ? x : elu1(x)) * m;
       v = accV[r] * (inv_len * m);
@@ -114,17 +117,18 @@ __device__ __forceinline__ void kv_state_32(const f32x16& accK, const f32x16& ac
 
 // phi(K)^T (V/S) for this wave's heads straight from the K and V accumulators,
 // plus sum_s phi(K); stores the per-tile partial states.
-template <int MODE, int NT>
+template <int MODE, int NT, bool MASKED = false>
 __device__ __forceinline__ void kv_state_store(f32x16 (&accK)[NT], f32x16 (&accV)[NT],
                                                bool skip_phi, int S_len, int nvalid, int lane,
                                                int wave, float* __restrict__ kv_out,
-                                               float* __restrict__ ks_out, int slot, Range& rg) {
+                                               float* __restrict__ ks_out, int slot, Range& rg,
+                                               const float* msk_s = nullptr) {
   const int half = lane >> 5;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float ksum;
     f32x16 kv;
-    kv_state_32<MODE>(accK[t], accV[t], skip_phi, S_len, nvalid, half, kv, ksum, rg);
+    kv_state_32<MODE, MASKED>(accK[t], accV[t], skip_phi, S_len, nvalid, half, kv, ksum, rg, msk_s);
     const int h = NT * wave + t;
     f32x4* dst = reinterpret_cast<f32x4*>(kv_out) + ((size_t)slot * NH + h) * 4 * 64 + lane;
 #pragma unroll
@@ -423,8 +427,11 @@ __device__ __forceinline__ void stage_ln_params(float* lnp_s, const EncLaunch& p
   }
 }
 
-template <bool HAS_B, int TAIL, int MODE, int NW, bool FULL = false, int POL = 0>
+// MASKED (forward_dummy's masks, see encoder64_body): instantiated for the exact-fp32 build - the
+// route a masked batch is re-run on when the default arithmetic reports an operand out of range.
+template <bool HAS_B, int TAIL, int MODE, int NW, bool FULL = false, int POL = 0, bool MASKED = false>
 __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
+  static_assert(!MASKED || !FULL, "masks: linear attention only");
   constexpr bool SPLIT = gm_half(MODE);  // GEMM operands live in 16-bit LDS planes
   using SP = SitePolicy<POL>;            // arithmetic per GEMM site (two-plane mode, NW = 8)
   static_assert(POL == 0 || (gm_planes(MODE) == 2 && NW == 8 && !FULL), "policies: split mode, one n-tile per wave");
@@ -703,6 +710,12 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
 
   const f32x4* pos = reinterpret_cast<const f32x4*>(
                          p.pos + (size_t)(g.prow0[side] + l0 + min(lrow, nvalid - 1)) * C) + lpart;
+  // (MASKED: the tile's mask values in the normaliser buffer, which phase B is done with; a
+  //  barrier lies between this store and every read)
+  float* msk_s = z_s;
+  if constexpr (MASKED && TAIL != 2) {
+    if (tid < TM) msk_s[tid] = tid < nvalid ? p.mask[side][(size_t)n * L + l0 + tid] : 0.f;
+  }
   if (TAIL == 0) {
     // ================= phase A: start layer l+1 =================
     // q_in = LN_q(x)+pos -> S1 ; kv_in = LN_kv(x)+pos -> S2 (one set of row stats)
@@ -744,7 +757,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
         for (int r = 0; r < 16; ++r) {
           const int row = crow(r, half);
           if (row < nvalid && !ABL(p.dbg, ABL_STORE))
-            (p.qp + row_base * C + wcol + 32 * t)[(unsigned)(row * C + col)] = (FULL || ABL(p.dbg, ABL_ELU)) ? acc[t][r] : elu1(acc[t][r]);
+            (p.qp + row_base * C + wcol + 32 * t)[(unsigned)(row * C + col)] =
+                (FULL || ABL(p.dbg, ABL_ELU)) ? acc[t][r] : MASKED ? elu1(acc[t][r]) * msk_s[row] : elu1(acc[t][r]);
         }
     }
     PHASE_STAMP(p, 8);
@@ -770,7 +784,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
         *reinterpret_cast<f32x4*>(vt + 8 * g4) =
             f32x4{accV[0][4 * g4], accV[0][4 * g4 + 1], accV[0][4 * g4 + 2], accV[0][4 * g4 + 3]};
     } else if (!ABL(p.dbg, ABL_KVSTATE))
-    kv_state_store<MODE, NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.kv_out, p.ks_out, slot, rg);
+    kv_state_store<MODE, NT, MASKED>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.kv_out, p.ks_out, slot, rg, msk_s);
     PHASE_STAMP(p, 10);
     // (lnp_s[0] - a LayerNorm-2 weight of the layer just finished - is dead by now)
     if constexpr (!FULL) reduce_states_last_arriver<NT>(p, side, n, tid, lane, wave, reinterpret_cast<volatile int*>(lnp_s));
@@ -812,8 +826,8 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
                                                                        lane, accV, p.d.wk[1], p.d.wk_l[1],
                                                                        NT * wave, p.dbg);
       if constexpr (dl == 1) {
-        kv_state_store<MODE, NT>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.dkv1_out,
-                                 p.dks1_out, slot, rg);
+        kv_state_store<MODE, NT, MASKED>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.dkv1_out,
+                                         p.dks1_out, slot, rg, msk_s);
       } else {
         // Decoder layer 0's query is a create-time constant q0 (decoder.hip), and
         // its cross-attention is linear in the state, so this tile contributes
@@ -824,7 +838,7 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
           const int h = NT * wave + t;
           float ksum;
           f32x16 kv;
-          kv_state_32<MODE>(accK[t], accV[t], false, L, nvalid, half, kv, ksum, rg);
+          kv_state_32<MODE, MASKED>(accK[t], accV[t], false, L, nvalid, half, kv, ksum, rg, msk_s);
           const float* q0 = p.dec_q0 + side * C + h * HD;
           float a = 0.f;
 #pragma unroll
@@ -1493,6 +1507,21 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
         else return hipErrorInvalidValue;
       }
 #undef OETR_LAUNCHM
+      return hipGetLastError();
+    } else if constexpr (MODE == GM_F32) {
+      // exact fp32: round 1-3's 32-row kernel, 4 waves (the re-run route of a masked batch)
+      if (!p.mask[0] || !p.mask[1] || p.policy != 0 || p.attn_full) return hipErrorInvalidValue;
+#define OETR_LAUNCHMF(B, T) \
+  hipLaunchKernelGGL((k_encoder<B, T, MODE, OETR_F32_WAVES, false, 0, true>), grid, dim3(64 * OETR_F32_WAVES), 0, s, p)
+      if (has_b) {
+        if (tail == 0) OETR_LAUNCHMF(true, 0);
+        else if (tail == 1) OETR_LAUNCHMF(true, 1);
+        else OETR_LAUNCHMF(true, 2);
+      } else {
+        if (tail == 0) OETR_LAUNCHMF(false, 0);
+        else return hipErrorInvalidValue;
+      }
+#undef OETR_LAUNCHMF
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;

@@ -323,9 +323,9 @@ class OETR(nn.Module):
             return False
         if mask1 is None or mask2 is None:
             raise ValueError('masks: pass both mask1 and mask2, or neither')
-        if encoder and (self.hip_precision != 'f32_split_f16' or self.hip_attention != 'linear'):
+        if encoder and (self.hip_precision not in ('f32_split_f16', 'f32') or self.hip_attention != 'linear'):
             raise NotImplementedError(
-                "masks are built for hip_precision='f32_split_f16' with linear attention (the "
+                "masks are built for hip_precision='f32_split_f16' / 'f32' with linear attention (the "
                 "reference's FullAttention turns a masked query row into NaN, linear_attention.py:74-81); "
                 f"this model runs hip_precision='{self.hip_precision}', hip_attention='{self.hip_attention}'")
         return True
@@ -465,28 +465,23 @@ class OETR(nn.Module):
     def boxes_from_features(self, feat1, feat2, pos1, pos2, hw1, hw2, mask1=None, mask2=None):
         """Everything after ``feature_extraction`` (reference ``src/model.py:239-252``)
         as one fused HIP call, with the f16 range guard of the chosen precision (deferred
-        like ``forward_dummy``'s under ``hip_defer_check``).  With masks a tripped guard
-        raises whatever ``hip_on_overflow`` says: the exact-fp32 kernels carry no masks."""
-        masked = self._check_masks(mask1, mask2)
+        like ``forward_dummy``'s under ``hip_defer_check``; the exact-fp32 re-run carries the
+        masks too)."""
+        self._check_masks(mask1, mask2)
         self.hip_flush()
         eng = self.engine()
         boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
         if self.hip_on_overflow == 'ignore' or eng.precision not in eng.F16_RANGE:
             return boxes
-        if masked:
-            def rerun():
-                raise OetrRangeError('a GEMM operand reached |x| >= 65504 in a masked batch: the exact-fp32 '
-                                     're-run route carries no masks')
-        else:
-            rerun = lambda: self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2)
-        return self._range_checked(boxes, [eng.read_flags_async()], rerun)
+        return self._range_checked(boxes, [eng.read_flags_async()],
+                                   lambda: self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2, mask1, mask2))
 
-    def _exact_boxes(self, feat1, feat2, pos1, pos2, hw1, hw2):
+    def _exact_boxes(self, feat1, feat2, pos1, pos2, hw1, hw2, mask1=None, mask2=None):
         if self.hip_on_overflow == 'raise':
             raise OetrRangeError(
                 f"a GEMM operand reached |x| >= 65504 under hip_precision="
                 f"'{self.hip_precision}'; set hip_precision to 'f32' or 'bf16'")
-        return self.exact_engine().forward(feat1, feat2, pos1, pos2, hw1, hw2)
+        return self.exact_engine().forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
 
     def _boxes_checked(self, feat1, feat2, pos1, pos2, hw1, hw2):
         """Immediate (synchronising) form: the re-run route of a tripped fused batch."""
@@ -516,7 +511,7 @@ class OETR(nn.Module):
         mask1 = mask2 = None
         if 'resize_mask1' in data:       # reference model.py:256-258
             mask1, mask2 = data['resize_mask1'][valid], data['resize_mask2'][valid]
-        masked = self._check_masks(mask1, mask2)
+        self._check_masks(mask1, mask2)
         image1, image2 = data['image1'][valid], data['image2'][valid]
         h1, w1 = image1.shape[1:3]
         h2, w2 = image2.shape[1:3]
@@ -528,10 +523,11 @@ class OETR(nn.Module):
                              mask1=mask1, mask2=mask2)
             if self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE \
                     and eng.query_flags() & FLAG_INVALID:
-                if self.hip_on_overflow == 'raise' or masked:   # (the exact-fp32 kernels carry no masks)
+                if self.hip_on_overflow == 'raise':
                     raise OetrRangeError('a GEMM operand reached |x| >= 65504; use hip_precision "f32"')
                 eng = self.exact_engine()
-                st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True)
+                st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True,
+                                 mask1=mask1, mask2=mask2)
             xyxy1, xyxy2, cxywh1, cxywh2 = losses.obtain_overlap_bbox(
                 st['cxy1'], st['tlbr1'], st['cxy2'], st['tlbr2'], (h1, w1), (h2, w2))
             gt1 = data['overlap_box1'][valid].to(xyxy1.device)
