@@ -61,12 +61,15 @@ class ReadImage:
         self.frame = frame
 
 
-def read_overlap_images(images, device, resize=(640,), grayscale=True, align='disk'):
+def read_overlap_images(images, device, resize=(640,), grayscale=True, align='disk', rotation=0):
     """Decoded BGR images (``[H,W,3]`` uint8 / float32, numpy or torch, any sizes) -> list of
     :class:`ReadImage` on ``device``.  The bytes of ALL images go through one pinned staging
     buffer and one host-to-device copy; images whose OETR frames agree in size share one
     ``[n,H,W,3]`` batch tensor (``ReadImage.overlap_inp`` are its slots, in input order within
-    the group).  Enqueue-only on torch's current stream."""
+    the group).  ``rotation`` (reference ``utils.py:322-325``): the matcher picture ``inp`` - not the
+    OETR frame - is turned by k x 90 degrees counter-clockwise and an odd k swaps ``scales``
+    (a permutation of the finished picture on the device: same pixels).  Enqueue-only on torch's
+    current stream."""
     lib = load_library()
     device = torch.device(device)
     if device.type != 'cuda':
@@ -112,6 +115,10 @@ def read_overlap_images(images, device, resize=(640,), grayscale=True, align='di
                     fr['w_new'], fr['h_ov'], fr['w_ov'], int(bool(grayscale)), int(not align), tmp.data_ptr(), ov.data_ptr(),
                     inp.data_ptr(), _stream(device)), 'oetr_read_overlap_image')
                 keep.append(tmp)
+                if rotation % 4:
+                    inp = torch.rot90(inp, int(rotation), dims=(2, 3)).contiguous()
+                    if rotation % 2:
+                        fr = dict(fr, scales=fr['scales'][::-1])
                 res = ReadImage(ov, inp, fr)
                 res._batch, res._slot, res._keep = batches[key], slot, keep
                 out[i] = res

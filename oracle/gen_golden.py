@@ -447,6 +447,11 @@ READER_CASES = [
     ((657, 493), [640], '', False),          # colour, no alignment
     ((1280, 1280), [-1], 'disk', True),      # native-size OETR frame
     ((97, 61), [64], 'disk', False),         # small: pixels kept in the fixture
+    # rotation != 0 (utils.py:322-325): the MATCHER picture is turned by k x 90 degrees (np.rot90), an odd
+    # k swaps `scales`; the OETR frame is not rotated
+    ((83, 57), [64], 'disk', True, 1),
+    ((97, 61), [64], '', False, 3),
+    ((800, 600), [640], 'loftr', True, 2),
 ]
 
 
@@ -468,13 +473,15 @@ def gen_reader(out_dir):
     cv2.cvtColor = lambda img, code: rdo.bgr_to_gray(img)
     utils = importlib.import_module('dloc.core.utils.utils')
     data = {'n_cases': np.int64(len(READER_CASES))}
-    for ci, ((w, h), resize, align, gray) in enumerate(READER_CASES):
+    for ci, case in enumerate(READER_CASES):
+        ((w, h), resize, align, gray), rotation = case[:4], (case[4] if len(case) > 4 else 0)
         g = torch.Generator().manual_seed(700 + ci)
         img = (torch.rand(h, w, 3, generator=g) * 255).to(torch.uint8).numpy()
         images[f'case{ci}'] = img
         image, overlap_inp, inp, scales, overlap_scales = utils.read_overlap_image(
-            f'case{ci}', 'cpu', resize, 0, True, grayscale=gray, align=align, overlap=True)
+            f'case{ci}', 'cpu', resize, rotation, True, grayscale=gray, align=align, overlap=True)
         tag = f'c{ci}_'
+        data[tag + 'rotation'] = np.int64(rotation)
         data[tag + 'wh'] = np.asarray((w, h))
         data[tag + 'resize'] = np.asarray(resize)
         data[tag + 'align'] = np.asarray(align)

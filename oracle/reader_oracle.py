@@ -109,10 +109,12 @@ def bgr_to_gray(img):
     return (a[:, :, 0] * np.float32(0.114) + a[:, :, 1] * np.float32(0.587) + a[:, :, 2] * np.float32(0.299)).astype(np.float32)
 
 
-def read_overlap_image(image_bgr, resize, grayscale=False, align='disk'):
+def read_overlap_image(image_bgr, resize, grayscale=False, align='disk', rotation=0):
     """The reader on an already decoded BGR image [h,w,3] (uint8 or float): returns
     ``dict(image, overlap_inp, inp, scales, overlap_scales)`` like ``:340-343`` (``image`` =
-    the grey matcher-frame picture, 0..255)."""
+    the grey matcher-frame picture, 0..255).  ``rotation`` (:322-325): the matcher picture -
+    not the OETR frame - is turned by k x 90 degrees counter-clockwise (``np.rot90``) after the
+    resizes, and an odd k swaps ``scales``."""
     img = np.asarray(image_bgr)
     if not align:                       # utils.py:283-284: "BGR to RGB" only without alignment - the
         img = img[:, :, ::-1]           # later grey conversion still reads the channels as B,G,R
@@ -122,10 +124,15 @@ def read_overlap_image(image_bgr, resize, grayscale=False, align='disk'):
     image = bilinear_resize(img, fr['w_new'], fr['h_new'])
     overlap_image = bilinear_resize(image, fr['w_ov'], fr['h_ov'])
     overlap_inp = torch.from_numpy(overlap_image[None] / 255.0).float()
+    scales = fr['scales']
+    if rotation != 0:
+        image = np.ascontiguousarray(np.rot90(image, k=rotation))
+        if rotation % 2:
+            scales = scales[::-1]
     gray = bgr_to_gray(image)
     if grayscale:
         inp = torch.from_numpy(gray[None, None] / 255.0).float()
     else:
         inp = torch.from_numpy(image.transpose((2, 0, 1))[None] / 255.0).float()
-    return dict(image=gray, overlap_inp=overlap_inp, inp=inp, scales=fr['scales'],
+    return dict(image=gray, overlap_inp=overlap_inp, inp=inp, scales=scales,
                 overlap_scales=fr['overlap_scales'])

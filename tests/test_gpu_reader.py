@@ -20,9 +20,10 @@ def test_device_reader_matches_reference_goldens(gpu, golden_dir):
     n = 0
     for ci, c, img in load_reader_cases(golden_dir):
         resize, gray, align = [int(v) for v in c['resize']], bool(c['grayscale']), str(c['align'])
-        ref = rdo.read_overlap_image(img, resize, gray, align)
+        rot = int(c['rotation'])
+        ref = rdo.read_overlap_image(img, resize, gray, align, rotation=rot)
         for src in (img, img.astype(np.float32)):            # uint8 as decoded, or float32
-            (res,) = pkg.read_overlap_images([src], gpu, resize, gray, align)
+            (res,) = pkg.read_overlap_images([src], gpu, resize, gray, align, rotation=rot)
             assert res.scales == tuple(c['scales']) and res.overlap_scales == tuple(c['overlap_scales']), ci
             assert tuple(res.overlap_inp.shape) == tuple(c['overlap_shape']), ci
             assert tuple(res.inp.shape) == tuple(c['inp_shape']), ci
@@ -31,7 +32,7 @@ def test_device_reader_matches_reference_goldens(gpu, golden_dir):
             if 'inp' in c:                                    # small case: the fixture holds the pixels
                 assert float((res.inp.cpu() - torch.from_numpy(c['inp'])).abs().max()) <= PIX_TOL
         n += 1
-    assert n == 5
+    assert n == 8
 
 
 def test_reader_batches_mixed_sizes_through_one_copy(gpu):

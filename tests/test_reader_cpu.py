@@ -27,7 +27,8 @@ def load_reader_cases(golden_dir):
 def test_oracle_reader_matches_reference_goldens(golden_dir):
     n = 0
     for ci, c, img in load_reader_cases(golden_dir):
-        out = rdo.read_overlap_image(img, [int(v) for v in c['resize']], bool(c['grayscale']), str(c['align']))
+        out = rdo.read_overlap_image(img, [int(v) for v in c['resize']], bool(c['grayscale']), str(c['align']),
+                                     rotation=int(c['rotation']))
         assert out['scales'] == tuple(c['scales']) and out['overlap_scales'] == tuple(c['overlap_scales']), ci
         assert tuple(out['overlap_inp'].shape) == tuple(c['overlap_shape']), ci
         assert tuple(out['inp'].shape) == tuple(c['inp_shape']), ci
@@ -36,7 +37,7 @@ def test_oracle_reader_matches_reference_goldens(golden_dir):
         if 'inp' in c:
             assert np.array_equal(out['inp'].numpy(), c['inp']) and np.array_equal(out['overlap_inp'].numpy(), c['overlap_inp'])
         n += 1
-    assert n == 5
+    assert n == 8
 
 
 def test_library_frame_arithmetic_is_the_references(golden_dir):
@@ -45,9 +46,10 @@ def test_library_frame_arithmetic_is_the_references(golden_dir):
     for ci, c, img in load_reader_cases(golden_dir):
         w, h = (int(v) for v in c['wh'])
         fr = pkg.overlap_frame(w, h, [int(v) for v in c['resize']], str(c['align']))
-        assert fr['scales'] == tuple(c['scales']) and fr['overlap_scales'] == tuple(c['overlap_scales']), ci
+        odd = int(c['rotation']) % 2      # (an odd rotation swaps the matcher picture's axes and `scales`)
+        assert fr['scales'][::-1 if odd else 1] == tuple(c['scales']) and fr['overlap_scales'] == tuple(c['overlap_scales']), ci
         assert (1, fr['h_ov'], fr['w_ov'], 3) == tuple(c['overlap_shape']), ci
-        assert (fr['h_new'], fr['w_new']) == tuple(c['inp_shape'][2:]), ci
+        assert (fr['h_new'], fr['w_new'])[::-1 if odd else 1] == tuple(c['inp_shape'][2:]), ci
     import random
     rng = random.Random(5)
     for _ in range(300):
