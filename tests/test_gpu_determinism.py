@@ -51,7 +51,14 @@ def test_forward_is_a_function_of_its_inputs_decoder_split(model, split):
     _interleaved(model, 'f32_split_f16', 64, 150, 'linear', 0, split)
 
 
-def _interleaved(model, precision, tile, rounds, attention, prereduce, split):
+@pytest.mark.parametrize('precision,tile,rounds', [('f32_split_f16', 64, 200), ('f32_split_f16', 32, 150), ('f32', 32, 30)])
+def test_masked_forward_is_a_function_of_its_inputs(model, precision, tile, rounds):
+    """The MASKED instantiations of the encoder kernels (forward_dummy's masks) are kernels
+    of their own: same interleaving, masks with holes on every shape."""
+    _interleaved(model, precision, tile, rounds, 'linear', 0, 0, masked=True)
+
+
+def _interleaved(model, precision, tile, rounds, attention, prereduce, split, masked=False):
     dev = torch.device('cuda', 0)
     eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision=precision, enc_tile=tile,
                             attention=attention)
@@ -67,15 +74,21 @@ def _interleaved(model, precision, tile, rounds, attention, prereduce, split):
         p1 = model.pos_encoding(f1.cpu()).contiguous().to(dev)
         p2 = model.pos_encoding(f2.cpu()).contiguous().to(dev)
         cases.append((f1, f2, p1, p2, (h1 * 32, w1 * 32), (h2 * 32, w2 * 32)))
-    refs = [eng.forward(*c, stages=True) for c in cases]
+    kws = [{} for _ in cases]
+    if masked:
+        from oracle import oetr_oracle as orc
+        kws = [dict(mask1=orc.make_masks(50 + i, n, h1, w1, 'holes').to(dev), mask2=orc.make_masks(60 + i, n, h2, w2, 'holes').to(dev))
+               for i, (n, h1, w1, h2, w2) in enumerate(SHAPES)]
+    cases_kw = list(zip(cases, kws))
+    refs = [eng.forward(*c, stages=True, **kw) for c, kw in cases_kw]
     keys = ('memory1', 'memory2', 'hs1', 'hs2', 'box1', 'box2')
     refs = [{k: r[k].clone() for k in keys} for r in refs]
     differing, runs = [], 0
     for rnd in range(rounds):
-        for ci, c in enumerate(cases):
+        for ci, (c, kw) in enumerate(cases_kw):
             if runs % 3 == 0:   # disturb the workspace: a shorter encoder run of the same shape
-                eng.forward(*c, stages=True, enc_layers=1 + runs % 5)
-            out = eng.forward(*c, stages=True)
+                eng.forward(*c, stages=True, enc_layers=1 + runs % 5, **kw)
+            out = eng.forward(*c, stages=True, **kw)
             runs += 1
             bad = [k for k in keys if not torch.equal(out[k], refs[ci][k])]
             if bad:

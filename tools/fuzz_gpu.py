@@ -34,8 +34,13 @@ for case in range(ncase):
     f1, f2 = orc.make_features(1000 + case, n, *g1), orc.make_features(2000 + case, n, *g2)
     p1, p2 = orc.position_table(*g1), orc.position_table(*g2)
     im1, im2 = (g1[0] * 32, g1[1] * 32), (g2[0] * 32, g2[1] * 32)
-    out = eng.forward(f1.to(dev), f2.to(dev), p1.to(dev), p2.to(dev), im1, im2, stages=True)
-    ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
+    # forward_dummy's masks on half of the cases (padding-style corners, or with random holes)
+    m1 = m2 = None
+    mk = rng.choice(['', '', 'pad', 'holes'])
+    if mk:
+        m1, m2 = orc.make_masks(3000 + case, n, *g1, kind=mk), orc.make_masks(4000 + case, n, *g2, kind=mk)
+    out = eng.forward(f1.to(dev), f2.to(dev), p1.to(dev), p2.to(dev), im1, im2, stages=True, mask1=m1, mask2=m2)
+    ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True, mask1=m1, mask2=m2)
     msgs = []
     for s in ('1', '2'):
         for k, tol in TOL.items():
@@ -52,5 +57,5 @@ for case in range(ncase):
     fl = eng.query_flags()
     if fl:
         msgs.append(f'flags={fl}'); status = 'BAD'; bad += 1
-    print(f'{status} case {case}: n={n} {g1} {g2} w{wseed}{"s" if sharp else ""} {prec} tail={tail} split={split} pre={pre} ' + ' '.join(msgs), flush=True)
+    print(f'{status} case {case}: n={n} {g1} {g2} w{wseed}{"s" if sharp else ""} {prec} tail={tail} split={split} pre={pre} masks={mk or "-"} ' + ' '.join(msgs), flush=True)
 print(f'{bad} bad of {ncase}')
