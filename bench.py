@@ -244,11 +244,12 @@ def pmc_traffic(kernel_substr):
 
 def mangled_encoder(tile, mode_id, policy=0, attention='linear'):
     """Substring of the B;A encoder kernel's mangled name in rocprofv3 CSVs."""
+    # (template arguments: HAS_B, TAIL, MODE, [waves, FULL,] policy, MASKED = false)
     if tile == 64:
-        return f'k_encoder64ILb1ELi0ELi{mode_id}ELi{policy}EE'
+        return f'k_encoder64ILb1ELi0ELi{mode_id}ELi{policy}ELb0EE'
     if mode_id == 1 and attention == 'linear':   # two-plane dtypes: the 32-row kernel on the 64-row kernel's body (encoder.hip: k_encoder32m)
-        return f'k_encoder32mILb1ELi0ELi{mode_id}ELi{policy}EE'
-    return f'k_encoderILb1ELi0ELi{mode_id}ELi{4 if mode_id == 0 else 8}ELb0ELi{policy}EE'
+        return f'k_encoder32mILb1ELi0ELi{mode_id}ELi{policy}ELb0EE'
+    return f'k_encoderILb1ELi0ELi{mode_id}ELi{4 if mode_id == 0 else 8}ELb0ELi{policy}ELb0EE'
 
 
 def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_workload, extra_flop=0, grids=None,

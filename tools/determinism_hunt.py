@@ -31,9 +31,15 @@ for n, h1, w1, h2, w2 in shapes:
     f1 = (torch.rand(n, 256, h1, w1) - 0.5).to(dev); f2 = (torch.rand(n, 256, h2, w2) - 0.5).to(dev)
     p1 = model.pos_encoding(f1.cpu()).contiguous().to(dev); p2 = model.pos_encoding(f2.cpu()).contiguous().to(dev)
     cases.append((f1, f2, p1, p2, (h1 * 32, w1 * 32), (h2 * 32, w2 * 32)))
+# HUNT_MASKS=1: forward_dummy's masks (with holes) on every shape - the MASKED kernel instantiations
+MASKS = [None] * len(cases)
+if os.environ.get('HUNT_MASKS'):
+    from oracle import oetr_oracle as orc
+    MASKS = [dict(mask1=orc.make_masks(50 + i, n, h1, w1, 'holes').to(dev), mask2=orc.make_masks(60 + i, n, h2, w2, 'holes').to(dev))
+             for i, (n, h1, w1, h2, w2) in enumerate(shapes)]
 FILL = os.environ.get('HUNT_FILL', '')
 THRASH = torch.zeros(int(os.environ.get('HUNT_THRASH_MB', '0')) * 262144 + 1, device=dev)
-def run(c, k=8, fill=''):
+def run(c, k=8, fill='', masks=None):
     if fill:
         ws = eng._current_ws()
         if ws is not None:
@@ -42,17 +48,17 @@ def run(c, k=8, fill=''):
             elif fill == 'nan': body.fill_(float('nan'))
             elif fill == 'big': body.fill_(3.0e4)
             elif fill == 'rand': body.copy_(torch.randn(body.shape, device=dev) * 10)
-    out = {kk: v.clone() for kk, v in eng.forward(*c, stages=True, enc_layers=k).items() if torch.is_tensor(v)}
+    out = {kk: v.clone() for kk, v in eng.forward(*c, stages=True, enc_layers=k, **(masks or {})).items() if torch.is_tensor(v)}
     torch.cuda.synchronize()
     out['_ws'] = eng._current_ws().clone()
     return out
-refs = [run(c) for c in cases]
+refs = [run(c, masks=m) for c, m in zip(cases, MASKS)]
 t0 = time.time(); runs = 0; found = 0
 while time.time() - t0 < budget:
     for ci, c in enumerate(cases):
-        if runs % 3 == 0: run(c, 1 + runs % 5)
+        if runs % 3 == 0: run(c, 1 + runs % 5, masks=MASKS[ci])
         if THRASH.numel() > 1: THRASH.add_(1.0)      # cold L2 / MALL for the measured run
-        b = run(c, 8, FILL); runs += 1
+        b = run(c, 8, FILL, MASKS[ci]); runs += 1
         diffs = {kk: float((refs[ci][kk] - b[kk]).abs().max()) for kk in b if kk != '_ws' and not torch.equal(refs[ci][kk], b[kk])}
         if diffs:
             found += 1
