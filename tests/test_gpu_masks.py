@@ -184,3 +184,25 @@ def test_masked_linear_attention_entry_vs_reference_golden(gpu, golden_dir):
         assert maxerr(only_kv, fullk) <= 2e-5 * max(1.0, float(fullk.abs().max()))
         ones = hip_engine.linear_attention(dq, dk, dv, q_mask=torch.ones(2, L), kv_mask=torch.ones(2, S))
         assert torch.equal(ones, hip_engine.linear_attention(dq, dk, dv))
+
+
+def test_fractional_and_empty_masks(gpu):
+    """The reference only MULTIPLIES by the masks in the attention (any float value, linear_attention.py:37-41)
+    and fills logits where ``bool(mask)`` is False (model.py:166-171): fractional weights scale, zeros fill;
+    an image masked everywhere gets the uniform softmax (centre of the grid) and a zero state."""
+    w = orc.make_hot_weights(3, sharpen=True)
+    f1, f2 = orc.make_features(51, 3, 9, 11), orc.make_features(52, 3, 14, 6)
+    p1, p2 = orc.position_table(9, 11), orc.position_table(14, 6)
+    g = torch.Generator().manual_seed(9)
+    m1 = torch.rand(3, 9, 11, generator=g) * (torch.rand(3, 9, 11, generator=g) > 0.2)     # weights in [0,1), ~20 % zeros
+    m2 = torch.rand(3, 14, 6, generator=g).clamp_min(0.05)
+    m1[2] = 0.0                                                                              # image 2 of side 1: nothing valid
+    im1, im2 = (288, 352), (448, 192)
+    dev = [t.to(gpu) for t in (f1, f2, p1, p2)]
+    ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True, mask1=m1, mask2=m2)
+    for tile in (None, 64):
+        out = engine(gpu, 3, True, tile).forward(*dev, im1, im2, stages=True, mask1=m1, mask2=m2)
+        check_stages(out, ref, f'tile {tile}')
+        assert torch.isfinite(out['memory1']).all() and torch.isfinite(out['hs1']).all()
+        # the empty image: uniform softmax -> centre of its token grid times the stride (32)
+        assert maxerr(out['cxy1'][2], torch.tensor([11 * 32 / 2.0, 9 * 32 / 2.0])) <= 1e-3
