@@ -85,6 +85,15 @@ def test_null_arguments_are_rejected_not_crashed():
     w.struct_size = 4                               # wrong size
     assert lib.oetr_create(ctypes.byref(w), 0, 0, ctypes.byref(h)) == 1
     assert lib.oetr_box_tlbr_to_xyxy(None, None, 0, 1, 1, None, None) == 1
+    # the masked entries (ABI 4) validate like the ones they extend
+    st = lib.oetr_forward_masked(None, None, None, None, None, None, None, 1, 20, 20, 20, 20, 640,
+                                 640, 640, 640, None, 0, None, None, None, None)
+    assert st == 1 and b'NULL' in lib.oetr_last_error()
+    assert lib.oetr_feature_correlation_masked(None, None, None, None, None, None, None, 1, 20, 20, 20, 20,
+                                               None, 0, None, None, None, None, None) == 1
+    assert lib.oetr_center_estimation_masked(None, None, None, None, None, None, None, 1, 20, 20, 20, 20,
+                                             640, 640, None, 0, None, None, None) == 1
+    assert lib.oetr_linear_attention_masked(None, None, None, None, None, 1, 4, 4, None, None, 0, None) == 1
 
 
 def test_product_path_has_no_cpu_fallback():
