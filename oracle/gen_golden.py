@@ -533,6 +533,21 @@ def gen_train_forward(out_dir, model):
         print(f'train_forward[{tag}]', {k: (float(v) if v.dim() == 0 else tuple(v.shape)) for k, v in res.items()})
     model.cycle, model.iouloss.oiou = False, False
     np.savez_compressed(out_dir / 'train_forward.npz', **out)
+    # the same batch with the mask branch taken (src/model.py:256-258: `resize_mask1` in data): masks at the
+    # token grids' resolution (4x5 and 5x4), sliced by overlap_valid like the images
+    mdata = dict(data, resize_mask1=orc.make_masks(78, 3, 4, 5, 'holes'), resize_mask2=orc.make_masks(79, 3, 5, 4, 'pad'))
+    mout = {'seed': np.int64(77), 'hot_seed': np.int64(5), 'mask_seeds': np.asarray([78, 79]),
+            'resize_mask1': mdata['resize_mask1'].numpy().astype(np.uint8),
+            'resize_mask2': mdata['resize_mask2'].numpy().astype(np.uint8)}
+    for tag, cycle, oiou in (('giou', False, False), ('oiou_cycle', True, True)):
+        model.cycle = cycle
+        model.iouloss.oiou = oiou
+        res = model(dict(mdata))
+        for k, v in res.items():
+            mout[f'{tag}_{k}'] = np.asarray(v.detach().numpy(), dtype=np.float32)
+        print(f'train_forward_masked[{tag}]', {k: (float(v) if v.dim() == 0 else tuple(v.shape)) for k, v in res.items()})
+    model.cycle, model.iouloss.oiou = False, False
+    np.savez_compressed(out_dir / 'train_forward_masked.npz', **mout)
 
 
 def main():

@@ -390,4 +390,20 @@ def test_training_forward_matches_the_reference_results(gpu, golden_dir):
             err = float((res[k].cpu() - ref).abs().max())
             tol = 0.1 if k.startswith('pred_bbox') else 2e-3
             assert err <= tol, (tag, k, err)
+    # the mask branch (reference src/model.py:256-258: `resize_mask1` in data): the reference model's own
+    # forward on the same batch WITH masks (tests/golden/train_forward_masked.npz)
+    gm = np.load(golden_dir / 'train_forward_masked.npz')
+    m1 = orc.make_masks(int(gm['mask_seeds'][0]), 3, 4, 5, 'holes')
+    m2 = orc.make_masks(int(gm['mask_seeds'][1]), 3, 5, 4, 'pad')
+    assert np.array_equal(m1.numpy().astype(np.uint8), gm['resize_mask1']) and np.array_equal(m2.numpy().astype(np.uint8), gm['resize_mask2'])
+    mdata = dict(data, resize_mask1=m1.to(gpu), resize_mask2=m2.to(gpu))
+    for tag, cycle, oiou in (('giou', False, False), ('oiou_cycle', True, True)):
+        model.cycle, model.oiou = cycle, oiou
+        res = model(mdata)
+        for k in res:
+            ref = torch.from_numpy(gm[f'{tag}_{k}'])
+            err = float((res[k].cpu() - ref).abs().max())
+            tol = 0.1 if k.startswith('pred_bbox') else 2e-3
+            assert err <= tol, ('masked', tag, k, err)
+        assert float((res['pred_bbox1'].cpu() - torch.from_numpy(g[f'{tag}_pred_bbox1'])).abs().max()) > 0.5   # the masks matter
     model.cycle, model.oiou = False, False
