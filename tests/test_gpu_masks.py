@@ -206,3 +206,25 @@ def test_fractional_and_empty_masks(gpu):
         assert torch.isfinite(out['memory1']).all() and torch.isfinite(out['hs1']).all()
         # the empty image: uniform softmax -> centre of its token grid times the stride (32)
         assert maxerr(out['cxy1'][2], torch.tensor([11 * 32 / 2.0, 9 * 32 / 2.0])) <= 1e-3
+
+
+def test_masked_forward_is_enqueue_only(gpu):
+    """oetr_forward_masked like oetr_forward: no synchronisation, no device-to-host copy - capturable into a HIP
+    graph; a replay after the MASKS changed in place returns what an eager call on the new masks returns."""
+    eng = engine(gpu, 1, True)
+    f1, f2 = orc.make_features(61, 2, 12, 12).to(gpu), orc.make_features(62, 2, 8, 15).to(gpu)
+    p1, p2 = orc.position_table(12, 12).to(gpu), orc.position_table(8, 15).to(gpu)
+    m1 = orc.make_masks(63, 2, 12, 12, 'pad').to(gpu).flatten(1).contiguous()     # float32 [N,L] on the device: no
+    m2 = orc.make_masks(64, 2, 8, 15, 'pad').to(gpu).flatten(1).contiguous()       # conversion inside the capture
+    first = [t.clone() for t in eng.forward(f1, f2, p1, p2, (384, 384), (256, 480), mask1=m1, mask2=m2)]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = eng.forward(f1, f2, p1, p2, (384, 384), (256, 480), mask1=m1, mask2=m2)
+    m1.copy_(orc.make_masks(65, 2, 12, 12, 'holes').flatten(1))
+    graph.replay()
+    torch.cuda.synchronize()
+    fresh = eng.forward(f1, f2, p1, p2, (384, 384), (256, 480), mask1=m1, mask2=m2)
+    assert torch.equal(captured[0], fresh[0]) and torch.equal(captured[1], fresh[1])
+    assert not torch.equal(fresh[0], first[0])
+    assert eng.query_flags() == 0
