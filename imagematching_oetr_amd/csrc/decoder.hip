@@ -736,9 +736,6 @@ __global__ __launch_bounds__(512) void k_decoder_convp(DecLaunch d, HeatLaunch h
   else conv_p_body<MODE>(h, P, blockIdx.x - nd, smem);
 }
 
-#ifndef OETR_CONVP64
-#define OETR_CONVP64 1   // 0: the round-1 rule (64-token conv-P tiles only when the encoder runs 64-token tiles)
-#endif
 template <int MODE>
 static hipError_t launch_decoder_convp_mode(const DecLaunch& d, const HeatLaunch& h0, float* P,
                                             hipStream_t s) {
@@ -746,18 +743,15 @@ static hipError_t launch_decoder_convp_mode(const DecLaunch& d, const HeatLaunch
   // whatever tile the encoder runs - P is indexed by row; fewer, longer workgroups leave the
   // one-workgroup decoder chain, then this launch's critical path, more of the L2 (52.0 vs
   // 53.5 us) - else TM-token tiles (h.g).  Three items per tile beside the split decoder (conv_p.h).
+  // (round 1's rule - 64-token conv tiles only when the encoder ran 64-token tiles - and its 32-row conv body
+  //  for the 16-bit-plane modes are gone: that instantiation was never launched and was the one conv kernel
+  //  that spilled, 20 B of scratch per lane)
   HeatLaunch h = h0;
-  const bool t64 = gm_half(MODE) && (OETR_CONVP64 || d.g.ntiles != h.g.ntiles);
+  constexpr bool t64 = gm_half(MODE);
   h.convp_split = t64 && d.ksplit == DEC_K ? 3 : 1;
   const int ptiles = t64 ? h.convp_split * h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT) : h.g.ntiles;
   const dim3 grid(2 * d.g.N * d.ksplit + ptiles);
-  if constexpr (gm_half(MODE)) {
-    if (t64) {
-      hipLaunchKernelGGL((k_decoder_convp<MODE, true>), grid, dim3(512), 0, s, d, h, P);
-      return hipGetLastError();
-    }
-  }
-  hipLaunchKernelGGL((k_decoder_convp<MODE, false>), grid, dim3(512), 0, s, d, h, P);
+  hipLaunchKernelGGL((k_decoder_convp<MODE, t64>), grid, dim3(512), 0, s, d, h, P);
   return hipGetLastError();
 }
 
