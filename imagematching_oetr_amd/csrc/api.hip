@@ -304,8 +304,8 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
 oetr_status check_masks(const oetr_ctx* h, const float* mask1, const float* mask2, bool encoder) {
   if (!mask1 && !mask2) return OETR_OK;
   if (!mask1 || !mask2) return fail(OETR_ERR_BAD_ARG, "masks: pass both mask1 and mask2, or neither");
-  if (encoder && ((h->mode != GM_SPLIT && h->mode != GM_F32) || h->policy != 0 || h->attn_full))
-    return fail(OETR_ERR_UNSUPPORTED, "masks: built for OETR_DTYPE_F32_SPLIT_F16 and OETR_DTYPE_F32 with linear attention "
+  if (encoder && ((h->mode != GM_SPLIT && h->mode != GM_F32) || h->attn_full))
+    return fail(OETR_ERR_UNSUPPORTED, "masks: built for OETR_DTYPE_F32_SPLIT_F16, OETR_DTYPE_F32_SPLIT_QK16 and OETR_DTYPE_F32 with linear attention "
                                       "(the reference's FullAttention turns a masked query row into NaN, "
                                       "linear_attention.py:74-81)");
   return OETR_OK;

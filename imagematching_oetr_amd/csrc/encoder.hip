@@ -1489,14 +1489,19 @@ template <int MODE>
 static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, hipStream_t s) {
   const dim3 grid(p.g.ntiles);
   if (p.mask[0] || p.mask[1]) {
-    // forward_dummy's masks: built for the default arithmetic (two planes, every site fp32-class,
-    // linear attention), both tile sizes
+    // forward_dummy's masks: built for the two-plane arithmetic (every site fp32-class, or the
+    // precision policy), linear attention, both tile sizes
     if constexpr (MODE == GM_SPLIT) {
-      if (!p.mask[0] || !p.mask[1] || p.policy != 0 || p.attn_full) return hipErrorInvalidValue;
-#define OETR_LAUNCHM(B, T)                                                                               \
-  do {                                                                                                   \
-    if (p.tile_rows == RT) hipLaunchKernelGGL((k_encoder64<B, T, MODE, 0, true>), grid, dim3(512), 0, s, p); \
-    else hipLaunchKernelGGL((k_encoder32m<B, T, MODE, 0, true>), grid, dim3(512), 0, s, p);                \
+      if (!p.mask[0] || !p.mask[1] || (p.policy != 0 && p.policy != 1) || p.attn_full) return hipErrorInvalidValue;
+#define OETR_LAUNCHM(B, T)                                                                                    \
+  do {                                                                                                        \
+    if (p.policy == 1) {                                                                                      \
+      if (p.tile_rows == RT) hipLaunchKernelGGL((k_encoder64<B, T, MODE, 1, true>), grid, dim3(512), 0, s, p);  \
+      else hipLaunchKernelGGL((k_encoder32m<B, T, MODE, 1, true>), grid, dim3(512), 0, s, p);                   \
+    } else {                                                                                                  \
+      if (p.tile_rows == RT) hipLaunchKernelGGL((k_encoder64<B, T, MODE, 0, true>), grid, dim3(512), 0, s, p);  \
+      else hipLaunchKernelGGL((k_encoder32m<B, T, MODE, 0, true>), grid, dim3(512), 0, s, p);                   \
+    }                                                                                                         \
   } while (0)
       if (has_b) {
         if (tail == 0) OETR_LAUNCHM(true, 0);

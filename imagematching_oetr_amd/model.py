@@ -323,9 +323,9 @@ class OETR(nn.Module):
             return False
         if mask1 is None or mask2 is None:
             raise ValueError('masks: pass both mask1 and mask2, or neither')
-        if encoder and (self.hip_precision not in ('f32_split_f16', 'f32') or self.hip_attention != 'linear'):
+        if encoder and (self.hip_precision not in ('f32_split_f16', 'f32_split_qk16', 'f32') or self.hip_attention != 'linear'):
             raise NotImplementedError(
-                "masks are built for hip_precision='f32_split_f16' / 'f32' with linear attention (the "
+                "masks are built for hip_precision='f32_split_f16' / 'f32_split_qk16' / 'f32' with linear attention (the "
                 "reference's FullAttention turns a masked query row into NaN, linear_attention.py:74-81); "
                 f"this model runs hip_precision='{self.hip_precision}', hip_attention='{self.hip_attention}'")
         return True

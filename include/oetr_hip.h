@@ -334,7 +334,7 @@ oetr_status oetr_forward_stages(oetr_handle h, const float *feat1,
  *   - fills the token's heat-map logit with -1e9 before the softmax where it is 0
  *     (src/model.py:22, :166-171) - the `logits` stage output then holds the filled values.
  * Both masks or neither (both NULL = oetr_forward_stages); OETR_ERR_UNSUPPORTED unless the handle
- * is OETR_DTYPE_F32_SPLIT_F16 (no precision policy) or OETR_DTYPE_F32, with linear attention (the
+ * is OETR_DTYPE_F32_SPLIT_F16, OETR_DTYPE_F32_SPLIT_QK16 or OETR_DTYPE_F32, with linear attention (the
  * reference's FullAttention turns a masked query's row into NaN, linear_attention.py:74-81).
  * `stages` may be NULL.  Same workspace, same enqueue-only behaviour as oetr_forward. */
 oetr_status oetr_forward_masked(oetr_handle h, const float *feat1,
