@@ -232,3 +232,16 @@ def test_masked_forward_is_enqueue_only(gpu):
     assert torch.equal(captured[0], fresh[0]) and torch.equal(captured[1], fresh[1])
     assert not torch.equal(fresh[0], first[0])
     assert eng.query_flags() == 0
+
+
+@pytest.mark.parametrize('tile', [None, 64], ids=['tile32', 'tile64'])
+def test_masked_forward_at_the_benchmark_size(gpu, tile):
+    """BASELINE configs[1]'s shape (8 pairs @640x640: 20x20 token grids, ragged last tiles) with padding-style masks."""
+    w = orc.make_hot_weights(5, sharpen=True)
+    f1, f2 = orc.make_features(81, 8, 20, 20), orc.make_features(82, 8, 20, 20)
+    p1 = orc.position_table(20, 20)
+    m1, m2 = orc.make_masks(83, 8, 20, 20, 'pad'), orc.make_masks(84, 8, 20, 20, 'holes')
+    ref = orc.hot_path(f1, f2, w, (640, 640), (640, 640), return_stages=True, mask1=m1, mask2=m2)
+    out = engine(gpu, 5, True, tile).forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p1.to(gpu), (640, 640), (640, 640),
+                                             stages=True, mask1=m1, mask2=m2)
+    check_stages(out, ref, f'8 pairs @640, tile {tile}')
