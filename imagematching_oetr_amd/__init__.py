@@ -11,11 +11,11 @@ from .model import OETR, build_detectors  # noqa: F401
 from .pipeline import forward_pairs, forward_pairs_raw, forward_pairs_sharded  # noqa: F401
 from .reader import overlap_frame, read_overlap_images  # noqa: F401
 from .hip_engine import (FLAG_EXCHANGE, FLAG_F16_RANGE, FLAG_INVALID, FULL_ATTENTION_VARIANTS, HotPathEngine, KernelTrace, NeckEngine, OetrError,  # noqa: F401
-                         OetrRangeError,
+                         OetrExchangeError, OetrRangeError,
                          box_tlbr_to_xyxy, full_attention, hot_path_keys,
                          linear_attention, load_library, neck_keys, overlap_crop)
 
 __all__ = ['Cfg', 'get_cfg_defaults', 'OETR', 'build_detectors',
-           'HotPathEngine', 'KernelTrace', 'NeckEngine', 'neck_keys', 'OetrError', 'OetrRangeError', 'FLAG_F16_RANGE', 'FLAG_EXCHANGE', 'FLAG_INVALID', 'box_tlbr_to_xyxy', 'full_attention',
+           'HotPathEngine', 'KernelTrace', 'NeckEngine', 'neck_keys', 'OetrError', 'OetrExchangeError', 'OetrRangeError', 'FLAG_F16_RANGE', 'FLAG_EXCHANGE', 'FLAG_INVALID', 'box_tlbr_to_xyxy', 'full_attention',
            'linear_attention', 'FULL_ATTENTION_VARIANTS', 'hot_path_keys', 'load_library', 'overlap_crop', 'forward_pairs',
            'forward_pairs_sharded', 'forward_pairs_raw', 'overlap_frame', 'read_overlap_images']

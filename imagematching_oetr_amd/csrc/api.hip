@@ -144,6 +144,7 @@ struct oetr_ctx {
   int device = 0;
   int mode = GM_SPLIT;  // GEMM mode GM_* (common.h) of the oetr_dtype
   int kv_prereduce = -1; // oetr_set_state_prereduce (-1 = auto)
+  mutable int dec_fault = 0;   // oetr_debug_decoder_fault: one shot, consumed by the next four-workgroup decoder launch
   int dec_split = 0;     // oetr_set_decoder_split: 0 auto, 1 one workgroup per image, 4 four (decoder.hip: decoder_body4)
   int tail_mode = 0;     // oetr_set_tail_mode: 0 auto, 1 P form (decoder || conv-P, combine), 2 direct (decoder, conv)
   int policy = 0;       // precision policy (SitePolicy<>) of the oetr_dtype: 1 = OETR_DTYPE_F32_SPLIT_QK16
@@ -364,6 +365,7 @@ DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, bool 
   d.xch = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w.flags) + STATUS_XCH_OFFSET);
   d.tbuf = nullptr;
   d.dbg = 0;
+  if (d.ksplit == DEC_SPLIT_K && h->dec_fault) { d.dbg = DEC_DBG_FAULT; h->dec_fault = 0; }
 #ifdef OETR_PHASE_TIMING
   d.tbuf = g_tbuf ? g_tbuf + 16 * 4096 : nullptr;
 #endif
@@ -1395,6 +1397,12 @@ oetr_status oetr_set_decoder_split(oetr_handle h, int k) {
   if (k != 0 && k != 1 && k != DEC_SPLIT_K)
     return fail(OETR_ERR_BAD_ARG, "oetr_set_decoder_split: 0 (auto), 1 or 4 workgroups per image");
   h->dec_split = k;
+  return OETR_OK;
+}
+
+oetr_status oetr_debug_decoder_fault(oetr_handle h, int on) {
+  if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_debug_decoder_fault: NULL handle");
+  h->dec_fault = on ? 1 : 0;
   return OETR_OK;
 }
 

@@ -425,6 +425,7 @@ constexpr uint32_t FLAG_EXCHANGE = 2u;    // == OETR_FLAG_EXCHANGE (decoder.hip:
 // oetr_workspace_init): word 0 = flags; words 16..31 = per-image call counters of the split
 // decoder; from byte 256 its exchange granules [16 images][5][4][256] x 8 bytes.
 constexpr int DEC_SPLIT_K = 4, DEC_SPLIT_MAX_IMAGES = 16, DEC_SPLIT_EXCHANGES = 5;
+constexpr int DEC_DBG_FAULT = 0x5a;   // DecLaunch::dbg: oetr_debug_decoder_fault (decoder.hip: exchange_sum)
 constexpr size_t STATUS_EPOCH_WORD = 16, STATUS_XCH_OFFSET = 256,
                  STATUS_XCH_BYTES = (size_t)DEC_SPLIT_MAX_IMAGES * DEC_SPLIT_EXCHANGES * DEC_SPLIT_K * 256 * 8,
                  STATUS_BYTES = STATUS_XCH_OFFSET + STATUS_XCH_BYTES;
@@ -1245,7 +1246,7 @@ struct DecLaunch {
   unsigned* xch_epoch;     // [2N] call counters = tags (workspace status block)
   uint32_t* flags;         // the workspace's status word (OETR_FLAG_EXCHANGE)
   long long* tbuf;         // OETR_PHASE_TIMING builds only
-  int dbg;                 // OETR_ABLATE builds only
+  int dbg;                 // OETR_ABLATE builds; DEC_DBG_FAULT (oetr_debug_decoder_fault)
 };
 struct DecConstLaunch {
   DecLayerDev layer[2];

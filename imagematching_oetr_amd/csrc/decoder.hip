@@ -494,12 +494,19 @@ __device__ __forceinline__ float collect(const float* part_s, int o) {
 // Sum of `mine` over the image's DEC_K workgroups, element tid of 256 (threads 0..255, whole
 // waves); the same value - same order of additions - in every workgroup.  LEADER_ONLY: the
 // last exchange, only workgroup 0 needs the sum.
+// `dead` (per wave): an earlier exchange of this call timed out - the call's outputs are invalid
+// already (OETR_FLAG_EXCHANGE is set), so the remaining exchanges publish and move on without
+// waiting: a failed call costs one spin limit, not five.
+// OETR_DEBUG_DECODER_FAULT (oetr_debug_decoder_fault, tests only): workgroup 1 of image 0 withholds
+// its stage-0 granules, so that the time-out path - flag, early exit of late workgroups, the host's
+// status-block reset - can be exercised on an idle device.
 template <bool LEADER_ONLY>
 __device__ __forceinline__ float exchange_sum(const DecLaunch& p, int img, int stage, int j, unsigned tag,
-                                              float mine, int tid) {
+                                              float mine, int tid, bool& dead) {
   gu64* slot = (gu64*)p.xch + ((size_t)(img * XCH_STAGES + stage) * DEC_K) * C + tid;
-  __hip_atomic_store(slot + j * C, ((unsigned long long)tag << 32) | __float_as_uint(mine), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+  if (!(p.dbg == DEC_DBG_FAULT && img == 0 && j == 1 && stage == 0))
+    __hip_atomic_store(slot + j * C, ((unsigned long long)tag << 32) | __float_as_uint(mine), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   if (LEADER_ONLY && j != 0) return 0.f;
   float v[DEC_K];
   const long long t0 = wall_clock64();
@@ -511,10 +518,11 @@ __device__ __forceinline__ float exchange_sum(const DecLaunch& p, int img, int s
       v[k] = k == j ? mine : __uint_as_float((unsigned)x);
       ok &= k == j || (unsigned)(x >> 32) == tag;
     }
-    if (__all(ok)) break;
+    if (__all(ok) || dead) break;
     __builtin_amdgcn_s_sleep(1);
     if ((spins & 63) == 63 && wall_clock64() - t0 > DEC_SPIN_LIMIT) {
       if ((tid & 63) == 0) atomicOr(p.flags, FLAG_EXCHANGE);
+      dead = true;
       break;
     }
   }
@@ -538,7 +546,14 @@ __device__ __forceinline__ void decoder_body4(const DecLaunch& p, int img, int j
   const DecLayerDev& w0 = p.layer[0];
   const DecLayerDev& w1 = p.layer[1];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const unsigned tag = p.xch_epoch[img] + 1;   // never 0; workgroup 0 stores it back at the end
+  // A workgroup that becomes resident only after its peers have given up on it (OETR_FLAG_EXCHANGE
+  // is set: by this call, or by an earlier one whose status the host has not settled yet) must not
+  // publish anything: workgroup 0 may have advanced the image's call counter by then, and granules
+  // tagged counter + 1 would be taken for the NEXT call's.  The call's outputs are invalid either
+  // way; the host re-zeroes the status block before it submits again (hip_engine.py: settle_exchange).
+  if (__hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_EXCHANGE) return;
+  const unsigned tag = __hip_atomic_load(p.xch_epoch + img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;   // never 0; workgroup 0 stores it back at the end
+  bool dead = false;
 
   f32x4 wa[16], wb[16];   // two stages of weights in flight
   issue_rows<64, 0>(w0.cross.wm_t, j, tid, wa);      // S1
@@ -594,7 +609,7 @@ __device__ __forceinline__ void decoder_body4(const DecLaunch& p, int img, int j
   fma_rows<64, 0>(wa, att, part_s, tid);
   issue_rows<128, 0>(w0.w2_t, j, tid, wa);            // S3
   __syncthreads();
-  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 0, j, tag, collect<8, C>(part_s, tid), tid);
+  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 0, j, tag, collect<8, C>(part_s, tid), tid, dead);
   __syncthreads();
   PHASE_STAMP(p, 2);
   // S2: hdn = relu(W1_0 . LN3(tgt))                           (columns: this FFN slab)
@@ -611,7 +626,7 @@ __device__ __forceinline__ void decoder_body4(const DecLaunch& p, int img, int j
   issue_cols<64, C, 0>(w1.self_attn.wv_t, j, tid, wa);   // S4 v
   issue_rows<64, 8>(w1.self_attn.wm_t, j, tid, wa);      // S5
   __syncthreads();
-  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 1, j, tag, collect<8, C>(part_s, tid), tid);
+  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 1, j, tag, collect<8, C>(part_s, tid), tid, dead);
   __syncthreads();
 
   PHASE_STAMP(p, 4);
@@ -648,7 +663,7 @@ __device__ __forceinline__ void decoder_body4(const DecLaunch& p, int img, int j
   fma_rows<64, 8>(wa, att, part_s, tid);
   issue_cols<128, FF, 0>(w1.w1_t, j, tid, wa);           // S8
   __syncthreads();
-  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 2, j, tag, collect<8, C>(part_s, tid), tid);
+  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 2, j, tag, collect<8, C>(part_s, tid), tid, dead);
   __syncthreads();
   PHASE_STAMP(p, 6);
   // S6: layer 1 cross-attention, this head pair
@@ -674,7 +689,7 @@ __device__ __forceinline__ void decoder_body4(const DecLaunch& p, int img, int j
   fma_rows<64, 8>(wb, att, part_s, tid);
   issue_rows<128, 0>(w1.w2_t, j, tid, wb);               // S9
   __syncthreads();
-  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 3, j, tag, collect<8, C>(part_s, tid), tid);
+  if (tid < C) tgt[tid] += exchange_sum<false>(p, img, 3, j, tag, collect<8, C>(part_s, tid), tid, dead);
   __syncthreads();
   PHASE_STAMP(p, 8);
   // S8/S9: ReLU MLP
@@ -686,10 +701,10 @@ __device__ __forceinline__ void decoder_body4(const DecLaunch& p, int img, int j
   fma_rows<128, 0>(wb, hdn_s, part_s, tid);
   __syncthreads();
   if (tid < C) {
-    const float s = exchange_sum<true>(p, img, 4, j, tag, collect<8, C>(part_s, tid), tid);
+    const float s = exchange_sum<true>(p, img, 4, j, tag, collect<8, C>(part_s, tid), tid, dead);
     if (j == 0) {
       p.hs[(size_t)img * C + tid] = tgt[tid] + s;
-      if (tid == 0) p.xch_epoch[img] = tag;
+      if (tid == 0) __hip_atomic_store(p.xch_epoch + img, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   PHASE_STAMP(p, 9);

@@ -1509,7 +1509,7 @@ static hipError_t launch_encoder_mode(const EncLaunch& p, bool has_b, int tail, 
         else OETR_LAUNCHM(true, 2);
       } else {
         if (tail == 0) OETR_LAUNCHM(false, 0);
-        else return hipErrorInvalidValue;
+        else return hipErrorInvalidValue;   // (no B phase + a tail = zero encoder layers: api.hip rejects enc_layers < 1 before any launch)
       }
 #undef OETR_LAUNCHM
       return hipGetLastError();

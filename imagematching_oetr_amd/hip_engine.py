@@ -67,7 +67,7 @@ class _CropInfo(C.Structure):
                 ('ratio', (C.c_double * 2) * 2), ('sbox', (C.c_float * 4) * 2)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # OETR_WORKSPACE_STATUS_BYTES: the block that opens a workspace - status word, the split decoder's
 # call counters and exchange granules; zero it once (oetr_workspace_init), the library owns it after
 WORKSPACE_STATUS_BYTES = 256 + 16 * 5 * 4 * 256 * 8
@@ -87,7 +87,7 @@ EXPORTS = (
     'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async',
     'oetr_set_state_prereduce', 'oetr_set_tail_mode', 'oetr_set_decoder_split', 'oetr_overlap_frame', 'oetr_read_overlap_image',
     'oetr_forward_masked', 'oetr_feature_correlation_masked', 'oetr_center_estimation_masked',
-    'oetr_linear_attention_masked')
+    'oetr_linear_attention_masked', 'oetr_debug_decoder_fault')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 FLAG_EXCHANGE = 2    # OETR_FLAG_EXCHANGE: the split decoder's workgroups were not resident together
@@ -214,6 +214,8 @@ def load_library(path=None):
     lib.oetr_set_tail_mode.argtypes = [vp, i]
     lib.oetr_set_decoder_split.restype = i
     lib.oetr_set_decoder_split.argtypes = [vp, i]
+    lib.oetr_debug_decoder_fault.restype = i
+    lib.oetr_debug_decoder_fault.argtypes = [vp, i]
     lib.oetr_neck_create.restype = i
     lib.oetr_neck_create.argtypes = [C.POINTER(_NeckWeights), i, C.POINTER(vp)]
     lib.oetr_neck_destroy.restype = None
@@ -268,6 +270,14 @@ class OetrError(RuntimeError):
 class OetrRangeError(OetrError):
     """A GEMM operand left the f16 range of an f16-based precision
     (``OETR_FLAG_F16_RANGE``): the outputs of that call are invalid."""
+
+
+class OetrExchangeError(OetrError):
+    """The four workgroups of an image's split decoder chain were not resident together within
+    its time limit (``OETR_FLAG_EXCHANGE``): the outputs of that call - and of every call that used
+    the workspace while the bit stood - are invalid.  Nothing is wrong with the inputs: the status
+    block has been re-initialised and the engine switched to one workgroup per image
+    (``set_decoder_split(1)``), so the same call can simply be submitted again."""
 
 
 def _check(lib, status, what):
@@ -527,6 +537,24 @@ class HotPathEngine:
         workgroups exchange five 256-float all-reduces per image inside the launch)."""
         _check(self.lib, self.lib.oetr_set_decoder_split(self._h, int(k)), 'oetr_set_decoder_split')
 
+    def debug_decoder_fault(self, on=True):
+        """``oetr_debug_decoder_fault`` (tests): the next four-workgroup decoder launch times out."""
+        _check(self.lib, self.lib.oetr_debug_decoder_fault(self._h, int(bool(on))), 'oetr_debug_decoder_fault')
+
+    def settle_exchange(self):
+        """Recovery after ``FLAG_EXCHANGE`` was READ (and cleared) from the current stream's
+        workspace: the failed call's per-image counters and granules are not trustworthy (a
+        workgroup that became resident late may have published under the next call's tag), so the
+        status block is zeroed again (``oetr_workspace_init``, enqueued behind everything
+        submitted so far), and the engine stops splitting the decoder chain - its residency
+        assumption does not hold on this device right now."""
+        ws = self._current_ws()
+        if ws is not None:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.oetr_workspace_init(ws.data_ptr(), ws.numel(), _stream(self.device)),
+                       'oetr_workspace_init')
+        self.set_decoder_split(1)
+
     def query_flags(self, clear=True):
         """Status word of the CURRENT STREAM's workspace (``oetr_query_flags``): synchronises
         torch's current stream on the engine's device.  Bit ``FLAG_F16_RANGE`` = a GEMM
@@ -543,9 +571,18 @@ class HotPathEngine:
                                       self._current_ws(), self.device, clear)
 
     def check_range(self):
-        """Raise :class:`OetrRangeError` if any call since the last check
-        overflowed the f16 operand range (clears the flag)."""
-        if self.query_flags(clear=True) & FLAG_F16_RANGE:
+        """Raise if any call since the last check was invalid (clears the word):
+        :class:`OetrExchangeError` when the split decoder timed out (after
+        :meth:`settle_exchange`: re-submitting works), :class:`OetrRangeError` when a GEMM
+        operand overflowed the f16 range."""
+        flags = self.query_flags(clear=True)
+        if flags & FLAG_EXCHANGE:
+            self.settle_exchange()
+            raise OetrExchangeError(
+                "the split decoder's workgroups were not resident together (OETR_FLAG_EXCHANGE): "
+                "results since the last check are invalid; the engine now runs one workgroup per "
+                "image - submit the batch again")
+        if flags & FLAG_F16_RANGE:
             raise OetrRangeError(
                 f"a GEMM operand reached |x| >= 65504 under precision "
                 f"'{self.precision}': results are invalid; use precision 'f32' or 'bf16'")
@@ -1018,7 +1055,7 @@ def linear_attention(q, k, v, q_mask=None, kv_mask=None):
             masks[0].data_ptr() if masks[0] is not None else None,
             masks[1].data_ptr() if masks[1] is not None else None,
             n, L, S, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q.device)),
-            'oetr_linear_attention_masked')
+            'oetr_linear_attention_masked', 'oetr_debug_decoder_fault')
     return out
 
 

@@ -24,7 +24,8 @@ import torch.nn.functional as F
 from . import losses
 
 from .backbone import PatchMerging, PositionEncodingSine, ResnetEncoder
-from .hip_engine import (FLAG_F16_RANGE, FLAG_INVALID, HotPathEngine, NeckEngine, OetrRangeError,
+from .hip_engine import (FLAG_EXCHANGE, FLAG_F16_RANGE, FLAG_INVALID, HotPathEngine, NeckEngine, OetrExchangeError,
+                         OetrRangeError,
                          hot_path_keys, neck_keys)
 
 
@@ -283,10 +284,21 @@ class OETR(nn.Module):
                                          precision=self.hip_precision,
                                          enc_tile=self.hip_enc_tile,
                                          attention=self.hip_attention)
-            if self.hip_precision == 'f32':     # no status check on this route: wait for nobody
-                self._engine.set_decoder_split(1)
             self._engine_key = key
+            self._split_ok = True     # False once OETR_FLAG_EXCHANGE was seen on this engine (settle_exchange)
         return self._engine
+
+    def _decoder_policy(self, eng, checked):
+        """The four-workgroup decoder chain (``oetr_set_decoder_split``) waits for its peers and
+        reports a residency time-out through ``OETR_FLAG_EXCHANGE`` - outputs invalid.  It is
+        therefore allowed (automatic rule, 0) only on calls whose status word WILL be read and
+        acted on; every other route - precisions without a range guard, ``hip_on_overflow =
+        'ignore'``, the reference's inner seams - runs one workgroup per image, which waits for
+        nobody.  Also off for good once a time-out was seen on this engine."""
+        want = 0 if (checked and getattr(self, '_split_ok', True)) else 1
+        if getattr(eng, '_dec_split_set', None) != want:
+            eng.set_decoder_split(want)
+            eng._dec_split_set = want
 
     def exact_engine(self):
         """Exact-fp32 MFMA engine on the same weights: the route taken when an
@@ -336,7 +348,9 @@ class OETR(nn.Module):
         """Reference ``src/model.py:132-143``: -> hs1, hs2 [N,1,C],
         memory1 [N,L1,C], memory2 [N,L2,C]."""
         self._check_masks(mask1, mask2)
-        return self.engine().feature_correlation(feat1, feat2, pos1, pos2, mask1, mask2)
+        eng = self.engine()
+        self._decoder_policy(eng, checked=False)     # a seam call reads no status word
+        return eng.feature_correlation(feat1, feat2, pos1, pos2, mask1, mask2)
 
     def center_estimation(self, hs1, hs2, memory1, memory2, hf1, wf1, hf2,
                           wf2, mask1=None, mask2=None):
@@ -398,17 +412,17 @@ class OETR(nn.Module):
         else:
             neck.forward_tokens(bb1, bufs['tokens1'])
             neck.forward_tokens(bb2, bufs['tokens2'])
+        self._decoder_policy(eng, checked=self.hip_on_overflow != 'ignore')
         boxes = eng.forward_tokens(n, hf1, wf1, hf2, wf2, hw1, hw2)
         if self.hip_on_overflow == 'ignore':
             return boxes
 
-        def rerun():   # the unfused route carries the per-stage handling (raise / exact fp32)
+        def rerun(exchange_only=False):   # the unfused route carries the per-stage handling (raise / exact fp32)
             feat1, feat2 = self.neck(bb1), self.neck(bb2)
             return self._boxes_checked(feat1, feat2, self.pos_encoding(feat1), self.pos_encoding(feat2),
                                        hw1, hw2)
-        tickets = [neck.read_flags_async()]
-        if eng.precision in eng.F16_RANGE:
-            tickets.append(eng.read_flags_async())
+        # (the engine's word is read in every checked precision: OETR_FLAG_EXCHANGE is not a range matter)
+        tickets = [neck.read_flags_async(), eng.read_flags_async()]
         return self._range_checked(boxes, tickets, rerun)
 
     # ------------------------------------------------ deferred range check
@@ -431,8 +445,15 @@ class OETR(nn.Module):
         nodes writing pinned host words): call after synchronising a replay.  A captured batch
         cannot be re-run from here, so a tripped word raises ``OetrRangeError`` whatever
         ``hip_on_overflow`` says (except 'ignore': nothing was captured)."""
-        tripped = any(t.value() & FLAG_INVALID for t in self._graph_tickets)
-        if tripped:
+        flags = 0
+        for t in self._graph_tickets:
+            flags |= t.value()
+        if flags & FLAG_EXCHANGE:
+            self._exchange_failed()
+            raise OetrExchangeError('a batch replayed from a HIP graph lost its split-decoder exchange '
+                                    '(OETR_FLAG_EXCHANGE): re-capture the graph (the engine now runs one '
+                                    'decoder workgroup per image) or re-submit the batch eagerly')
+        if flags & FLAG_F16_RANGE:
             raise OetrRangeError('a batch replayed from a HIP graph overflowed the f16 operand range: '
                                  're-submit it eagerly (exact-fp32 re-run) or use hip_precision "f32"')
 
@@ -444,10 +465,26 @@ class OETR(nn.Module):
             t.release()
         self._graph_tickets = []
 
+    def _exchange_failed(self):
+        """OETR_FLAG_EXCHANGE was read from the main engine's word: re-initialise its status block
+        and keep the decoder on one workgroup per image from here on."""
+        self._split_ok = False
+        if self._engine is not None:
+            self._engine.settle_exchange()
+            self._engine._dec_split_set = 1
+
     def _settle(self, boxes, tickets, rerun):
-        if not any(t.value() & FLAG_INVALID for t in tickets):
+        flags = 0
+        for t in tickets:
+            flags |= t.value()
+        if not flags & FLAG_INVALID:
             return boxes
-        good = rerun()              # raises under hip_on_overflow == 'raise'
+        if flags & FLAG_EXCHANGE:
+            # a residency time-out of the split decoder, not a property of the inputs: the same
+            # precision is submitted again (one workgroup per image); only a range overflow of
+            # THAT run takes the exact-fp32 / raise route
+            self._exchange_failed()
+        good = rerun(exchange_only=not flags & FLAG_F16_RANGE)   # may raise under hip_on_overflow == 'raise'
         for dst, src in zip(boxes, good):
             dst.copy_(src)          # in place and in stream order: holders of `boxes` see the re-run
         return boxes
@@ -470,11 +507,17 @@ class OETR(nn.Module):
         self._check_masks(mask1, mask2)
         self.hip_flush()
         eng = self.engine()
+        checked = self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE
+        self._decoder_policy(eng, checked)
         boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
-        if self.hip_on_overflow == 'ignore' or eng.precision not in eng.F16_RANGE:
+        if not checked:
             return boxes
-        return self._range_checked(boxes, [eng.read_flags_async()],
-                                   lambda: self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2, mask1, mask2))
+
+        def rerun(exchange_only=False):
+            if exchange_only:
+                return self._boxes_checked(feat1, feat2, pos1, pos2, hw1, hw2, mask1, mask2)
+            return self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2, mask1, mask2)
+        return self._range_checked(boxes, [eng.read_flags_async()], rerun)
 
     def _exact_boxes(self, feat1, feat2, pos1, pos2, hw1, hw2, mask1=None, mask2=None):
         if self.hip_on_overflow == 'raise':
@@ -483,12 +526,18 @@ class OETR(nn.Module):
                 f"'{self.hip_precision}'; set hip_precision to 'f32' or 'bf16'")
         return self.exact_engine().forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
 
-    def _boxes_checked(self, feat1, feat2, pos1, pos2, hw1, hw2):
+    def _boxes_checked(self, feat1, feat2, pos1, pos2, hw1, hw2, mask1=None, mask2=None):
         """Immediate (synchronising) form: the re-run route of a tripped fused batch."""
         eng = self.engine()
-        boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2)
-        if eng.precision in eng.F16_RANGE and eng.query_flags() & FLAG_INVALID:
-            boxes = self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2)
+        self._decoder_policy(eng, checked=True)
+        boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
+        flags = eng.query_flags()
+        if flags & FLAG_EXCHANGE:          # (only while the split is still allowed: first time-out)
+            self._exchange_failed()
+            boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
+            flags = eng.query_flags()
+        if eng.precision in eng.F16_RANGE and flags & FLAG_F16_RANGE:
+            boxes = self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2, mask1, mask2)
         return boxes
 
     def forward(self, data, validation=False):
@@ -519,10 +568,17 @@ class OETR(nn.Module):
         with torch.no_grad():
             feat1, feat2, pos1, pos2, hf1, wf1, hf2, wf2 = self.feature_extraction(image1, image2)
             eng = self.engine()
+            checked = self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE
+            self._decoder_policy(eng, checked)
             st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True,
                              mask1=mask1, mask2=mask2)
-            if self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE \
-                    and eng.query_flags() & FLAG_INVALID:
+            flags = eng.query_flags() if checked else 0
+            if flags & FLAG_EXCHANGE:      # residency time-out of the split decoder: same precision again
+                self._exchange_failed()
+                st = eng.forward(feat1, feat2, pos1, pos2, (h1, w1), (h2, w2), stages=True,
+                                 mask1=mask1, mask2=mask2)
+                flags = eng.query_flags()
+            if flags & FLAG_F16_RANGE:
                 if self.hip_on_overflow == 'raise':
                     raise OetrRangeError('a GEMM operand reached |x| >= 65504; use hip_precision "f32"')
                 eng = self.exact_engine()

@@ -43,8 +43,10 @@ extern "C" {
  *    decoder's call counters and exchange granules live there: oetr_set_decoder_split);
  *    OETR_FLAG_EXCHANGE
  * 4: forward_dummy's optional masks: oetr_forward_masked, oetr_feature_correlation_masked,
- *    oetr_center_estimation_masked, oetr_linear_attention_masked (new exports; nothing else changed) */
-#define OETR_ABI_VERSION 4
+ *    oetr_center_estimation_masked, oetr_linear_attention_masked (new exports; nothing else changed)
+ * 5: oetr_debug_decoder_fault (new export, tests only); a timed-out split decoder publishes nothing
+ *    further and the caller re-initialises the status block (OETR_FLAG_EXCHANGE below) */
+#define OETR_ABI_VERSION 5
 #define OETR_D_MODEL 256
 #define OETR_N_HEAD 8
 #define OETR_N_ENC 8 /* self,cross x4  - reference src/models/transformer.py:295 */
@@ -180,7 +182,11 @@ void oetr_destroy(oetr_handle h);
  *   OETR_FLAG_EXCHANGE   the four workgroups of an image's decoder chain (oetr_set_decoder_split)
  *                        did not all become resident within 2 ms - more forwards in flight on
  *                        the device than the automatic rule allows for, or a forced split on a
- *                        busy device.  The outputs of that call are INVALID.  Re-run with
+ *                        busy device.  The outputs of that call are INVALID, and so are those of
+ *                        every call that used the workspace while the bit stood (their decoder
+ *                        workgroups return at once without publishing).  On seeing it: clear it,
+ *                        call oetr_workspace_init again (the per-image call counters and granules
+ *                        of the failed call are not trustworthy) and re-run with
  *                        oetr_set_decoder_split(h, 1).
  * oetr_workspace_init   zeroes the status block (enqueued on `stream`); call it once after
  *                       allocating a workspace (or zero the first OETR_WORKSPACE_STATUS_BYTES
@@ -255,6 +261,13 @@ oetr_status oetr_set_tail_mode(oetr_handle h, int mode);
  * OETR_FLAG_EXCHANGE instead of hanging.  1: one workgroup per image (rounds 1-3).  Results
  * differ between 1 and 4 in fp32 summation order only.  Mutates the handle like the other setters. */
 oetr_status oetr_set_decoder_split(oetr_handle h, int workgroups_per_image);
+
+/* Tests only: the NEXT forward call that runs the four-workgroup decoder has workgroup 1 of image
+ * 0 withhold its first exchange, so that its peers time out (2 ms) and OETR_FLAG_EXCHANGE is
+ * raised on an otherwise idle device - the only way to exercise the caller's recovery path
+ * (status-block reset, re-run on one workgroup per image) deterministically.  One shot: the
+ * call after that is normal again.  `on` = 0 withdraws a pending fault. */
+oetr_status oetr_debug_decoder_fault(oetr_handle h, int on);
 
 /* Attention core of the eight encoder layers.  The reference builds
  * QueryTransformer(attention_mode='linear') (src/model.py:82-84; the config knob

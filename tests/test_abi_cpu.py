@@ -23,7 +23,7 @@ def header_functions():
 def test_library_exports_every_declared_symbol():
     lib = pkg.load_library()
     names = header_functions()
-    assert len(names) == 47, names
+    assert len(names) == 48, names
     assert set(names) == set(hip_engine.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/oetr_hip.h but not exported'

@@ -536,6 +536,86 @@ def test_decoder_split_forms_match_the_goldens(path, precision, gpu):
         eng.set_decoder_split(2)
 
 
+def test_split_decoder_timeout_path_recovers(gpu):
+    """The time-out path of the four-workgroup decoder: ``oetr_debug_decoder_fault`` makes
+    workgroup 1 of image 0 withhold its first exchange on an idle device.  Engine level: the call
+    raises ``OETR_FLAG_EXCHANGE``; a call submitted while the bit stands publishes nothing (its decoder
+    workgroups return at once) and is invalid too; after ``settle_exchange`` (status block re-zeroed)
+    the next calls on the SAME workspace are bit-exact again, in both split forms - no stale granule
+    survives under the next call's tag; ``check_range`` raises ``OetrExchangeError``, not a range
+    error.  Module level: the deferred check re-runs the batch on the same precision with one
+    workgroup per image (never the exact-fp32 route, also under hip_on_overflow = 'raise'), the boxes
+    the caller holds are corrected in place, and the split stays off afterwards."""
+    from imagematching_oetr_amd import (FLAG_EXCHANGE, FLAG_F16_RANGE, HotPathEngine, OetrExchangeError,
+                                        build_detectors, get_cfg_defaults, hot_path_keys)
+    w = orc.make_hot_weights(5, sharpen=True)
+    eng = HotPathEngine(w, device=gpu)
+    n, hf = 3, 13
+    f1, f2 = orc.make_features(91, n, hf, hf).to(gpu), orc.make_features(92, n, hf, hf).to(gpu)
+    pos = orc.position_table(hf, hf).to(gpu)
+    args = (f1, f2, pos, pos, (hf * 32, hf * 32), (hf * 32, hf * 32))
+    eng.set_decoder_split(1)
+    ref1 = [t.clone() for t in eng.forward(*args)]
+    eng.set_decoder_split(4)
+    ref4 = [t.clone() for t in eng.forward(*args)]
+    assert eng.query_flags() == 0
+    # -- the faulted call, and one submitted behind it before anybody has looked at the word
+    eng.debug_decoder_fault()
+    eng.forward(*args)
+    eng.forward(*args)
+    flags = eng.query_flags(clear=True)
+    assert flags & FLAG_EXCHANGE and not flags & FLAG_F16_RANGE, flags
+    eng.settle_exchange()                       # re-zeroes the status block, split -> 1
+    for k, ref in ((1, ref1), (4, ref4), (4, ref4), (1, ref1)):
+        eng.set_decoder_split(k)
+        out = eng.forward(*args)
+        assert eng.query_flags() == 0, k
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), k
+    eng.set_decoder_split(4)
+    eng.debug_decoder_fault()
+    eng.forward(*args)
+    with pytest.raises(OetrExchangeError):
+        eng.check_range()
+    out = eng.forward(*args)                    # check_range settled: one workgroup per image now
+    assert eng.query_flags() == 0 and torch.equal(out[0], ref1[0]) and torch.equal(out[1], ref1[1])
+
+    # -- module level
+    model = build_detectors(get_cfg_defaults().OETR).to(gpu).eval()
+    state = model.state_dict()
+    for k in hot_path_keys():
+        state[k] = w[k].to(gpu)
+    model.load_state_dict(state)
+    for mode in ('f32', 'raise'):
+        model.hip_on_overflow = mode
+        model._split_ok = True
+        good = [t.clone() for t in model.boxes_from_features(*args)]
+        model.hip_flush()
+        assert getattr(model.engine(), '_dec_split_set', 0) == 0      # checked route: automatic rule
+        model.engine().debug_decoder_fault()
+        boxes = model.boxes_from_features(*args)   # deferred: returned before the word was read
+        model.hip_flush()                          # settles: OETR_FLAG_EXCHANGE -> same precision, split 1
+        assert model._split_ok is False and model._engine_f32 is None or mode == 'f32'
+        for b, r in zip(boxes, ref1):
+            assert torch.equal(b, r), mode
+        again = model.boxes_from_features(*args)
+        model.hip_flush()
+        for b, r in zip(again, ref1):
+            assert torch.equal(b, r), mode
+        for b, g in zip(boxes, good):
+            assert maxerr(b, g) <= 0.2 * TOL['box']
+    # routes that read no status word never split: precisions without a range guard, 'ignore', the seams
+    model.hip_on_overflow = 'ignore'
+    model._split_ok = True
+    model.boxes_from_features(*args)
+    assert model.engine()._dec_split_set == 1
+    model.hip_on_overflow = 'f32'
+    model.boxes_from_features(*args)
+    model.hip_flush()
+    assert model.engine()._dec_split_set == 0
+    model.feature_correlation(f1, f2, pos, pos)
+    assert model.engine()._dec_split_set == 1
+
+
 def test_split_decoder_on_concurrent_streams(gpu):
     """Four forwards in flight on four streams (what the automatic rule allows for): the exchanging
     workgroups of all of them are resident together - every batch returns the serial boxes bit for bit
