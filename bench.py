@@ -209,7 +209,7 @@ def cpu_baseline(weights, feat1, feat2, size, size2, budget_s=12.0):
         if dt > budget_s or iters >= 400:
             break
     return dict(value=round(f1.shape[0] * iters / dt, 2), unit='image-pairs/s',
-                cores=best_t, kind='port',
+                cores=best_t, threads=best_t, host_cpus=ncpu, kind='port',
                 sample=f'{iters} batches of {f1.shape[0]} pairs @ {size}x{size}'
                        + (f' vs {size2}x{size2} ' if size2 != size else ' ')
                        + f'(hot path only, features precomputed) in {dt:.1f} s; '
@@ -370,6 +370,11 @@ def end_to_end(args, model, device, n, size2, pkg):
     model.hip_defer_check = False          # the round-2 behaviour: one stream sync per call
     res['end_to_end_pairs_per_s_sync_check'] = round(n / timed(lambda: model.forward_dummy(im1, im2), reps), 1)
     model.hip_defer_check = True
+    # throughput mode of the product path: the hot path of batch i on side stream i mod 3 under the trunk of batch i+1
+    model.hip_streams, model.hip_throughput = 3, None
+    res['end_to_end_pairs_per_s_streams3'] = round(n / timed(lambda: model.forward_dummy(im1, im2), reps), 1)
+    model.hip_flush()
+    model.hip_streams = 1
     # the reference's calling pattern: a stream of single pairs, bucketed by shape into batches of n
     pair_list = [(im1[i:i + 1], im2[i:i + 1]) for i in range(n)] * 2
     t_fp = timed(lambda: pkg.forward_pairs(model, pair_list, max_batch=n), 5)
@@ -697,75 +702,115 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(eng, ns):
+    # Every timed step goes through the PRODUCT path: OETR.boxes_from_features (what forward_dummy
+    # calls behind the trunk) - the model picks the stream (hip_streams: throughput mode, batch i on
+    # side stream i mod k with the engines' throughput settings) and enqueues the deferred range
+    # check behind every batch; hip_flush() at the end of the region settles them in order.
+    model.to(device)
+    model.hip_freeze_weights = True           # (documented knob: skip the per-call parameter identity check)
+    models = {}
+
+    def model_for(precision):
+        if precision not in models:
+            if not models:
+                m = model
+            else:      # a second module on the same weights (the engines hold ctypes handles: no deepcopy)
+                m = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+                m.load_state_dict(model.state_dict())
+                m = m.to(device)
+                m.hip_freeze_weights = True
+            m.hip_precision = precision
+            m.hip_attention = args.attention if precision == args.precision else 'linear'
+            m.hip_enc_tile = args.enc_tile or None
+            models[precision] = m
+        return models[precision]
+
+    def configure(m, ns, overlapped):
+        """Stream count + engine settings of a region, OUTSIDE the timed part (the setters need an idle
+        device).  Defaults = the model's own policy; the --*-overlap / --decoder-split flags are A/B knobs."""
+        m.hip_flush()
+        m.hip_streams = ns
+        m.hip_throughput = bool(overlapped)
+        eng = m.engine()
+        half = eng.precision != 'f32'
+        if overlapped:
+            if args.tail_mode_overlap != 2 and eng.precision in ('f32_split_f16', 'f32_split_qk16'):
+                eng.set_tail_mode(args.tail_mode_overlap)
+            if eng.attention == 'linear':
+                eng.set_state_prereduce(args.prereduce_overlap)
+            if args.decoder_split_overlap:
+                eng.set_decoder_split(args.decoder_split_overlap); eng._dec_split_set = args.decoder_split_overlap
+        else:
+            if eng.attention == 'linear':
+                eng.set_state_prereduce(-1)
+            if args.decoder_split:
+                eng.set_decoder_split(args.decoder_split); eng._dec_split_set = args.decoder_split
+        return eng, (args.enc_tile or (64 if (overlapped and half and eng.attention == 'linear') else 0))
+
+    step_spread = {}
+
+    def run_mode(m, ns):
         """One timed region: exactly --steps steps over `ns` streams."""
         def step(i):
-            # consecutive steps alternate over the streams (one workspace per stream in
+            # consecutive steps alternate over the model's streams (one workspace per stream in
             # the engine); every step is a full batch of n pairs through the whole path
-            with torch.cuda.stream(streams[i % ns]):
-                b1, b2 = eng.forward(feat1, feat2, pos, pos2, hw, hw2)
-                if gatherer is not None:
-                    # the all-gather of this batch's boxes runs on RCCL's stream under the
-                    # next batch's kernels; it is completed at the next submit / the flush
+            b1, b2 = m.boxes_from_features(feat1, feat2, pos, pos2, hw, hw2)
+            if gatherer is not None:
+                # the all-gather of this batch's boxes is enqueued right behind the batch (its
+                # stream) and runs on RCCL's stream under the next batch's kernels; it is
+                # completed at the next submit / the flush
+                with torch.cuda.stream(m.hip_batch_stream()):
                     gatherer.submit(b1, b2)
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
+        m.hip_flush()                   # every batch's range check settled, in submission order
         if gatherer is not None:
             gatherer.flush()            # last batch's gather is inside the timed region
         barrier()
         dt = time.perf_counter() - t0
         if use_pg:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            t = torch.tensor([dt, -dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            step_spread['last'] = (float(-t[1].item()), float(t[0].item()))   # (fastest, slowest) rank
+            dt = float(t[0].item())
         return dt
 
-    def warm(eng, ns):
+    def warm(m, ns):
         saved, args.steps = args.steps, max(1, args.warmup)
-        run_mode(eng, ns)
+        run_mode(m, ns)
         args.steps = saved
 
-    def repeated(eng, ns):
-        regions = sorted(run_mode(eng, ns) for _ in range(max(1, args.repeats)))
+    def repeated(m, ns):
+        regions = sorted(run_mode(m, ns) for _ in range(max(1, args.repeats)))
         return statistics.median(regions), regions[0], regions[-1]
 
-    def traced(eng):
+    def traced(m, eng):
         with pkg.KernelTrace(eng, max_launches=24 * args.steps + 64) as trace:
-            dt = run_mode(eng, 1)
+            dt = run_mode(m, 1)
         return trace.summary(), dt
 
     def measure(precision, with_serial_trace):
-        eng = pkg.HotPathEngine(weights, device=device, precision=precision,
-                                attention=args.attention if precision == args.precision else 'linear')
-        half = precision != 'f32'
-        tile_overlap = args.enc_tile or (64 if (n_streams > 1 and half and eng.attention == 'linear') else 0)
-        res = {'tile_overlap': tile_overlap, 'engine': eng}
-        eng.set_encoder_tile(args.enc_tile)
-        warm(eng, 1)
-        eng.set_encoder_tile(tile_overlap)
-        eng.set_decoder_split(args.decoder_split_overlap if n_streams > 1 else args.decoder_split)
-        if n_streams > 1 and half and precision != 'f16' and precision != 'bf16':
-            eng.set_tail_mode(args.tail_mode_overlap)
-        if n_streams > 1 and eng.attention == 'linear':
-            eng.set_state_prereduce(args.prereduce_overlap)
-        warm(eng, n_streams)
-        res['overlap'] = repeated(eng, n_streams)            # -> value (no instrumentation)
+        m = model_for(precision)
+        eng, _ = configure(m, 1, False)
+        res = {'engine': eng, 'model': m}
+        warm(m, 1)
+        eng, tile_overlap = configure(m, n_streams, n_streams > 1)
+        res['tile_overlap'] = tile_overlap
+        warm(m, n_streams)
+        res['overlap'] = repeated(m, n_streams)              # -> value (no instrumentation)
+        res['rank_spread'] = step_spread.get('last')
         if not args.no_trace:
             # same K steps on ONE stream (kernel durations only mean something when launches
             # do not share the chip), in the tile shape that produced `value`, with the
             # library's per-kernel HIP events recorded on its launch stream
-            res['trace_overlap_shape'] = traced(eng)
-        eng.set_encoder_tile(args.enc_tile)
-        eng.set_decoder_split(args.decoder_split)
-        if half and precision != 'f16' and precision != 'bf16':
-            eng.set_tail_mode(0)
-        if eng.attention == 'linear':
-            eng.set_state_prereduce(-1)
-        res['serial'] = repeated(eng, 1) if n_streams > 1 else res['overlap']
+            configure(m, 1, n_streams > 1)
+            res['trace_overlap_shape'] = traced(m, eng)
+        configure(m, 1, False)
+        res['serial'] = repeated(m, 1) if n_streams > 1 else res['overlap']
         if not args.no_trace and with_serial_trace and tile_overlap != (args.enc_tile or 0):
-            res['trace_serial_shape'] = traced(eng)
+            res['trace_serial_shape'] = traced(m, eng)
         return res
 
     main_res = measure(args.precision, with_serial_trace=True)
@@ -817,6 +862,11 @@ def main():
                                + (', attention=full' if args.attention == 'full' else ''),
                    'pairs_per_gpu': n, 'global_pairs': n_total,
                    'streams': n_streams,
+                   'api': 'OETR.boxes_from_features with model.hip_streams = %d (product path; deferred range check '
+                          'per batch, settled by hip_flush inside the timed region)' % n_streams,
+                   'world_size': world,
+                   'rank_step_ms_fastest_slowest': ([round(v / args.steps * 1e3, 4) for v in main_res['rank_spread']]
+                                                     if main_res.get('rank_spread') else None),
                    'encoder_tile_rows': tile_overlap or 'auto',
                    'tail_mode': ({0: 'library rule', 1: 'P form', 2: 'direct form (throughput setting for overlapped streams)',
                                   3: 'direct form, per-tap staging'}[args.tail_mode_overlap]
@@ -842,6 +892,7 @@ def main():
             out['roofline'] = rb
             out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
                                  for k, v in kern.items()}
+            out['kernels_us_sum'] = round(sum(v[1] for v in kern.values()) / args.steps * 1e3, 1)
     if 'trace_serial_shape' in main_res:
         kern, t_s = main_res['trace_serial_shape']
         rb = roofline_block(kern, args.precision, tokens, 64 if args.precision in POLICY_ID else (args.enc_tile or 32), args.steps, t_s, standard, extra_flop,
@@ -850,6 +901,8 @@ def main():
             out['serial']['roofline'] = rb
             out['serial']['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
                                            for k, v in kern.items()}
+            # (per-kernel HIP events inflate each launch by their own cost: the sum exceeds the untraced step)
+            out['serial']['kernels_us_sum'] = round(sum(v[1] for v in kern.values()) / args.steps * 1e3, 1)
     if exact_res is not None:
         x_med, x_min, x_max = exact_res['overlap']
         xs_med = exact_res['serial'][0]
@@ -886,7 +939,22 @@ def main():
     if (not args.no_other_configs and world == 1 and standard and args.precision == 'f32_split_f16'
             and not args.no_trace):
         try:     # configs[2] / [3] / [4] under the same clock (short regions, ~20 s)
-            out['other_configs'] = other_configs(args, device, pkg)
+            oc = other_configs(args, device, pkg)
+            out['other_configs'] = oc
+            if 'roofline' in out:
+                def compact(prefix):
+                    for k, v in oc.items():
+                        if k.startswith(prefix) and isinstance(v, dict):
+                            r = v.get('roofline', {})
+                            return [v['pairs_per_s'], r.get('frac'), r.get('avg_launch_us'), v['serial_pairs_per_s']]
+                    return None
+                # [pairs/s overlapped, frac of the dominant kernel's roof, its average launch us, pairs/s serial]
+                out['roofline']['other_configs'] = {
+                    'c3_32p_1024': compact('configs[3] 32 pairs @1024x1024, auto'),
+                    'c3_32p_1024_tile32': compact('configs[3] 32 pairs @1024x1024, 32-row'),
+                    'c4_8p_640v1280': compact('configs[4] share: 8 pairs 640x640 vs 1280x1280, default'),
+                    'c4_policy': compact('configs[4] share: 8 pairs 640x640 vs 1280x1280, precision policy'),
+                    'c2_policy': compact('configs[2] share')}
         except Exception as e:
             out['other_configs_error'] = repr(e)[:300]
     if use_pg:

@@ -331,7 +331,7 @@ class FlagTicket:
 class _FlagReader:
     """Pinned host words for asynchronous status reads, one set per engine: a ring for eager
     calls (each word is consumed before the ring comes round: the deferred check settles
-    batch i when batch i+1 is submitted) and words handed out to calls captured into a HIP
+    batch i when batch i+2 is submitted - at most two batches, i.e. four words, are pending) and words handed out to calls captured into a HIP
     graph (every replay rewrites them) until the ticket is released.  Pinning host memory is
     not allowed while a stream is capturing, so graph words come in pages allocated OUTSIDE
     capture: one page up front, another whenever an eager call finds the free list short
@@ -1055,7 +1055,7 @@ def linear_attention(q, k, v, q_mask=None, kv_mask=None):
             masks[0].data_ptr() if masks[0] is not None else None,
             masks[1].data_ptr() if masks[1] is not None else None,
             n, L, S, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q.device)),
-            'oetr_linear_attention_masked', 'oetr_debug_decoder_fault')
+            'oetr_linear_attention_masked')
     return out
 
 

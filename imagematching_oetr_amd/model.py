@@ -17,6 +17,8 @@ key for key and so that random init follows the reference's
 (Xavier-uniform on the transformer matrices, ``transformer.py:308-311``).
 Their ``forward`` is never called.
 """
+import collections
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -132,7 +134,8 @@ class OETR(nn.Module):
         self.hip_on_overflow = 'f32'
         #: True (default): forward_dummy only ENQUEUES - the status word of batch i travels to a
         #: pinned host word behind the batch (oetr_read_flags_async) and is examined when batch
-        #: i+1 is submitted, or by hip_flush(); a tripped batch is then re-run ('f32': its box
+        #: i+2 is submitted (one batch stays in flight behind the one being submitted, so the host
+        #: never waits for the device), or by hip_flush(); a tripped batch is then re-run ('f32': its box
         #: tensors are overwritten in place, in stream order) or reported ('raise').  The boxes
         #: of the LAST batch are final after hip_flush().  False: check before returning (one
         #: stream synchronisation per call, as the reference's consumers read boxes at once)
@@ -166,7 +169,20 @@ class OETR(nn.Module):
         self._neck_key = None
         self._hot_params = None       # cached parameter lists of the identity checks (engine())
         self._neck_params = None
-        self._pending = None          # deferred range check of the previous batch (hip_defer_check)
+        #: THROUGHPUT MODE: batches of consecutive forward_dummy / boxes_from_* calls alternate over this
+        #: many HIP streams (one workspace per stream in the engines), so that the kernels of batch
+        #: i+1 fill the CUs batch i leaves idle; the engines run their throughput settings (64-token
+        #: encoder workgroups, direct tail form: fewest CU-microseconds per batch).  The trunk stays
+        #: on the caller's stream; every side stream waits for its inputs.  Box tensors are complete
+        #: - and range-checked, in submission order - after hip_flush() (forward_pairs* call it); at
+        #: most hip_streams batches are in flight.  1 (default): latency mode, everything on the
+        #: caller's stream with the automatic rules.
+        self.hip_streams = 1
+        #: the engines' throughput settings without the streams (None: follow hip_streams > 1)
+        self.hip_throughput = None
+        self._inflight = collections.deque()   # submitted, not yet settled: (boxes, tickets, rerun, stream, event)
+        self._side_streams = []
+        self._submitted = 0
         self._graph_tickets = []      # status reads captured into HIP graphs (hip_graph_check)
 
     # ---------------------------------------------------------------- host
@@ -267,6 +283,7 @@ class OETR(nn.Module):
         ops (see :meth:`invalidate_engine` for the writes it cannot see)."""
         if self.hip_freeze_weights and self._engine is not None and \
                 self._engine_key[:3] == (self.hip_precision, self.hip_enc_tile, self.hip_attention):
+            self._throughput_policy(self._engine)
             return self._engine
         if self._hot_params is None:      # (151 get_parameter() lookups cost ~0.5 ms: done once)
             self._hot_params = [self.get_parameter(k) for k in hot_path_keys()]
@@ -286,7 +303,25 @@ class OETR(nn.Module):
                                          attention=self.hip_attention)
             self._engine_key = key
             self._split_ok = True     # False once OETR_FLAG_EXCHANGE was seen on this engine (settle_exchange)
+            self._engine._throughput_set = None
+        self._throughput_policy(self._engine)
         return self._engine
+
+    def _throughput_policy(self, eng):
+        """Latency or throughput settings of the engine (``hip_streams`` / ``hip_throughput``):
+        the setters mutate the handle, so a change is applied with nothing in flight."""
+        want = bool(self.hip_streams > 1 if self.hip_throughput is None else self.hip_throughput)
+        if getattr(eng, '_throughput_set', None) == want:
+            return
+        if getattr(eng, '_throughput_set', None) is not None:      # (first call on a fresh engine: nothing in flight yet)
+            self.hip_flush()
+            torch.cuda.synchronize(eng.device)
+        two_plane = eng.precision in ('f32_split_f16', 'f32_split_qk16')
+        if self.hip_enc_tile is None and eng.precision != 'f32' and eng.attention == 'linear':
+            eng.set_encoder_tile(64 if want else 0)
+        if two_plane:
+            eng.set_tail_mode(2 if want else 0)
+        eng._throughput_set = want
 
     def _decoder_policy(self, eng, checked):
         """The four-workgroup decoder chain (``oetr_set_decoder_split``) waits for its peers and
@@ -295,7 +330,7 @@ class OETR(nn.Module):
         acted on; every other route - precisions without a range guard, ``hip_on_overflow =
         'ignore'``, the reference's inner seams - runs one workgroup per image, which waits for
         nobody.  Also off for good once a time-out was seen on this engine."""
-        want = 0 if (checked and getattr(self, '_split_ok', True)) else 1
+        want = 0 if (checked and getattr(self, '_split_ok', True) and self.hip_streams <= 4) else 1
         if getattr(eng, '_dec_split_set', None) != want:
             eng.set_decoder_split(want)
             eng._dec_split_set = want
@@ -371,7 +406,7 @@ class OETR(nn.Module):
         (box1, box2), each [N,4] xyxy pixels.  ``mask1`` / ``mask2`` [N,hf,wf]: the
         reference's optional masks at the token grid's resolution (padded batches)."""
         masked = self._check_masks(mask1, mask2)
-        self.hip_flush()          # the previous batch's deferred range check (no-op otherwise)
+        self._settle_down_to(max(1, int(self.hip_streams)) - 1)   # the deferred checks of earlier batches, oldest first
         h1, w1 = image1.shape[1:3]
         h2, w2 = image2.shape[1:3]
         self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
@@ -399,46 +434,104 @@ class OETR(nn.Module):
         ``bb1``/``bb2`` are halves of (one neck call).  Same values as
         ``feature_extraction`` + ``boxes_from_features``, which is also the route taken
         when a range flag trips."""
-        self.hip_flush()          # (idempotent after forward_dummy's: a direct caller's previous batch)
         eng, neck = self.engine(), self.neck_engine()
         n = int(bb1.shape[0])
         hf1, wf1 = int(bb1.shape[2]) // 2, int(bb1.shape[3]) // 2
         hf2, wf2 = int(bb2.shape[2]) // 2, int(bb2.shape[3]) // 2
-        bufs = eng.token_buffers(n, hf1, wf1, hf2, wf2)
+        checked = self.hip_on_overflow != 'ignore'
+        self._decoder_policy(eng, checked)
         meta = lambda h, w: torch.empty(1, 1, h, w, device='meta')   # pos_encoding reads sizes only
-        eng.load_pos_tokens(bufs, self.pos_encoding(meta(hf1, wf1)), self.pos_encoding(meta(hf2, wf2)))
-        if both is not None:
-            neck.forward_tokens(both, bufs['tokens'])
-        else:
-            neck.forward_tokens(bb1, bufs['tokens1'])
-            neck.forward_tokens(bb2, bufs['tokens2'])
-        self._decoder_policy(eng, checked=self.hip_on_overflow != 'ignore')
-        boxes = eng.forward_tokens(n, hf1, wf1, hf2, wf2, hw1, hw2)
-        if self.hip_on_overflow == 'ignore':
-            return boxes
+        pos1, pos2 = self.pos_encoding(meta(hf1, wf1)), self.pos_encoding(meta(hf2, wf2))
+
+        def enqueue():
+            bufs = eng.token_buffers(n, hf1, wf1, hf2, wf2)
+            eng.load_pos_tokens(bufs, pos1, pos2)
+            if both is not None:
+                neck.forward_tokens(both, bufs['tokens'])
+            else:
+                neck.forward_tokens(bb1, bufs['tokens1'])
+                neck.forward_tokens(bb2, bufs['tokens2'])
+            boxes = eng.forward_tokens(n, hf1, wf1, hf2, wf2, hw1, hw2)
+            # (the engine's word is read in every checked precision: OETR_FLAG_EXCHANGE is not a range matter)
+            return boxes, ([neck.read_flags_async(), eng.read_flags_async()] if checked else [])
 
         def rerun(exchange_only=False):   # the unfused route carries the per-stage handling (raise / exact fp32)
             feat1, feat2 = self.neck(bb1), self.neck(bb2)
             return self._boxes_checked(feat1, feat2, self.pos_encoding(feat1), self.pos_encoding(feat2),
                                        hw1, hw2)
-        # (the engine's word is read in every checked precision: OETR_FLAG_EXCHANGE is not a range matter)
-        tickets = [neck.read_flags_async(), eng.read_flags_async()]
-        return self._range_checked(boxes, tickets, rerun)
+        return self._submit(enqueue, rerun if checked else None, [bb1, bb2] if both is None else [both])
+
+    # -------------------------------------- submission, deferred range check
+    def _streams(self, k):
+        dev = self.engine().device
+        while len(self._side_streams) < k:
+            self._side_streams.append(torch.cuda.Stream(device=dev))
+        return self._side_streams
+
+    def _submit(self, enqueue, rerun, inputs):
+        """``enqueue()`` -> (boxes, tickets): the HIP calls of one batch and the asynchronous reads of
+        the status words behind them.  One stream (default): on the caller's stream, after the
+        deferred check of the previous batch.  ``hip_streams`` = k > 1: on side stream (batch index
+        mod k), which first waits for the caller's stream (the batch's inputs); at most k batches
+        stay in flight, their checks are settled oldest first.  ``rerun`` None: nothing to check."""
+        k = max(1, int(self.hip_streams))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if k == 1 or capturing:
+            # one batch stays in flight behind the one being submitted (its status word is still on
+            # its way): settling it here would make the host wait for the device before every submit
+            self._settle_down_to(0 if (capturing or not self.hip_defer_check) else 1)
+            self._last_side = None
+            boxes, tickets = enqueue()
+            if rerun is None:
+                return boxes
+            return self._range_checked(boxes, tickets, rerun)
+        self._settle_down_to(k - 1)
+        dev = self.engine().device
+        side = self._streams(k)[self._submitted % k]
+        self._submitted += 1
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            boxes, tickets = enqueue()
+            done = torch.cuda.Event()
+            done.record(side)
+        for t in inputs:                      # allocated on the caller's stream, read on `side`
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(side)
+        self._inflight.append([boxes, tickets, rerun, side, done, False])
+        self._last_side = side
+        if not self.hip_defer_check:
+            self._settle_down_to(0)
+        return boxes
+
+    def hip_batch_stream(self):
+        """The HIP stream the most recently submitted batch was enqueued on (throughput mode:
+        one of the side streams; otherwise the caller's current stream) - for work that must be
+        ordered right behind that batch without waiting for hip_flush(), e.g. an asynchronous
+        all-gather of its boxes."""
+        side = getattr(self, '_last_side', None)
+        if side is not None and self.hip_streams > 1:
+            return side
+        return torch.cuda.current_stream(self.engine().device)
 
     # ------------------------------------------------ deferred range check
     def _range_checked(self, boxes, tickets, rerun):
-        """``boxes`` were enqueued together with ``tickets`` (asynchronous reads of the status
-        words behind them).  Deferred mode: remember them, return at once; the check runs at
-        the next submit / ``hip_flush()``.  Immediate mode: wait for the words now."""
+        """``boxes`` were enqueued on the caller's stream together with ``tickets``.  Deferred
+        mode: remember them, return at once; the check runs at the next submit / ``hip_flush()``.
+        Immediate mode: wait for the words now."""
         if torch.cuda.is_current_stream_capturing():
             # part of a HIP graph: nothing can be examined now, and every replay rewrites the
             # words - hip_graph_check() reads them after the caller has synchronised a replay
             self._graph_tickets += tickets
             return boxes
-        if self.hip_defer_check:
-            self._pending = (boxes, tickets, rerun)
-            return boxes
-        return self._settle(boxes, tickets, rerun)
+        self._inflight.append([boxes, tickets, rerun, None, None, False])
+        if not self.hip_defer_check:
+            self._settle_down_to(0)
+        return boxes
+
+    @property
+    def _pending(self):
+        """The most recently submitted batch whose check has not been settled (None: none)."""
+        return self._inflight[-1] if self._inflight else None
 
     def hip_graph_check(self):
         """Range guard of forward calls CAPTURED into a HIP graph (their status reads are graph
@@ -465,39 +558,63 @@ class OETR(nn.Module):
             t.release()
         self._graph_tickets = []
 
-    def _exchange_failed(self):
-        """OETR_FLAG_EXCHANGE was read from the main engine's word: re-initialise its status block
-        and keep the decoder on one workgroup per image from here on."""
+    def _exchange_failed(self, side=None):
+        """OETR_FLAG_EXCHANGE was read from the main engine's word (of the workspace of stream
+        ``side``; None = the caller's): re-initialise that status block and keep the decoder on one
+        workgroup per image from here on."""
         self._split_ok = False
         if self._engine is not None:
-            self._engine.settle_exchange()
+            if side is None:
+                self._engine.settle_exchange()
+            else:
+                with torch.cuda.stream(side):
+                    self._engine.settle_exchange()
             self._engine._dec_split_set = 1
 
-    def _settle(self, boxes, tickets, rerun):
+    def _settle_down_to(self, keep):
+        """Settle submitted batches, oldest first, until at most ``keep`` are in flight: the
+        caller's stream is ordered behind the batch (side streams), its status words are read
+        (they have long arrived unless the batch is the newest), a tripped batch is re-run and
+        its box tensors are corrected in place."""
+        while len(self._inflight) > keep:
+            boxes, tickets, rerun, side, done, tainted = self._inflight.popleft()
+            if side is not None:
+                cur = torch.cuda.current_stream(boxes[0].device)
+                cur.wait_event(done)
+                for b in boxes:
+                    b.record_stream(cur)       # allocated on `side`, consumed on the caller's stream
+            if rerun is not None:
+                self._settle(boxes, tickets, rerun, side, tainted)
+
+    def _settle(self, boxes, tickets, rerun, side=None, tainted=False):
         flags = 0
         for t in tickets:
             flags |= t.value()
-        if not flags & FLAG_INVALID:
+        if not flags & FLAG_INVALID and not tainted:
             return boxes
         if flags & FLAG_EXCHANGE:
             # a residency time-out of the split decoder, not a property of the inputs: the same
             # precision is submitted again (one workgroup per image); only a range overflow of
-            # THAT run takes the exact-fp32 / raise route
-            self._exchange_failed()
+            # THAT run takes the exact-fp32 / raise route.  Batches already enqueued BEHIND this one
+            # on the same stream used the failed call's status block (its call counters are not
+            # trustworthy): they are re-run as well when their turn comes.
+            for later in self._inflight:
+                if later[3] is side:
+                    later[5] = True
+            self._exchange_failed(side)
         good = rerun(exchange_only=not flags & FLAG_F16_RANGE)   # may raise under hip_on_overflow == 'raise'
         for dst, src in zip(boxes, good):
             dst.copy_(src)          # in place and in stream order: holders of `boxes` see the re-run
         return boxes
 
     def hip_flush(self):
-        """Complete the deferred range check of the last submitted batch (``hip_defer_check``):
-        waits for that batch's status words only (an event behind an asynchronous 4-byte
-        copy).  A tripped batch is re-run in exact fp32 into the box tensors it returned
-        ('f32') or raises ``OetrRangeError`` ('raise').  Called automatically when the next
-        batch is submitted; call it before consuming the boxes of the LAST batch."""
-        pending, self._pending = getattr(self, '_pending', None), None
-        if pending is not None:
-            self._settle(*pending)
+        """Complete every submitted batch's deferred range check (``hip_defer_check``), oldest
+        first: waits for those batches' status words only (an event behind an asynchronous 4-byte
+        copy each) and orders the caller's stream behind the side streams of the throughput mode.
+        A tripped batch is re-run in exact fp32 into the box tensors it returned ('f32') or raises
+        ``OetrRangeError`` ('raise').  Called automatically as far as needed when the next batch is
+        submitted; call it before consuming the boxes of the LAST batch(es)."""
+        self._settle_down_to(0)
 
     def boxes_from_features(self, feat1, feat2, pos1, pos2, hw1, hw2, mask1=None, mask2=None):
         """Everything after ``feature_extraction`` (reference ``src/model.py:239-252``)
@@ -505,19 +622,19 @@ class OETR(nn.Module):
         like ``forward_dummy``'s under ``hip_defer_check``; the exact-fp32 re-run carries the
         masks too)."""
         self._check_masks(mask1, mask2)
-        self.hip_flush()
         eng = self.engine()
         checked = self.hip_on_overflow != 'ignore' and eng.precision in eng.F16_RANGE
         self._decoder_policy(eng, checked)
-        boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
-        if not checked:
-            return boxes
+
+        def enqueue():
+            boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
+            return boxes, ([eng.read_flags_async()] if checked else [])
 
         def rerun(exchange_only=False):
             if exchange_only:
                 return self._boxes_checked(feat1, feat2, pos1, pos2, hw1, hw2, mask1, mask2)
             return self._exact_boxes(feat1, feat2, pos1, pos2, hw1, hw2, mask1, mask2)
-        return self._range_checked(boxes, [eng.read_flags_async()], rerun)
+        return self._submit(enqueue, rerun if checked else None, [feat1, feat2, pos1, pos2, mask1, mask2])
 
     def _exact_boxes(self, feat1, feat2, pos1, pos2, hw1, hw2, mask1=None, mask2=None):
         if self.hip_on_overflow == 'raise':

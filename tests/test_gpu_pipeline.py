@@ -407,3 +407,77 @@ def test_training_forward_matches_the_reference_results(gpu, golden_dir):
             assert err <= tol, ('masked', tag, k, err)
         assert float((res['pred_bbox1'].cpu() - torch.from_numpy(g[f'{tag}_pred_bbox1'])).abs().max()) > 0.5   # the masks matter
     model.cycle, model.oiou = False, False
+
+
+def test_throughput_mode_is_the_serial_result_bit_for_bit(gpu):
+    """the throughput mode as a product path.  ``model.hip_streams = 3``: consecutive
+    batches alternate over three side streams with the engines' throughput settings (64-token encoder
+    workgroups, direct tail), one workspace per stream, at most three batches in flight, range checks
+    settled in submission order.  Twelve batches of three shapes, one of them overflow-injected (its
+    status word trips on a side stream while its neighbours are in flight; it is re-run in exact fp32
+    and corrected in place): after hip_flush() every batch equals - bit for bit - what the same
+    settings return one batch at a time; the tripped batch equals the exact-fp32 engine."""
+    import imagematching_oetr_amd as pkg
+    from oracle import oetr_oracle as orc
+    torch.manual_seed(0)
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    sd = model.state_dict()
+    w = orc.make_hot_weights(5, sharpen=True)
+    sd.update(w)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    shapes = [(3, 13, 13), (8, 20, 20), (2, 10, 20)]
+    batches = []
+    for i in range(12):
+        n, h1, h2 = shapes[i % 3]
+        f1, f2 = orc.make_features(100 + i, n, h1, h1), orc.make_features(200 + i, n, h2, h2)
+        if i == 4:
+            f1 = f1 * 4.0e5                       # a GEMM operand beyond the f16 range
+        batches.append([t.to(gpu) for t in (f1, f2, orc.position_table(h1, h1), orc.position_table(h2, h2))]
+                       + [(h1 * 32, h1 * 32), (h2 * 32, h2 * 32)])
+    # one batch at a time, the same engine settings
+    model.hip_streams, model.hip_throughput = 1, True
+    serial = []
+    for b in batches:
+        out = model.boxes_from_features(*b)
+        model.hip_flush()
+        serial.append([t.clone() for t in out])
+    exact = pkg.HotPathEngine(w, device=gpu, precision='f32')
+    exact.set_decoder_split(1)
+    e = exact.forward(*batches[4])
+    assert torch.equal(serial[4][0], e[0]) and torch.equal(serial[4][1], e[1])
+    # three streams
+    model.hip_streams, model.hip_throughput = 3, None
+    for rnd in range(3):
+        outs, most = [], 0
+        for b in batches:
+            outs.append(model.boxes_from_features(*b))
+            most = max(most, len(model._inflight))
+        assert most == 3, most
+        assert model.hip_batch_stream() in model._side_streams
+        model.hip_flush()
+        assert len(model._inflight) == 0
+        torch.cuda.synchronize()
+        for i, (o, r) in enumerate(zip(outs, serial)):
+            assert torch.equal(o[0], r[0]) and torch.equal(o[1], r[1]), (rnd, i)
+    assert model.engine().query_flags() == 0
+    # 'raise' reports the tripped batch when ITS turn comes, and leaves the queue consistent
+    model.hip_on_overflow = 'raise'
+    for b in batches[:4]:
+        model.boxes_from_features(*b)
+    model.boxes_from_features(*batches[4])
+    model.boxes_from_features(*batches[5])
+    with pytest.raises(pkg.OetrRangeError):
+        model.hip_flush()
+    model.hip_flush()                             # the batches behind it
+    assert len(model._inflight) == 0
+    model.hip_on_overflow = 'f32'
+    # the pair front-end from images (trunk on the caller's stream, hot path on the side streams)
+    g = torch.Generator().manual_seed(3)
+    pairs = [(torch.rand(160, 192, 3, generator=g), torch.rand(192, 160, 3, generator=g)) for _ in range(5)] + \
+            [(torch.rand(128, 128, 3, generator=g), torch.rand(128, 128, 3, generator=g)) for _ in range(4)]
+    many = pkg.forward_pairs(model, pairs, max_batch=2)
+    model.hip_streams, model.hip_throughput = 1, True
+    one = pkg.forward_pairs(model, pairs, max_batch=2)
+    # (two trunk runs: MIOpen's convolutions are not run-to-run bit-stable; box tolerance)
+    assert float((many[0] - one[0]).abs().max()) <= 5e-2 and float((many[1] - one[1]).abs().max()) <= 5e-2

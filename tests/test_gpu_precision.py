@@ -331,16 +331,19 @@ def test_module_reruns_an_overflowing_batch_in_exact_fp32(gpu, defer):
     assert model._engine_f32 is None
 
 
-def test_deferred_check_settles_one_call_later(gpu):
-    """hip_defer_check: batch i's status word is examined when batch i+1 is submitted - the
-    injected x4e5 batch's boxes are overwritten by the exact re-run at that point, and the
-    in-range batch that follows is untouched."""
+def test_deferred_check_settles_two_calls_later(gpu):
+    """hip_defer_check: batch i's status word is examined when batch i+2 is submitted (round 5: one
+    batch stays in flight behind the one being submitted, so the host never waits for the device) -
+    the injected x4e5 batch's boxes are overwritten by the exact re-run at that point, and the
+    in-range batches that follow are untouched."""
     pkg, model, w, dev = _overflow_model(gpu)
     good = [dev[0] / 4.0e5] + dev[1:]
     bad1, bad2 = model.boxes_from_features(*dev, (256, 320), (320, 256))      # trips, unnoticed so far
     assert model._pending is not None and model._engine_f32 is None
-    ok1, ok2 = model.boxes_from_features(*good, (256, 320), (320, 256))       # settles the first
-    assert model._engine_f32 is not None
+    ok1, ok2 = model.boxes_from_features(*good, (256, 320), (320, 256))       # the first stays in flight
+    assert model._engine_f32 is None and len(model._inflight) == 2
+    model.boxes_from_features(*good, (256, 320), (320, 256))                  # settles the first
+    assert model._engine_f32 is not None and len(model._inflight) == 2
     exact = pkg.HotPathEngine(w, device=gpu, precision='f32')
     exact.set_decoder_split(1)     # as the module's re-run route (waits for nobody)
     e1, e2 = exact.forward(*dev, (256, 320), (320, 256))
