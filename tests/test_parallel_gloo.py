@@ -240,6 +240,88 @@ def test_forward_sharded_world2_gloo(n_pairs):
         assert torch.equal(torch.tensor(c1), f1) and torch.equal(torch.tensor(c2), f2), rank   # masked: sharded with the pairs
 
 
+def _world8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from imagematching_oetr_amd.parallel import BoxGatherer, forward_sharded
+        from imagematching_oetr_amd.pipeline import forward_pairs_sharded
+        out = {}
+        for n_pairs in (64, 61):          # BASELINE configs[2]: 64 pairs over 8 GPUs = 8 per rank; and an indivisible job
+            lo, hi = shard_bounds(n_pairs, rank, world)
+            idx = torch.arange(lo, hi, dtype=torch.float32)
+            box1 = torch.stack([idx, idx + 0.25, idx + 0.5, idx + 0.75], 1)
+            g1, g2 = gather_boxes(box1, -box1, n_pairs)
+            out['gather', n_pairs] = (g1.tolist(), g2.tolist(), hi - lo)
+            gat = BoxGatherer()
+            assert gat.submit(box1, -box1, n_pairs=n_pairs) is None
+            nxt = gat.submit(box1 + 1000, -box1, n_pairs=n_pairs)        # returns batch 0
+            last = gat.flush()
+            out['pipe', n_pairs] = (nxt[0].tolist(), last[0].tolist())
+            g = torch.Generator().manual_seed(3)                       # every rank holds the full batch
+            im1, im2 = torch.rand(n_pairs, 6, 5, 3, generator=g), torch.rand(n_pairs, 4, 7, 3, generator=g)
+            b1, b2 = forward_sharded(_StubModel(), im1, im2)
+            out['sharded', n_pairs] = (b1.tolist(), b2.tolist())
+        # BASELINE configs[4] as a mixed-scale job: two shapes interleaved, 61 pairs, chunks of 8
+        g = torch.Generator().manual_seed(4)
+        pairs = []
+        for i in range(61):
+            hw2 = (8, 8) if i % 3 else (16, 16)          # "640 vs 640" and "640 vs 1280"
+            pairs.append((torch.rand(8, 8, 3, generator=g), torch.rand(*hw2, 3, generator=g)))
+        m1, m2 = forward_pairs_sharded(_StubModel(), pairs, max_batch=8)
+        out['mixed'] = (m1.tolist(), m2.tolist())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_gloo_dry_run_of_the_scaling_job():
+    """the first real 8-GPU attempt must not fail on arithmetic.  Eight gloo ranks
+    run what `bench.py --gpus 8` and the pair front-end run over RCCL: `gather_boxes` and the pipelined
+    `BoxGatherer` at BASELINE configs[2]'s real split (64 pairs = 8 per rank) and at an indivisible 61
+    (shards of 8 and 7, padded to 8 for the one all_gather_into_tensor), `forward_sharded`, and the
+    mixed-scale bucketing of configs[4] (`forward_pairs_sharded`: two shapes interleaved, every bucket
+    sharded, one gather) - every rank ends with every pair's boxes in input order."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in results) == list(range(world))
+    ref = _StubModel()
+    g = torch.Generator().manual_seed(4)
+    pairs = []
+    for i in range(61):
+        hw2 = (8, 8) if i % 3 else (16, 16)
+        pairs.append((torch.rand(8, 8, 3, generator=g), torch.rand(*hw2, 3, generator=g)))
+    from imagematching_oetr_amd.pipeline import forward_pairs
+    x1, x2 = forward_pairs(ref, pairs, max_batch=8)
+    for rank, out in results:
+        for n_pairs in (64, 61):
+            idx = torch.arange(n_pairs, dtype=torch.float32)
+            expect = torch.stack([idx, idx + 0.25, idx + 0.5, idx + 0.75], 1)
+            g1, g2, mine = out['gather', n_pairs]
+            assert mine == (8 if n_pairs == 64 else (8 if rank < 5 else 7)), (rank, mine)
+            assert torch.equal(torch.tensor(g1), expect) and torch.equal(torch.tensor(g2), -expect), rank
+            nxt, last = out['pipe', n_pairs]
+            assert torch.equal(torch.tensor(nxt), expect) and torch.equal(torch.tensor(last), expect + 1000), rank
+            gg = torch.Generator().manual_seed(3)
+            im1, im2 = torch.rand(n_pairs, 6, 5, 3, generator=gg), torch.rand(n_pairs, 4, 7, 3, generator=gg)
+            r = _StubModel()
+            e1, e2 = r.forward_dummy(im1, im2)
+            r.hip_flush()
+            b1, b2 = out['sharded', n_pairs]
+            assert torch.equal(torch.tensor(b1), e1) and torch.equal(torch.tensor(b2), e2), rank
+        m1, m2 = out['mixed']
+        assert torch.equal(torch.tensor(m1), x1) and torch.equal(torch.tensor(m2), x2), rank
+
+
 def test_gather_is_identity_without_process_group():
     b1, b2 = torch.rand(3, 4), torch.rand(3, 4)
     g1, g2 = gather_boxes(b1, b2, 3)
