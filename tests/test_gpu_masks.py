@@ -41,7 +41,7 @@ def test_masked_hot_path_vs_reference_golden_and_oracle(path, tile, gpu):
         dead = (m.flatten(1) == 0).to(gpu)
         assert (out['logits' + s][dead] == orc.MASK_FILL).all(), 'masked logits must hold -1e9'
         assert (out['logits' + s][~dead] > -1e8).all()
-    check_stages(out, ref, 'vs oracle')
+    check_stages(out, ref, 'vs oracle', 'hotmask', 'f32_split_f16')
     # ... and against what the reference itself produced
     for s in ('1', '2'):
         step = int(g[f'memory{s}_step'])
@@ -123,7 +123,7 @@ def test_masked_seams_and_module(gpu):
         engine(gpu, 2, True, attention='full').forward(*dev, im1, im2, mask1=m1, mask2=m2)
     # the exact-fp32 build carries the masks too (the re-run route of a masked batch that overflowed f16)
     out32 = e32.forward(*dev, im1, im2, stages=True, mask1=m1, mask2=m2)
-    check_stages(out32, ref, 'exact fp32 vs oracle')
+    check_stages(out32, ref, 'exact fp32 vs oracle', 'hotmask', 'f32')
 
     # drop-in module: forward_dummy with masks = the reference's signature
     torch.manual_seed(0)
@@ -206,7 +206,7 @@ def test_fractional_and_empty_masks(gpu):
     ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True, mask1=m1, mask2=m2)
     for tile in (None, 64):
         out = engine(gpu, 3, True, tile).forward(*dev, im1, im2, stages=True, mask1=m1, mask2=m2)
-        check_stages(out, ref, f'tile {tile}')
+        check_stages(out, ref, f'weighted masks, tile {tile}', 'masks_9x11_14x6', 'f32_split_f16')
         assert torch.isfinite(out['memory1']).all() and torch.isfinite(out['hs1']).all()
         # the empty image: uniform softmax -> centre of its token grid times the stride (32)
         assert maxerr(out['cxy1'][2], torch.tensor([11 * 32 / 2.0, 9 * 32 / 2.0])) <= 1e-3
@@ -244,4 +244,4 @@ def test_masked_forward_at_the_benchmark_size(gpu, tile):
     ref = orc.hot_path(f1, f2, w, (640, 640), (640, 640), return_stages=True, mask1=m1, mask2=m2)
     out = engine(gpu, 5, True, tile).forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p1.to(gpu), (640, 640), (640, 640),
                                              stages=True, mask1=m1, mask2=m2)
-    check_stages(out, ref, f'8 pairs @640, tile {tile}')
+    check_stages(out, ref, f'8 pairs @640, tile {tile}', 'masks_8p_640', 'f32_split_f16')

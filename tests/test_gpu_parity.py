@@ -19,6 +19,8 @@ Tolerances (fp32, north_star: boxes within 1e-3 IoU):
   5e-2 px keeps IoU drift below 3e-4 for any box larger than 32 px.
 """
 import glob
+import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -30,7 +32,23 @@ from oracle import oetr_oracle as orc
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TOL = dict(memory=2e-4, hs=1e-4, logits=1e-3, cxy=5e-2, tlbr=1e-5, box=5e-2)
+# Round 5: every tolerance is <= 2x the worst error OBSERVED on MI355X for that stage
+# over the goldens, the masked goldens, the edge grids and the fuzz sample (profiles/r5_parity_margins.json,
+# written by this module).  Two-plane modes (the default f32_split_f16 at both tile shapes, the policy):
+#   memory 6.3e-5  hs 3.5e-5 (a 1 x 1 grid)  logits 2.9e-4  cxy 6.6e-3 px (4.0e-3 on the goldens)  tlbr 2.0e-6
+# i.e. cxy sits inside SURVEY 8c's 1e-2 px.  Exact fp32 (OETR_DTYPE_F32, the re-run route) is the LESS
+# accurate build: its MFMA (32x32x2) adds one product per accumulator step, K = 256 .. 512 dependent
+# fp32 additions per output against 16 .. 32 for the f16 MFMAs - memory 7.1e-5, cxy 2.1e-2 px on the
+# 1024 / 1280-px sharpened goldens (the soft-argmax amplification described above): its own, wider row.
+TOL = dict(memory=1.3e-4, hs=7e-5, logits=6e-4, cxy=1e-2, tlbr=4e-6, box=1e-2)
+TOL_F32 = dict(memory=1.5e-4, hs=7e-5, logits=9e-4, cxy=4.2e-2, tlbr=4e-6, box=4.2e-2)
+# two forms of the SAME arithmetic (tail forms, decoder on one / four workgroups): fp32 summation order only
+FORM_TOL = dict(hs=1e-5, box=1e-2)
+
+
+def tol(precision=''):
+    return TOL_F32 if precision == 'f32' else TOL
+
 HOT = sorted(glob.glob(str(Path(__file__).parent / 'golden' / 'hot_*.npz')))
 
 
@@ -40,11 +58,48 @@ def maxerr(a, b):
     return float((a - b).abs().max())
 
 
-def check_stages(out, ref, note=''):
+# Observed margins: every comparison against the oracle / the reference's goldens
+# leaves its max error here - worst case per (case, precision, against, stage) - and the module writes
+# gpurun_out/parity_margins.json when it is done (copied to profiles/r5_parity_margins.json): the
+# tolerances above are <= 2x the worst observation of a stage, and a regression inside the tolerance is
+# visible in the table.
+MARGINS = {}
+MARGIN_LOG = Path(os.environ.get('OETR_MARGIN_LOG',
+                                 Path(__file__).resolve().parents[1] / 'gpurun_out' / 'parity_margins.json'))
+
+
+def margin(case, precision, against, stage, err):
+    key = (case, precision, against, stage)
+    MARGINS[key] = max(MARGINS.get(key, 0.0), float(err))
+    return err
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _write_margins():
+    yield
+    if not MARGINS:
+        return
+    rows = [dict(case=c, precision=p, against=a, stage=s, max_err=float(f'{e:.3e}'))
+            for (c, p, a, s), e in sorted(MARGINS.items())]
+    worst = {}
+    for r in rows:
+        if 'ratio' in r['against']:
+            continue
+        st = r['stage'].rstrip('12')
+        worst[st] = max(worst.get(st, 0.0), r['max_err'])
+    try:
+        MARGIN_LOG.parent.mkdir(parents=True, exist_ok=True)
+        MARGIN_LOG.write_text(json.dumps({'tolerances': TOL, 'worst_per_stage': worst, 'rows': rows}, indent=1))
+    except OSError:
+        pass
+
+
+def check_stages(out, ref, note='', case='', precision=''):
+    t = tol(precision)
     for s in ('1', '2'):
         for key in ('memory', 'hs', 'logits', 'cxy', 'tlbr', 'box'):
-            e = maxerr(out[key + s].reshape(ref[key + s].shape), ref[key + s])
-            assert e <= TOL[key], f'{note} {key}{s}: max err {e:.3e} > {TOL[key]:.1e}'
+            e = margin(case, precision, note, key + s, maxerr(out[key + s].reshape(ref[key + s].shape), ref[key + s]))
+            assert e <= t[key], f'{note} {key}{s}: max err {e:.3e} > {t[key]:.1e}'
         b_hip, b_ref = out['box' + s].cpu(), ref['box' + s]
         area = (b_ref[:, 2] - b_ref[:, 0]) * (b_ref[:, 3] - b_ref[:, 1])
         iou = orc.bbox_iou_aligned(b_hip, b_ref)
@@ -90,23 +145,23 @@ def test_hot_path_vs_reference_golden_and_oracle(path, precision, gpu, engines):
     dev = [t.to(gpu) for t in (f1, f2, p1, p2)]
     out = eng.forward(*dev, im1, im2, stages=True)
     ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
-    check_stages(out, ref, 'vs oracle')
+    case = Path(path).stem
+    check_stages(out, ref, 'vs oracle', case, precision)
     # ... and directly against what the reference itself produced
     for s in ('1', '2'):
         step = int(g[f'memory{s}_step'])
-        assert maxerr(out['memory' + s][:, ::step], g['memory' + s]) <= TOL['memory']
-        assert maxerr(out['hs' + s], g['hs' + s]) <= TOL['hs']
-        assert maxerr(out['logits' + s], g['logits' + s]) <= TOL['logits']
-        assert maxerr(out['cxy' + s], g['cxy' + s]) <= TOL['cxy']
-        assert maxerr(out['tlbr' + s], g['tlbr' + s]) <= TOL['tlbr']
-        assert maxerr(out['box' + s], g['box' + s]) <= TOL['box']
+        rec = lambda stage, e: margin(case, precision, 'vs reference golden', stage + s, e)
+        assert rec('memory', maxerr(out['memory' + s][:, ::step], g['memory' + s])) <= tol(precision)['memory']
+        for stage in ('hs', 'logits', 'cxy', 'tlbr', 'box'):
+            assert rec(stage, maxerr(out[stage + s], g[stage + s])) <= tol(precision)[stage], (stage, s)
     # encoder prefixes: after layer 0 (self) and layer 1 (cross)
     for li in (0, 1):
         pre = eng.forward(*dev, im1, im2, stages=True, enc_layers=li + 1)
         for s in ('1', '2'):
             step = int(g[f'enc{li}_x{s}_step'])
-            e = maxerr(pre['memory' + s][:, ::step], g[f'enc{li}_x{s}'])
-            assert e <= TOL['memory'], f'enc{li} x{s}: {e:.3e}'
+            e = margin(case, precision, 'vs reference golden', f'enc{li}_x{s}',
+                       maxerr(pre['memory' + s][:, ::step], g[f'enc{li}_x{s}']))
+            assert e <= tol(precision)['memory'], f'enc{li} x{s}: {e:.3e}'
     # plain forward == staged forward, bit for bit; and repeatable
     b1, b2 = eng.forward(*dev, im1, im2)
     assert torch.equal(b1, out['box1']) and torch.equal(b2, out['box2'])
@@ -120,6 +175,8 @@ def test_full_forward_golden_boxes(gpu, engines, golden_dir):
     eng = engines(int(g['weight_seed']), True)
     t = [torch.from_numpy(g[k]).to(gpu) for k in ('feat1', 'feat2', 'pos1', 'pos2')]
     b1, b2 = eng.forward(*t, (640, 640), (640, 640))
+    margin('full_640', 'f32_split_f16', 'vs reference golden', 'box1', maxerr(b1, g['box1']))
+    margin('full_640', 'f32_split_f16', 'vs reference golden', 'box2', maxerr(b2, g['box2']))
     assert maxerr(b1, g['box1']) <= TOL['box'] and maxerr(b2, g['box2']) <= TOL['box']
     iou = orc.bbox_iou_aligned(torch.cat([b1, b2]).cpu(),
                                torch.from_numpy(np.concatenate([g['box1'], g['box2']])))
@@ -217,7 +274,7 @@ def test_edge_shapes(n, g1, g2, precision, gpu, engines):
     out = eng.forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p2.to(gpu), im1, im2,
                       stages=True)
     ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
-    check_stages(out, ref, f'{n} {g1} {g2}')
+    check_stages(out, ref, f'{n} {g1} {g2}', 'edge_grids', 'f32_split_f16')
 
 
 def test_random_shapes_fuzz(gpu, engines):
@@ -237,7 +294,7 @@ def test_random_shapes_fuzz(gpu, engines):
         out = engines(wseed, sharp, prec).forward(f1.to(gpu), f2.to(gpu), p1.to(gpu),
                                                   p2.to(gpu), im1, im2, stages=True)
         ref = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
-        check_stages(out, ref, f'fuzz {case} n={n} {g1} {g2} {prec}')
+        check_stages(out, ref, f'fuzz {case} n={n} {g1} {g2}', 'fuzz', prec)
 
 
 def test_error_paths(gpu, engines):
@@ -257,10 +314,14 @@ def test_error_paths(gpu, engines):
                     (3232, 3200), (128, 128))
 
 
+FP32_CLASS = 8.0
+
+
 def test_split_mode_is_fp32_class(gpu, engines):
     """The default GEMM mode (a = ah + al/2^11 in f16, 3 MFMAs per product, fp32
     accumulate) must be as close to the fp64 oracle as an fp32 implementation:
-    bounds = 4x the drift of torch's own fp32 CPU run on the same graph."""
+    bound = FP32_CLASS x the drift of torch's own fp32 CPU run on the same graph (or an absolute floor
+    where that drift is tiny); the observed ratios go to the margin table."""
     w = orc.make_hot_weights(3, sharpen=True)
     f1, f2 = orc.make_features(51, 2, 20, 20), orc.make_features(52, 2, 32, 32)
     p1, p2 = orc.position_table(20, 20), orc.position_table(32, 32)
@@ -275,7 +336,9 @@ def test_split_mode_is_fp32_class(gpu, engines):
         ref = s64[key]
         drift32 = (s32[key].double() - ref).abs().max().item()
         err = (out[key].cpu().double().reshape(ref.shape) - ref).abs().max().item()
-        assert err <= max(8 * drift32, floor), (key, err, drift32)
+        margin('split_vs_fp64_20x20_32x32', 'f32_split_f16', 'err / torch-fp32-drift (ratio)', key, err / max(drift32, 1e-12))
+        margin('split_vs_fp64_20x20_32x32', 'f32_split_f16', 'vs fp64 oracle', key, err)
+        assert err <= max(FP32_CLASS * drift32, floor), (key, err, drift32)
 
 
 @pytest.mark.parametrize('precision', ['f32_split_f16', 'f32_split_f16@64'])
@@ -465,16 +528,17 @@ def test_tail_forms_agree_and_match_the_goldens(path, precision, gpu):
         outs[mode] = eng.forward(*dev, im1, im2, stages=True)
         tol_scale = 1.0 if precision == 'f32_split_f16' else 30.0   # (policy: bounded drift, test_gpu_precision has the bar)
         for s in ('1', '2'):
-            assert maxerr(outs[mode]['logits' + s], g['logits' + s]) <= TOL['logits'] * tol_scale, (mode, s)
-            assert maxerr(outs[mode]['cxy' + s], g['cxy' + s]) <= TOL['cxy'] * tol_scale, (mode, s)
-            assert maxerr(outs[mode]['box' + s], g['box' + s]) <= TOL['box'] * tol_scale, (mode, s)
+            for stage in ('logits', 'cxy', 'box'):
+                e = margin(Path(path).stem, precision, f'tail form {mode} vs reference golden', stage + s,
+                           maxerr(outs[mode][stage + s], g[stage + s]))
+                assert e <= TOL[stage] * tol_scale, (mode, stage, s, e)
     for s in ('1', '2'):
         for other in (2, 3):
             assert torch.equal(outs[1]['hs' + s], outs[other]['hs' + s])            # same decoder
             # (the nine taps are summed in another order: a tenth of the golden tolerances, scaled by the logits' size)
             scale = 1.0 + float(outs[1]['logits' + s].abs().max())
             assert maxerr(outs[1]['logits' + s], outs[other]['logits' + s]) <= 1e-5 * scale, other
-            assert maxerr(outs[1]['box' + s], outs[other]['box' + s]) <= 0.2 * TOL['box'], other
+            assert maxerr(outs[1]['box' + s], outs[other]['box' + s]) <= FORM_TOL['box'], other
     with pytest.raises(Exception):
         eng.set_tail_mode(4)
     if True:
@@ -526,12 +590,14 @@ def test_decoder_split_forms_match_the_goldens(path, precision, gpu):
             outs[k] = eng.forward(*dev, im1, im2, stages=True)
         assert eng.query_flags() == 0
         for s in ('1', '2'):
-            assert maxerr(outs[k]['hs' + s], g['hs' + s]) <= TOL['hs'], (k, s)
-            assert maxerr(outs[k]['box' + s], g['box' + s]) <= TOL['box'], (k, s)
+            assert margin(Path(path).stem, precision, f'decoder split {k} vs reference golden', 'hs' + s,
+                          maxerr(outs[k]['hs' + s], g['hs' + s])) <= tol(precision)['hs'], (k, s)
+            assert margin(Path(path).stem, precision, f'decoder split {k} vs reference golden', 'box' + s,
+                          maxerr(outs[k]['box' + s], g['box' + s])) <= tol(precision)['box'], (k, s)
     for s in ('1', '2'):
         assert torch.equal(outs[0]['hs' + s], outs[4]['hs' + s])       # auto = four at these sizes
-        assert maxerr(outs[1]['hs' + s], outs[4]['hs' + s]) <= 0.1 * TOL['hs']
-        assert maxerr(outs[1]['box' + s], outs[4]['box' + s]) <= 0.2 * TOL['box']
+        assert maxerr(outs[1]['hs' + s], outs[4]['hs' + s]) <= FORM_TOL['hs']
+        assert maxerr(outs[1]['box' + s], outs[4]['box' + s]) <= FORM_TOL['box']
     with pytest.raises(Exception):
         eng.set_decoder_split(2)
 
@@ -602,7 +668,7 @@ def test_split_decoder_timeout_path_recovers(gpu):
         for b, r in zip(again, ref1):
             assert torch.equal(b, r), mode
         for b, g in zip(boxes, good):
-            assert maxerr(b, g) <= 0.2 * TOL['box']
+            assert maxerr(b, g) <= FORM_TOL['box']
     # routes that read no status word never split: precisions without a range guard, 'ignore', the seams
     model.hip_on_overflow = 'ignore'
     model._split_ok = True

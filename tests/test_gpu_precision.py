@@ -118,13 +118,19 @@ def test_reduced_precision_drift_is_recorded_and_bounded(path, precision, gpu):
     assert all(v >= floor for v in ious), f'{precision}: IoU below its floor {floor}: {entry}'
 
 
-@pytest.mark.xfail(reason=BAR_XFAIL, strict=False)
+# hot_s2's boxes are saturated at the image border in every mode (IoU 1.0 whatever the drift): it says
+# nothing about the bar and is left out; on the others the failure is STRICT - a mode that starts to
+# meet the bar shows up as an XPASS failure and gets promoted to a passing test.
+HOT_BAR = [p for p in HOT if not Path(p).stem.startswith('hot_s2')]
+
+
+@pytest.mark.xfail(reason=BAR_XFAIL, strict=True)
 @pytest.mark.parametrize('precision', REDUCED)
-@pytest.mark.parametrize('path', HOT, ids=lambda p: p.split('hot_')[-1][:-4])
+@pytest.mark.parametrize('path', HOT_BAR, ids=lambda p: p.split('hot_')[-1][:-4])
 def test_reduced_precision_meets_the_north_star_iou_bar(path, precision, gpu):
     """The north_star bar itself (IoU >= 1 - 1e-3 vs the reference's boxes) in the
-    single-pass modes.  Expected to fail on every golden whose boxes are not saturated
-    at the image border (hot_s2: XPASS) - see BAR_XFAIL for the measured margins."""
+    single-pass modes: fails on every golden whose boxes are not saturated at the image
+    border - see BAR_XFAIL for the measured margins."""
     entry, _, ious = _golden_drift(path, precision, gpu)
     assert all(v >= 1 - 1e-3 for v in ious), f'{precision}: IoU bar missed: {entry}'
 
