@@ -122,7 +122,7 @@ def parse_args(argv=None):
                          '(decoder, then the 64-row conv: fewest CU-microseconds - no P buffer, no combine - which is what '
                          'counts when other streams fill the chip; +2.4 %% at 8 pairs @640x640), 0 = the library rule '
                          '(latency: P form below 16 000 token rows)')
-    ap.add_argument('--prereduce-overlap', type=int, default=-1, choices=[-1, 0, 1, 2],
+    ap.add_argument('--prereduce-overlap', type=int, default=-1, choices=[-1, 0, 1],
                     help='oetr_set_state_prereduce for the overlapped run (-1 = the library rule; A/Bs)')
     ap.add_argument('--decoder-split', type=int, default=0, choices=[0, 1, 4],
                     help='oetr_set_decoder_split for the serial run (0 = the library rule; A/Bs)')

@@ -185,8 +185,7 @@ long long* g_tbuf = nullptr;
 
 struct Workspace {
   float *x, *qp, *pos, *kvp[2], *ksp[2], *att0, *z0, *dkv1, *dks1, *conv_out, *gn_part, *sm_part, *hs,
-      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *kvr[2], *ksr[2];
-  unsigned* red_cnt;   // arrival counters of the in-launch state reduction: [OETR_N_ENC][2N], zeroed per call
+      *logits, *cxy, *tlbr, *convp, *kbuf[2], *vt[2], *kvr, *ksr;
   uint32_t* flags;   // the workspace's status word (first 256 bytes: shape-independent position)
   size_t bytes;
 };
@@ -253,11 +252,8 @@ Workspace carve(const Geom& g, void* base, bool attn_full = false) {
   w.cxy = take((size_t)2 * g.N * 2);
   w.tlbr = take((size_t)2 * g.N * 4);
   w.convp = take((size_t)9 * rows * C);  // P_tap = W_tap . memory (forward path)
-  for (int i = 0; i < 2; ++i) {                // one reduced linear-attention state per image and
-    w.kvr[i] = take((size_t)2 * g.N * KV_FLOATS);   // layer parity (oetr_set_state_prereduce)
-    w.ksr[i] = take((size_t)2 * g.N * C);
-  }
-  w.red_cnt = reinterpret_cast<unsigned*>(take((size_t)OETR_N_ENC * 2 * g.N));
+  w.kvr = take((size_t)2 * g.N * KV_FLOATS);   // one reduced linear-attention state per image (oetr_set_state_prereduce)
+  w.ksr = take((size_t)2 * g.N * C);
   for (int i = 0; i < 2; ++i) {           // attention == full: K rows and V^T, per layer parity
     w.kbuf[i] = attn_full ? take(rows * C) : nullptr;
     w.vt[i] = attn_full ? take((size_t)g.N * C * TM * (g.nt[0] + g.nt[1])) : nullptr;
@@ -410,23 +406,16 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
   p.a = h->enc[0];
   p.kv_out = w.kvp[0]; p.ks_out = w.ksp[0];
   // oetr_set_state_prereduce: each image's per-tile partial states are summed ONCE instead of in
-  // every consuming workgroup.  1 = in a launch of its own between the encoder launches (measured
-  // on MI355X: the consumer launch gets 2.1-2.3 us shorter, the extra launch is a 4-5 us latency
-  // chain - serial steps slower, overlapped throughput unchanged).  2 = by the LAST workgroup of
-  // the image to finish, inside the launch that writes the partials (encoder.hip:
-  // reduce_states_last_arriver; the counters are zeroed here, once per call).
-  // -1 (default) = auto: the reduction launch pays once an image has many partials - measured on
-  // MI355X, 64-row tiles (profiles/r4_prereduce_auto.txt): 400 tokens per image (7 partials) +0.9 %
-  // step time with it, 1024 tokens (16) -3.9 % (k_encoder64<B,A> 246 -> 225 us), 1600 tokens (25)
-  // -4.2 % (120 -> 105 us) - so it is on from OETR_PREREDUCE_MIN_TOKENS source tokens per image.
+  // every consuming workgroup, in a launch of its own between the encoder launches (the consumer
+  // launch gets shorter, the extra launch is a 4-5 us latency chain).  -1 (default) = auto: it pays once
+  // an image has many partials - measured on MI355X, 64-row tiles (profiles/r4_prereduce_auto.txt):
+  // 400 tokens per image (7 partials) +0.9 % step time with it, 1024 tokens (16) -3.9 %
+  // (k_encoder64<B,A> 246 -> 225 us), 1600 tokens (25) -4.2 % (120 -> 105 us) - so it is on from
+  // OETR_PREREDUCE_MIN_TOKENS source tokens per image.  (Rounds 3-4 also had an in-launch form - the
+  // last workgroup of an image to finish reduced its partials behind an agent-scope release / ticket /
+  // acquire: bit-identical, and slower at every size; removed in round 5.)
   int prereduce = h->attn_full ? 0 : h->kv_prereduce;
   if (prereduce < 0) prereduce = (g.L[0] >= OETR_PREREDUCE_MIN_TOKENS || g.L[1] >= OETR_PREREDUCE_MIN_TOKENS) ? 1 : 0;
-  const size_t cnt_per_launch = (size_t)2 * g.N;
-  p.kvr_out = p.ksr_out = nullptr; p.red_cnt = nullptr;
-  if (prereduce == 2) {
-    HIP_TRY(hipMemsetAsync(w.red_cnt, 0, sizeof(unsigned) * OETR_N_ENC * cnt_per_launch, s));
-    if (enc_layers > 0) { p.kvr_out = w.kvr[0]; p.ksr_out = w.ksr[0]; p.red_cnt = w.red_cnt; }
-  }
   TRACED(h, s, K_ENC_A, launch_encoder(p, false, 0, h->mode, s));
   p.feat_nchw[0] = p.feat_nchw[1] = p.pos_nchw[0] = p.pos_nchw[1] = nullptr;
   for (int l = 0; l < enc_layers; ++l) {
@@ -434,18 +423,10 @@ oetr_status run_correlation(oetr_ctx* h, const Geom& g, const Workspace& w, cons
     p.b_cross = l & 1;
     p.kv_in = w.kvp[l & 1]; p.ks_in = w.ksp[l & 1];
     p.kv_reduced = 0;
-    p.kvr_out = p.ksr_out = nullptr; p.red_cnt = nullptr;
     if (prereduce == 1) {   // sum layer l's per-tile partial states once per image, in a launch of its own
-      TRACED(h, s, K_KV_REDUCE, launch_kv_reduce(p.g, w.kvp[l & 1], w.ksp[l & 1], w.kvr[0], w.ksr[0], s));
-      p.kv_in = w.kvr[0]; p.ks_in = w.ksr[0];
+      TRACED(h, s, K_KV_REDUCE, launch_kv_reduce(p.g, w.kvp[l & 1], w.ksp[l & 1], w.kvr, w.ksr, s));
+      p.kv_in = w.kvr; p.ks_in = w.ksr;
       p.kv_reduced = 1;
-    } else if (prereduce == 2) {   // the previous launch's last-arriving workgroups did
-      p.kv_in = w.kvr[l & 1]; p.ks_in = w.ksr[l & 1];
-      p.kv_reduced = 1;
-      if (l + 1 < OETR_N_ENC && l + 1 < enc_layers) {   // this launch runs phase A of layer l + 1
-        p.kvr_out = w.kvr[(l + 1) & 1]; p.ksr_out = w.ksr[(l + 1) & 1];
-        p.red_cnt = w.red_cnt + (size_t)(l + 1) * cnt_per_launch;
-      }
     }
     p.kbuf_in = w.kbuf[l & 1]; p.vt_in = w.vt[l & 1];
     int tail;
@@ -1408,7 +1389,7 @@ oetr_status oetr_debug_decoder_fault(oetr_handle h, int on) {
 
 oetr_status oetr_set_state_prereduce(oetr_handle h, int on) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: NULL handle");
-  if (on < -1 || on > 2) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: -1 (auto), 0 (off), 1 (own launch) or 2 (in-launch, last arriver)");
+  if (on < -1 || on > 1) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: -1 (auto), 0 (off) or 1 (a reduction launch between the encoder launches)");
   h->kv_prereduce = on;
   return OETR_OK;
 }

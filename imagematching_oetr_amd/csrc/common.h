@@ -1186,14 +1186,7 @@ struct EncLaunch {
                          // g.nt / g.tile0 / g.ntiles are in units of this tile
   int b_cross;           // phase-B layer is a cross layer
   int kv_reduced;        // kv_in / ks_in hold ONE reduced state per image ([2N][8192] / [2N][256], side 0
-                         // first) instead of per-tile partials: k_kv_reduce ran between the launches,
-                         // or the previous launch's last-arriving workgroups reduced them (below)
-  // TAIL == 0, optional (NULL = off): the workgroup that finishes LAST among an image's tiles sums
-  // the image's partial states (fixed tile order) into kvr_out / ksr_out - encoder.hip:
-  // reduce_states_last_arriver.  red_cnt: [2N] arrival counters of THIS launch, zeroed per call.
-  float* kvr_out;        // [2N][8192]
-  float* ksr_out;        // [2N][256]
-  unsigned* red_cnt;
+                         // first) instead of per-tile partials: k_kv_reduce ran between the launches
   int policy;            // precision policy id (SitePolicy<>): 0 = every site fp32-class
   int dbg;               // ablation flags (OETR_ABLATE builds only)
   long long* tbuf;       // per-phase cycle stamps (OETR_PHASE_TIMING builds only)

@@ -335,74 +335,6 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
   }   // f16-based modes
 }
 
-// ---------------------------------------------------------------------------
-// In-launch reduction of an image's partial linear-attention states by the workgroup that
-// finishes LAST among the image's tiles (oetr_set_state_prereduce(h, 2)): the next launch's
-// workgroups then read ONE 33-KB state instead of re-reading and re-summing every tile's partial
-// (7 x 33 KB per 64-token workgroup at 400 tokens, 13 x per 32-token one - two thirds of their
-// prologue's bytes).  Same summation order as the consumers' own loop and as k_kv_reduce
-// (tile 0, 1, ...): bit-identical results.
-//
-// Hand-off between workgroups inside a launch (8 XCDs with private L2s, per-CU L1s): every
-// storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope and
-// takes a ticket (a relaxed agent-scope fetch_add on a per-call zeroed counter); the workgroup
-// that draws the last ticket acquires at agent scope, meets again and reads every partial with
-// plain loads.  Placement- and order-independent: whichever workgroup is last sees all the
-// others' stores.  `flag`: one free LDS word of the kernel's own array.
-// ---------------------------------------------------------------------------
-template <int HEADS_PER_WAVE>
-__device__ __forceinline__ void reduce_states_last_arriver(const EncLaunch& p, int side, int n, int tid,
-                                                            int lane, int wave, volatile int* flag) {
-  if (p.red_cnt == nullptr) return;               // (launch-uniform)
-  const Geom& g = p.g;
-  const int img = side * g.N + n, nt = g.nt[side];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial-state stores have left
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (restates the wait behind the write-back)
-    const unsigned ticket = __hip_atomic_fetch_add(p.red_cnt + img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = ticket == (unsigned)(nt - 1);
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    *flag = last;
-  }
-  __syncthreads();
-  if (*flag == 0) return;                          // (workgroup-uniform)
-  const int slot0 = g.tile0[side] + n * nt;
-  constexpr int U = 8;   // tiles in flight per round trip
-#pragma unroll
-  for (int t = 0; t < HEADS_PER_WAVE; ++t) {
-    const int head = HEADS_PER_WAVE * wave + t;
-    const f32x4* src = reinterpret_cast<const f32x4*>(p.kv_out) + ((size_t)slot0 * NH + head) * 256 + (unsigned)lane;
-    const float* ks = p.ks_out + (size_t)slot0 * C + head * HD + (lane & 31);
-    f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
-                    f32x4{0.f, 0.f, 0.f, 0.f}};
-    float kacc = 0.f;
-    for (int t0 = 0; t0 < nt; t0 += U) {
-      f32x4 tmp[U][4];
-      float kt[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int ti = min(t0 + u, nt - 1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tmp[u][e] = src[(size_t)ti * (NH * 256) + e * 64];
-        kt[u] = ks[(size_t)ti * C];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (t0 + u < nt) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += tmp[u][e];
-          kacc += kt[u];
-        }
-    }
-    f32x4* dst = reinterpret_cast<f32x4*>(p.kvr_out) + ((size_t)img * NH + head) * 256 + (unsigned)lane;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dst[e * 64] = acc[e];
-    if (lane < 32) p.ksr_out[(size_t)img * C + head * HD + lane] = kacc;
-  }
-}
-
 // LayerNorm affines -> LDS, six rows of 256 [ln2 w, b | lnq w, b | lnkv w, b].  Every source
 // pointer is a compile-time choice per 256-thread group: with a run-time row index hipcc built
 // a pointer table in scratch and fetched through it with dependent flat loads - three
@@ -787,7 +719,6 @@ __global__ __launch_bounds__(64 * NW) void k_encoder(EncLaunch p) {
     kv_state_store<MODE, NT, MASKED>(accK, accV, ABL(p.dbg, ABL_ELU), L, nvalid, lane, wave, p.kv_out, p.ks_out, slot, rg, msk_s);
     PHASE_STAMP(p, 10);
     // (lnp_s[0] - a LayerNorm-2 weight of the layer just finished - is dead by now)
-    if constexpr (!FULL) reduce_states_last_arriver<NT>(p, side, n, tid, lane, wave, reinterpret_cast<volatile int*>(lnp_s));
   } else if (TAIL == 1) {
     // ============ decoder preparation (transformer.py:240-246) ============
     // k = (memory + pos) Wk^T + bk ; v = memory Wv^T + bv  (no norm, no pos on v)
@@ -1383,7 +1314,6 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
     kv_state_write(kv, ksum, lane, wave, p.kv_out, p.ks_out, slot);
     PHASE_STAMP(p, 12);
     // (the LayerNorm exchange buffer is dead after phase B)
-    reduce_states_last_arriver<1>(p, side, n, tid, lane, wave, reinterpret_cast<volatile int*>(lnx_s));
   } else if (TAIL == 1) {
     // ============ decoder preparation (transformer.py:240-246) ============
     float bias_k[2], bias_v[2];

@@ -119,16 +119,17 @@ __global__ __launch_bounds__(64 * NW) void k_heat_conv(HeatLaunch p) {
     bias[t] = p.w.conv_b[WC * wave + 32 * t + col];
     acc[t] = f32x16{0};
   }
-  const ATile<MODE> buf[2] = {ATile<MODE>(smem, LDA, LDAH, &rg),
-                              ATile<MODE>(smem + TILE_FLOATS, LDA, LDAH, &rg)};
+  // (the two staging tiles are addressed by arithmetic: an array of tile descriptors indexed by
+  //  tap & 1 lived in scratch, 112 bytes per lane)
+  auto tile = [&](int i) { return ATile<MODE>(smem + (i & 1) * TILE_FLOATS, LDA, LDAH, &rg); };
   // f32 mode: tap t = [256 out][256 in] of 4-byte values -> C*C/4 float4 units;
   // split mode: f16 values -> C*C/8 16-byte units per plane.
   constexpr size_t TAP_UNITS = gm_half(MODE) ? (size_t)C * C / 8 : (size_t)C * C / 4;
-  stage(0, buf[0]);
+  stage(0, tile(0));
   __syncthreads();
   for (int tap = 0; tap < 9; ++tap) {
-    if (tap + 1 < 9) stage(tap + 1, buf[(tap + 1) & 1]);
-    buf[tap & 1].template gemm<C, NT>(p.w.conv_w + tap * TAP_UNITS, p.w.conv_w_l + tap * TAP_UNITS,
+    if (tap + 1 < 9) stage(tap + 1, tile(tap + 1));
+    tile(tap).template gemm<C, NT>(p.w.conv_w + tap * TAP_UNITS, p.w.conv_w_l + tap * TAP_UNITS,
                                       NT * wave, lane, acc, 0);
     __syncthreads();
   }

@@ -519,8 +519,7 @@ class HotPathEngine:
     def set_state_prereduce(self, mode):
         """``oetr_set_state_prereduce``: partial linear-attention states summed once per image
         instead of in every consuming workgroup - -1 automatic (the library default: the reduction
-        launch from 768 source tokens per image), 0 off, 1 in a launch of their own, 2 inside
-        the producing launch by the last workgroup of the image to finish (bit-identical
+        launch from 768 source tokens per image), 0 off, 1 in a launch of their own (bit-identical
         results in every setting)."""
         _check(self.lib, self.lib.oetr_set_state_prereduce(self._h, int(mode)), 'oetr_set_state_prereduce')
 

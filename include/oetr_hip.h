@@ -228,10 +228,9 @@ oetr_status oetr_set_encoder_tile(oetr_handle h, int rows);
  * consuming workgroup.  -1 (default): automatic - the reduction launch (1) from 768 source
  * tokens per image, off below (measured on MI355X: +0.9 % step time at 400 tokens per image,
  * -3.9 % at 1024, -4.2 % at 1600).  0: off.  1: in a small launch between the encoder launches.
- * 2: inside the launch that writes the partials, by the last workgroup of an image to finish
- * (agent-scope release / ticket / acquire; arrival counters in the workspace, zeroed per call;
- * measured slower than 1 at every size).  Bit-identical results in every setting (same
- * summation order).  Mutates the handle like the other setters. */
+ * (2, the in-launch last-arriver form of ABI <= 4, measured slower at every size and was removed:
+ * OETR_ERR_BAD_ARG.)  Bit-identical results in every setting (same summation order).  Mutates the
+ * handle like the other setters. */
 oetr_status oetr_set_state_prereduce(oetr_handle h, int on);
 
 /* How the forward path orders its tail (center_estimation, reference src/model.py:145-186; decoder

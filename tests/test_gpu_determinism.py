@@ -32,10 +32,9 @@ def model():
                           ('f16', 64, 400, 'linear', 0), ('bf16', 64, 150, 'linear', 0),
                           ('f32_split_f16', 32, 300, 'linear', 0), ('f32_split_qk16', 32, 200, 'linear', 0),
                           ('f16', 32, 150, 'linear', 0), ('f32', 32, 40, 'linear', 0),
-                          # both state pre-reduction forms (oetr_set_state_prereduce): the reduction launch and the
-                          # last-arriving workgroup inside the producing launch (agent-scope release / ticket / acquire)
-                          ('f32_split_f16', 64, 200, 'linear', 1), ('f32_split_f16', 64, 200, 'linear', 2),
-                          ('f32_split_qk16', 64, 150, 'linear', 2), ('f32_split_f16', 32, 150, 'linear', 2),
+                          # the state pre-reduction launch (oetr_set_state_prereduce) forced on
+                          ('f32_split_f16', 64, 200, 'linear', 1), ('f32_split_qk16', 64, 150, 'linear', 1),
+                          ('f32_split_f16', 32, 150, 'linear', 1),
                           ('f32_split_f16', 32, 100, 'full', 0),     # (the all-pairs mode's MFMA triples are fenced too)
                           ('f32_split_f16', 64, 100, 'full', 0),     # (tile request ignored by the all-pairs mode: 32 rows)
                           ('f32', 32, 20, 'full', 0)])

@@ -25,7 +25,7 @@ for case in range(ncase):
     # size-dependent rules: automatic or pinned at random (tail form, decoder workgroups per image, state pre-reduction)
     tail = rng.choice([0, 0, 1, 2, 3]) if prec != 'f32' else rng.choice([0, 1])
     split = rng.choice([0, 0, 1, 4])
-    pre = rng.choice([-1, -1, 0, 1, 2])
+    pre = rng.choice([-1, -1, 0, 1])
     eng.set_tail_mode(tail); eng.set_decoder_split(split); eng.set_state_prereduce(pre)
     n = rng.randrange(1, 10)
     big = 61 if rng.random() < 0.15 else 41
