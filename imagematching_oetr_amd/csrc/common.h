@@ -1070,6 +1070,9 @@ struct WStream2T {
       else if constexpr (HAS_NEXT) fetch<(P + PF) % D, NSITE>(nwh, nwl, PF - NS);
       if constexpr (CI + 1 < NS) load_a<SITE>(a[(CI + 1) & 1], ah_ptr, al_ptr, CI + 1);
       __builtin_amdgcn_sched_barrier(0);
+#if defined(OETR_SOAK_AMP) && (OETR_SOAK_AMP & 1)   // soak builds only: the waves of a workgroup drift apart behind their loads
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       const BStep& b = ring[(P + CI) % D];
       const AStep& ac = a[CI & 1];
       epi(std::integral_constant<int, CI>{});

@@ -46,6 +46,13 @@
 //    not named, so no split-f16 state ships and none can be built by a flag.  Commit 23fac5d
 //    holds the study's knobs (OETR_SPLIT_STATE, OETR_HZ).
 
+#ifndef OETR_SOAK_AMP
+#define OETR_SOAK_AMP 0   // determinism-soak builds (tools/r5_soak.sh): 1 = vmcnt(0) before every GEMM step, 2 = s_setprio 3 around the state
+#endif
+#ifndef OETR_SPLIT_STATE
+#define OETR_SPLIT_STATE 1   // linear-attention state of the two-plane encoder kernels on f16 MFMAs (kv_state_64)
+#endif
+
 namespace oetr {
 
 // ---------------------------------------------------------------------------
@@ -843,7 +850,52 @@ __device__ __forceinline__ void kv_state_64(const f32x16 (&accK)[NMT], const f32
   //  clamps at the top of the kernel and 32 values live - spilled - until here)
   int nv2 = nvalid - 4 * half;
   asm volatile("" : "+v"(nv2));
-  {
+  if constexpr (MODE == GM_SPLIT && OETR_SPLIT_STATE) {
+    // Round 5: the contraction over a row tile's 32 tokens as 2 k16 steps of the fp32-class split
+    // (6 f16 MFMAs of 32 cycles instead of 16 f32 MFMAs of 64: the largest single residual of the
+    // encoder launch, profiles/r4_ablation_bounds.txt).  k-slot i of step s <-> token
+    // crow(8 s + i, half) - the same bijection for A = phi(K)^T and B = V/S.  ONE code path: the row
+    // masks on every tile, the MFMA triples fenced (mma16_split3) - the form of round 4's hazard
+    // study that never produced a differing forward (single-path builds: 0 of 157 000 under both
+    // amplifiers; the failures needed a run-time choice between two forms of this block), re-soaked
+    // in round 5 (profiles/r5_determinism_soak.txt).
+    f32x16 c1 = {0};
+#if OETR_SOAK_AMP & 2   // soak builds only: the amplifier of round 4's study (the wave outruns its SIMD sibling)
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    auto row_tile = [&](auto MT_) {
+      constexpr int mt = decltype(MT_)::value;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        f32x4 k0, k1, v0, v1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = 8 * st + i;
+          float m;
+          if constexpr (MASKED) m = msk_s[32 * mt + crow(r, half)];
+          else m = 32 * mt + crow(r, 0) < nv2 ? 1.0f : 0.0f;
+          const float kk = elu1(accK[mt][r]) * m;
+          const float vv = accV[mt][r] * (inv_len * m);
+          ksum += kk;
+          if (i < 4) { k0[i] = kk; v0[i] = vv; } else { k1[i - 4] = kk; v1[i - 4] = vv; }
+        }
+        f32x4 ah, al, bh, bl;
+        split8(k0, k1, ah, al, rg);
+        split8(v0, v1, bh, bl, rg);
+        mma16_split3(ah, al, bh, bl, kv, c1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    row_tile(std::integral_constant<int, 0>{});
+    if constexpr (NMT == 2) {
+      if (two) row_tile(std::integral_constant<int, 1>{});   // (else: no valid row in the second row tile)
+    }
+#if OETR_SOAK_AMP & 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kv[r] = fmaf(c1[r], SPLIT_INV, kv[r]);
+  } else {
     // (see kv_state_32: the operands of the next register under the current f32 MFMA)
     auto row_tile = [&](auto MT_) {
       constexpr int mt = decltype(MT_)::value;

@@ -16,7 +16,7 @@ w = model.hot_path_state()
 prec = sys.argv[1] if len(sys.argv) > 1 else 'f32_split_f16'
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 60.0
-if len(sys.argv) > 4:
+if len(sys.argv) > 4 and sys.argv[4]:
     hip_engine._lib = hip_engine.load_library(str(REPO / 'tools' / 'variants' / sys.argv[4] / 'liboetr_hip.so'))
 eng = pkg.HotPathEngine(w, device=dev, precision=prec, enc_tile=tile, attention=os.environ.get('HUNT_ATTENTION', 'linear'))
 if os.environ.get('HUNT_PREREDUCE'): eng.set_state_prereduce(int(os.environ['HUNT_PREREDUCE']))
