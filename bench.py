@@ -738,13 +738,11 @@ def main():
                 eng.set_tail_mode(args.tail_mode_overlap)
             if eng.attention == 'linear':
                 eng.set_state_prereduce(args.prereduce_overlap)
-            if args.decoder_split_overlap:
-                eng.set_decoder_split(args.decoder_split_overlap); eng._dec_split_set = args.decoder_split_overlap
+            m.hip_decoder_split = args.decoder_split_overlap or None
         else:
             if eng.attention == 'linear':
                 eng.set_state_prereduce(-1)
-            if args.decoder_split:
-                eng.set_decoder_split(args.decoder_split); eng._dec_split_set = args.decoder_split
+            m.hip_decoder_split = args.decoder_split or None
         return eng, (args.enc_tile or (64 if (overlapped and half and eng.attention == 'linear') else 0))
 
     step_spread = {}

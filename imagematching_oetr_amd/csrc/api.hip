@@ -292,7 +292,7 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.img_w[0] = p.img_w[1] = 0;
   p.flags = w.flags;
   p.force_staged_conv = h->tail_mode == 3;
-  p.convp_split = 1;
+  p.convp_units = 9;
   p.mask[0] = p.mask[1] = nullptr;
   return p;
 }
@@ -347,13 +347,26 @@ DecLaunch dec_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, bool 
   //    does get shorter, 52.5 -> 42.6 us, but the eight encoder launches around it each get 1 us
   //    LONGER - the busier launch costs the chip its clock - and the step stays where it was
   //    (358 vs 361 us) while three overlapped streams lose 2.5 %: one workgroup per image there.
+  // Round 5: the conv work is cut into items of `convp_units` (tile, tap) units - nine units per 64-token
+  // tile - sized so that the decoder's workgroups + the items fill the chip in ONE round: at 8 pairs
+  // @640x640 1 008 units on the 192 CUs the 64 decoder workgroups leave = 6 units per item (168 items),
+  // where three per tile (336 items) took two rounds; never fewer than 3 units per item (the staging of
+  // the tile's rows per item: nine items per tile measured worse than three at every size, round 4).
   const int images = 2 * g.N;
   bool fits = images <= DEC_SPLIT_MAX_IMAGES && images * DEC_SPLIT_K * 4 <= h->num_cus;
+  d.convp_units = 9;
   if (fits && beside_convp) {
-    const int tiles64 = g.N * ((g.L[0] + RT - 1) / RT + (g.L[1] + RT - 1) / RT);
-    const int items = gm_half(h->mode) ? 3 * tiles64 : g.ntiles;
-    fits = images * DEC_SPLIT_K + items <= h->num_cus;
+    if (gm_half(h->mode)) {
+      const int units = 9 * g.N * ((g.L[0] + RT - 1) / RT + (g.L[1] + RT - 1) / RT);
+      const int avail = h->num_cus - images * DEC_SPLIT_K;
+      const int upi = std::max(3, (units + avail - 1) / avail);
+      fits = upi <= 9;
+      if (fits) d.convp_units = upi;
+    } else {
+      fits = images * DEC_SPLIT_K + g.ntiles <= h->num_cus;
+    }
   }
+  if (h->dec_split == DEC_SPLIT_K && d.convp_units == 9 && beside_convp && gm_half(h->mode)) d.convp_units = 3;   // forced split: round 4's items
   d.ksplit = (h->dec_split == DEC_SPLIT_K || (h->dec_split == 0 && fits)) && images <= DEC_SPLIT_MAX_IMAGES
                  ? DEC_SPLIT_K : 1;
   d.flags = w.flags;

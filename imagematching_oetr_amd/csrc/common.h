@@ -1237,6 +1237,7 @@ struct DecLaunch {
   const float* dkv1;       // [ntiles][8192]
   const float* dks1;       // [ntiles][256]
   float* hs;               // [2N][256]
+  int convp_units;         // beside the conv-P GEMMs: (tile, tap) units per conv work item (api.hip: dec_launch)
   int ksplit;              // workgroups per image: 1, or OETR_DEC_SPLIT_K with the three fields below
   unsigned long long* xch; // [2N][5 exchanges][4][256] {tag, value} granules (workspace status block)
   unsigned* xch_epoch;     // [2N] call counters = tags (workspace status block)
@@ -1276,7 +1277,7 @@ struct HeatLaunch {
   int img_w[2];
   uint32_t* flags;         // the handle's status word (FLAG_F16_RANGE)
   int force_staged_conv;   // direct form: k_heat_conv64 (per-tap staging) even where the halo-resident form fits
-  int convp_split;         // conv-P work items per 64-token tile: 1 or 3 (conv_p.h), set by launch_decoder_convp
+  int convp_units;         // (tile, tap) units per conv-P work item, 3 .. 9 (conv_p.h), set by launch_decoder_convp from DecLaunch
   const float* mask[2];    // forward_dummy's masks per side [N][L] or NULL: logits of tokens with mask == 0
                            // are filled with -1e9 before the softmax (reference src/model.py:166-171)
 };

@@ -757,14 +757,15 @@ static hipError_t launch_decoder_convp_mode(const DecLaunch& d, const HeatLaunch
   // conv-P work items: in the 16-bit-plane modes 64-token tiles (x convp_split tap groups)
   // whatever tile the encoder runs - P is indexed by row; fewer, longer workgroups leave the
   // one-workgroup decoder chain, then this launch's critical path, more of the L2 (52.0 vs
-  // 53.5 us) - else TM-token tiles (h.g).  Three items per tile beside the split decoder (conv_p.h).
+  // 53.5 us) - else TM-token tiles (h.g).  Beside the split decoder: items of d.convp_units (tile, tap) units (conv_p.h).
   // (round 1's rule - 64-token conv tiles only when the encoder ran 64-token tiles - and its 32-row conv body
   //  for the 16-bit-plane modes are gone: that instantiation was never launched and was the one conv kernel
   //  that spilled, 20 B of scratch per lane)
   HeatLaunch h = h0;
   constexpr bool t64 = gm_half(MODE);
-  h.convp_split = t64 && d.ksplit == DEC_K ? 3 : 1;
-  const int ptiles = t64 ? h.convp_split * h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT) : h.g.ntiles;
+  h.convp_units = t64 && d.ksplit == DEC_K ? d.convp_units : 9;
+  const int units = 9 * h.g.N * ((h.g.L[0] + RT - 1) / RT + (h.g.L[1] + RT - 1) / RT);
+  const int ptiles = t64 ? (units + h.convp_units - 1) / h.convp_units : h.g.ntiles;
   const dim3 grid(2 * d.g.N * d.ksplit + ptiles);
   hipLaunchKernelGGL((k_decoder_convp<MODE, t64>), grid, dim3(512), 0, s, d, h, P);
   return hipGetLastError();

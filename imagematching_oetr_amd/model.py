@@ -331,6 +331,8 @@ class OETR(nn.Module):
         'ignore'``, the reference's inner seams - runs one workgroup per image, which waits for
         nobody.  Also off for good once a time-out was seen on this engine."""
         want = 0 if (checked and getattr(self, '_split_ok', True) and self.hip_streams <= 4) else 1
+        if want == 0 and getattr(self, 'hip_decoder_split', None):     # A/B knob (bench.py): force 1 or 4 on checked routes
+            want = int(self.hip_decoder_split)
         if getattr(eng, '_dec_split_set', None) != want:
             eng.set_decoder_split(want)
             eng._dec_split_set = want
