@@ -53,6 +53,9 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
+# (the package sets the same default at import; torch is imported first here: three side streams, the
+#  caller's stream and RCCL's need more than the HIP runtime's four hardware queues)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 PAIR_GFLOP_640 = 8.365            # BASELINE.md §4, hot path per 640x640 pair
 ENC_FLOP_PER_TOKEN = 16 * 256 * 256 + 4 * 256 * 32   # one B;A launch
@@ -862,7 +865,7 @@ def main():
                    'streams': n_streams,
                    'api': 'OETR.boxes_from_features with model.hip_streams = %d (product path; deferred range check '
                           'per batch, settled by hip_flush inside the timed region)' % n_streams,
-                   'world_size': world,
+                   'world_size': world, 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                    'rank_step_ms_fastest_slowest': ([round(v / args.steps * 1e3, 4) for v in main_res['rank_spread']]
                                                      if main_res.get('rank_spread') else None),
                    'encoder_tile_rows': tile_overlap or 'auto',

@@ -6,6 +6,16 @@ Drop-in for the inference half of TencentYoutuResearch/ImageMatching-OETR's
 centre/size regression heads run as hand-written HIP kernels for gfx950
 behind the C ABI in ``include/oetr_hip.h``.
 """
+import os as _os
+
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
+# and work of two streams that share a queue is serialised.  The throughput mode (model.hip_streams = 3)
+# uses three side streams + the caller's stream, and RCCL adds its own: five streams on four queues
+# halved the overlapped rate (measured, MI355X: 30.5 k -> 14.7 k pairs/s with a process group up; 27.5 k
+# with eight queues).  The variable is read when the runtime initialises - i.e. before the first HIP
+# call of the process, normally after this import - and an explicit setting of the caller's wins.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 from .config import Cfg, get_cfg_defaults  # noqa: F401
 from .model import OETR, build_detectors  # noqa: F401
 from .pipeline import forward_pairs, forward_pairs_raw, forward_pairs_sharded  # noqa: F401
