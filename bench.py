@@ -53,9 +53,6 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
-# (the package sets the same default at import; torch is imported first here: three side streams, the
-#  caller's stream and RCCL's need more than the HIP runtime's four hardware queues)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 PAIR_GFLOP_640 = 8.365            # BASELINE.md §4, hot path per 640x640 pair
 ENC_FLOP_PER_TOKEN = 16 * 256 * 256 + 4 * 256 * 32   # one B;A launch
@@ -132,6 +129,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the short driver-timed regions of BASELINE configs[2] / [3] / [4] (N=1, default '
                          'workload only; about 20 s)')
+    ap.add_argument('--gather-on-stream', default='auto', choices=['auto', '0', '1'],
+                    help="N > 1: BoxGatherer(on_stream=...) - 'auto' = blocking collective on the batch's side stream in "
+                         'the throughput mode, asynchronous on the process group\'s stream in the serial mode (A/B knob)')
     ap.add_argument('--workload', default='uniform', choices=['uniform', 'mixed'],
                     help="'mixed' = BASELINE configs[4] as a mixed-scale job: every rank holds the same global "
                          'pair list (640x640 vs 640x640 and 640x640 vs 1280x1280, --pairs-per-gpu of each per '
@@ -554,7 +554,7 @@ def bench_mixed(args, device, world, rank, use_pg, pkg):
             eng = pkg.HotPathEngine(weights, device=device, precision=args.precision)
         work.append(dict(key=key, n_bucket=len(idx), n_local=hi - lo, f1=f1, f2=f2, p1=p1, p2=p2,
                          hw=(h1, h1), hw2=(h2, h2), tokens=hf * hf + hf2 * hf2))
-    gatherer = BoxGatherer() if use_pg else None
+    gatherer = BoxGatherer(on_stream={'auto': None, '0': False, '1': True}[args.gather_on_stream]) if use_pg else None     # on-stream collective when submitted from a side stream
     streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
     eng.set_encoder_tile(args.enc_tile or (64 if len(streams) > 1 else 0))
 
@@ -696,7 +696,7 @@ def main():
     # attention='full' adds QK^T and PV: 4*L*S*C per encoder call and image (self / cross average)
     extra_flop = 0 if args.attention == 'linear' else 4 * 256 * n * (L1 * L1 + L2 * L2 + 2 * L1 * L2) // 2
 
-    gatherer = BoxGatherer() if use_pg else None
+    gatherer = BoxGatherer(on_stream={'auto': None, '0': False, '1': True}[args.gather_on_stream]) if use_pg else None
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
 
@@ -757,9 +757,10 @@ def main():
             # the engine); every step is a full batch of n pairs through the whole path
             b1, b2 = m.boxes_from_features(feat1, feat2, pos, pos2, hw, hw2)
             if gatherer is not None:
-                # the all-gather of this batch's boxes is enqueued right behind the batch (its
-                # stream) and runs on RCCL's stream under the next batch's kernels; it is
-                # completed at the next submit / the flush
+                # the all-gather of this batch's boxes is enqueued right behind the batch: on the batch's
+                # own side stream in the throughput mode (a blocking collective there - the other side
+                # streams carry on), on RCCL's stream under the next batch's kernels in the serial
+                # mode; it is completed at the next submit / the flush
                 with torch.cuda.stream(m.hip_batch_stream()):
                     gatherer.submit(b1, b2)
         barrier()

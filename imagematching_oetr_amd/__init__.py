@@ -8,13 +8,13 @@ behind the C ABI in ``include/oetr_hip.h``.
 """
 import os as _os
 
-# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
-# and work of two streams that share a queue is serialised.  The throughput mode (model.hip_streams = 3)
-# uses three side streams + the caller's stream, and RCCL adds its own: five streams on four queues
-# halved the overlapped rate (measured, MI355X: 30.5 k -> 14.7 k pairs/s with a process group up; 27.5 k
-# with eight queues).  The variable is read when the runtime initialises - i.e. before the first HIP
-# call of the process, normally after this import - and an explicit setting of the caller's wins.
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# Streams and hardware queues: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES
+# hardware queues (default 4), and work of two streams that share a queue is serialised.  The throughput
+# mode (model.hip_streams = 3) uses three side streams + the caller's stream = four; a fifth stream (an
+# asynchronous collective on the process group's stream) halved the overlapped rate (30.5 k -> 14.7 k
+# pairs/s), which is why parallel.BoxGatherer issues a BLOCKING collective on the batch's own side stream
+# in that mode.  More queues are not a fix: with 8 the stream -> queue assignment depends on the order in
+# which torch / RCCL / this package create their streams (28-32 k by order; profiles/r5_pg_streams.txt).
 
 from .config import Cfg, get_cfg_defaults  # noqa: F401
 from .model import OETR, build_detectors  # noqa: F401

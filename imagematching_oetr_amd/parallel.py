@@ -82,9 +82,20 @@ class BoxGatherer:
     ``model.hip_flush()`` before ``submit`` (or pass ``settle=model.hip_flush``), otherwise
     a batch that is corrected in place afterwards leaves its stale boxes on the other ranks."""
 
-    def __init__(self, group=None, settle=None):
+    def __init__(self, group=None, settle=None, on_stream=None):
+        """``on_stream``: False = the collective is asynchronous (the process group's own stream) and
+        completed at the next ``submit`` - right for ONE stream of batches (latency mode), where it runs
+        under the next batch's kernels.  True = a blocking collective, ordered behind the batch on the
+        stream ``submit`` is called from - right for the throughput mode (``model.hip_streams = k``,
+        submit under ``torch.cuda.stream(model.hip_batch_stream())``): that side stream's next batch is k
+        batches away, the other side streams carry on, and no fifth stream joins the four that the HIP
+        runtime's default of four hardware queues carries without sharing (measured, MI355X, world 1:
+        32.5 k pairs/s without a gather, 32.3 k with the on-stream one, 14.9 k with the asynchronous one -
+        two streams on one queue serialise; `profiles/r5_pg_streams.txt`).  None (default) = True when
+        ``submit`` is called from a stream other than the device's default stream."""
         self.settle = settle
         self.group = group
+        self.on_stream = on_stream
         self._pending = None
 
     def _finish(self):
@@ -92,11 +103,27 @@ class BoxGatherer:
             return None
         work, everyone, n_pairs, keep = self._pending
         self._pending = None
-        work.wait()
+        if isinstance(work, torch.cuda.Event):                 # on-stream collective: order the consumer behind it
+            torch.cuda.current_stream(everyone.device).wait_event(work)
+        elif work is not None:
+            work.wait()
         if keep is not None:                                   # unequal shards: drop the padding
             everyone = everyone.index_select(0, keep.to(everyone.device))
             return everyone[:, 0].contiguous(), everyone[:, 1].contiguous()
         return (everyone[:, 0].reshape(n_pairs, 4), everyone[:, 1].reshape(n_pairs, 4))
+
+    def _collective(self, out, mine):
+        on_stream = self.on_stream
+        if on_stream is None:
+            on_stream = out.is_cuda and torch.cuda.current_stream(out.device) != torch.cuda.default_stream(out.device)
+        if not on_stream:
+            return dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True)
+        dist.all_gather_into_tensor(out, mine, group=self.group, async_op=False)
+        if not out.is_cuda:
+            return None
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(out.device))
+        return done
 
     def submit(self, box1, box2, n_pairs=None):
         if self.settle is not None:
@@ -109,7 +136,7 @@ class BoxGatherer:
             mine = torch.stack((box1, box2))                          # [2, n_local, 4]
             flat = torch.empty((world * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype,
                                device=mine.device)             # concatenation along dim 0
-            work = dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)
+            work = self._collective(flat, mine)
             self._pending = (work, flat.view((world, 2) + tuple(mine.shape[1:])),
                              world * box1.shape[0], None)
             return done
@@ -122,7 +149,7 @@ class BoxGatherer:
         mine[:hi - lo, 0] = box1
         mine[:hi - lo, 1] = box2
         everyone = torch.empty(world * cap, 2, 4, dtype=box1.dtype, device=box1.device)
-        work = dist.all_gather_into_tensor(everyone, mine, group=self.group, async_op=True)
+        work = self._collective(everyone, mine)
         sizes = [shard_bounds(n_pairs, r, world) for r in range(world)]
         keep = torch.cat([torch.arange(r * cap, r * cap + (b - a)) for r, (a, b) in enumerate(sizes)])
         self._pending = (work, everyone, n_pairs, keep)

@@ -75,12 +75,12 @@ def test_gather_boxes_world2_gloo(n_pairs):
         assert torch.equal(torch.tensor(g2), -expect1), rank
 
 
-def _pipe_worker(rank, world, port, q):
+def _pipe_worker(rank, world, port, q, on_stream=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from imagematching_oetr_amd.parallel import BoxGatherer
-        g = BoxGatherer()
+        g = BoxGatherer(on_stream=on_stream)
         outs = []
         for k in range(3):                       # three batches of 2 pairs per rank
             b1 = torch.full((2, 4), float(10 * k + rank))
@@ -95,11 +95,14 @@ def _pipe_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_pipelined_box_gatherer_world2_gloo():
+@pytest.mark.parametrize('on_stream', [None, True])
+def test_pipelined_box_gatherer_world2_gloo(on_stream):
+    """on_stream=True: the blocking collective of the throughput mode (ordered on the submitting stream);
+    same hand-out order as the asynchronous one."""
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q, on_stream)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in procs]

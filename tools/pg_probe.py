@@ -8,12 +8,27 @@ from imagematching_oetr_amd.parallel import BoxGatherer
 torch.set_grad_enabled(False)
 dev = torch.device('cuda:0'); torch.cuda.set_device(0)
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', str(bench.free_port()))
-dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
 model, weights, f1, f2, p1, p2, hf, hf2 = bench.synthetic_inputs(8, 640, 640, dev)
 model = model.to(dev); model.hip_freeze_weights = True
 hw = (640, 640)
 model.hip_streams = 3
 gs = torch.cuda.Stream(device=dev)
+
+
+def plain(steps=100):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(steps):
+        model.boxes_from_features(f1, f2, p1, p2, hw, hw)
+    model.hip_flush(); torch.cuda.synchronize()
+    return 8 * steps / (time.perf_counter() - t0)
+
+
+plain(30)
+print('before init_process_group:', [round(plain()) for _ in range(3)], flush=True)
+dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
+print('after init_process_group :', [round(plain()) for _ in range(3)], flush=True)
+t = torch.ones(4, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
+print('after first collective   :', [round(plain()) for _ in range(3)], flush=True)
 
 
 BAR = [False]
