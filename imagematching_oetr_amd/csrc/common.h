@@ -41,6 +41,11 @@ constexpr int MAX_TOKENS = 10000;  // NECK.MAX_SHAPE 100x100 (reference default.
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 16 && (p).tbuf)                          \
       (p).tbuf[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (idx)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+#elif defined(OETR_PHASE_TIMING) && OETR_PHASE_TIMING == 3   // REAL time (s_memrealtime, 100 MHz): launch boundaries, clock (tools/launch_boundary.py)
+#define PHASE_STAMP(p, idx)                                                              \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && (p).tbuf) (p).tbuf[blockIdx.x * 16 + (idx)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #elif defined(OETR_PHASE_TIMING)
 #define PHASE_STAMP(p, idx)                                                              \
   do {                                                                                   \
