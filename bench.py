@@ -94,6 +94,7 @@ def parse_args(argv=None):
                     help='side of image2 (default: same as --size); BASELINE configs[4] = 1280')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true')
+    ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi power / clock samples (N=1; about 6 s)')
     ap.add_argument('--no-exact-f32', action='store_true',
                     help='skip the exact-fp32 comparison leg (N=1, default precision only)')
     ap.add_argument('--precision', default='f32_split_f16', choices=sorted(MODE_ID),
@@ -218,6 +219,52 @@ def cpu_baseline(weights, feat1, feat2, size, size2, budget_s=12.0):
                        + f'(hot path only, features precomputed) in {dt:.1f} s; '
                        f'oracle/oetr_oracle.py on torch CPU, {best_t} intra-op '
                        f'threads (best of 4..64 on a {ncpu}-CPU host)'), boxes
+
+
+def power_sample(run_steps, seconds=2.5):
+    """Socket power, power cap and shader clock while `run_steps(k)` keeps the hot path running (rocm-smi sampled
+    from a thread beside it, OUTSIDE every timed region).  The hot path runs the chip at its power cap - the clock
+    it holds is what the cap allows - so the line records both.  None if rocm-smi is not there."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    if shutil.which('rocm-smi') is None:
+        return None
+    samples, stop = [], []
+
+    def smi(*flags):
+        return subprocess.run(['rocm-smi', '-d', '0', *flags], capture_output=True, text=True, timeout=15).stdout
+
+    def sampler():
+        while not stop:
+            try:
+                out = smi('--showpower', '--showclocks')
+                w = re.search(r'Socket Graphics Package Power \(W\):\s*([0-9.]+)', out)
+                c = re.search(r'sclk clock level:[^(]*\((\d+)Mhz\)', out)
+                if w and c:
+                    samples.append((float(w.group(1)), int(c.group(1))))
+            except Exception:
+                return
+    try:
+        cap = re.search(r'Max Graphics Package Power \(W\):\s*([0-9.]+)', smi('--showmaxpower'))
+        th = threading.Thread(target=sampler, daemon=True)
+        t0 = time.perf_counter()
+        run_steps(20)
+        th.start()
+        while time.perf_counter() - t0 < seconds:
+            run_steps(20)
+        stop.append(1)
+        th.join(timeout=20)
+    except Exception:
+        return None
+    if len(samples) < 2:
+        return None
+    samples = samples[1:]                      # (the first sample straddles the ramp)
+    watts = sorted(w for w, _ in samples)
+    clocks = sorted(c for _, c in samples)
+    return {'socket_w': watts[len(watts) // 2], 'cap_w': float(cap.group(1)) if cap else None,
+            'sclk_mhz': clocks[len(clocks) // 2], 'samples': len(samples), 'source': 'rocm-smi beside a %.1f-s run' % seconds}
 
 
 def pmc_traffic(kernel_substr):
@@ -817,6 +864,22 @@ def main():
 
     main_res = measure(args.precision, with_serial_trace=True)
     eng = main_res['engine']
+    power = None
+    if world == 1 and not use_pg and not args.no_power:
+        # what the chip draws and clocks while each mode runs (not timed; rank 0 at N = 1 only)
+        m = main_res['model']
+
+        def keep_running(ns, overlapped):
+            def go(k):
+                for _ in range(k):
+                    m.boxes_from_features(feat1, feat2, pos, pos2, hw, hw2)
+                m.hip_flush()
+                torch.cuda.synchronize()
+            return go
+        configure(m, n_streams, n_streams > 1)
+        power = {'overlapped': power_sample(keep_running(n_streams, True))}
+        configure(m, 1, False)
+        power['serial'] = power_sample(keep_running(1, False))
     exact_res = None
     if args.precision == 'f32_split_f16' and not args.no_exact_f32 and args.attention == 'linear':
         exact_res = measure('f32', with_serial_trace=False)
@@ -879,6 +942,10 @@ def main():
         'hot_path_tflops': round(value * pair_gflop / 1e3, 2),
         'hot_path_frac_of_mfma_peak': round(value * pair_gflop / 1e3 / (pipe_peak / cost), 4),
     }
+    if power and (power.get('overlapped') or power.get('serial')):
+        # the roof that binds: the hot path runs the socket at its power cap in both modes, and the shader clock is
+        # what the cap leaves (MFMA peaks in `roofline` are quoted at the nominal 2.4 GHz)
+        out['power'] = power
     s_med, s_min, s_max = main_res['serial']
     # the same K steps strictly one after the other on one stream (batch latency;
     # encoder tile = library default)
@@ -892,6 +959,11 @@ def main():
                             grids=(n, hf * hf, hf2 * hf2), attention=args.attention)
         if rb:
             out['roofline'] = rb
+            if out.get('power', {}).get('overlapped'):   # (kept keys of the driver's record: roofline, config)
+                pw = out['power']['overlapped']
+                rb['socket_w_cap_w_sclk_mhz'] = [pw['socket_w'], pw['cap_w'], pw['sclk_mhz']]
+                rb['power_note'] = ('the socket draws within a few percent of its power cap while this mode runs (sustained: '
+                                    'profiles/r5_power.txt); peak is quoted at the nominal 2400 MHz, the cap leaves sclk_mhz')
             out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
                                  for k, v in kern.items()}
             out['kernels_us_sum'] = round(sum(v[1] for v in kern.values()) / args.steps * 1e3, 1)
