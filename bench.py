@@ -626,7 +626,7 @@ def bench_mixed(args, device, world, rank, use_pg, pkg):
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0       # this rank's own time (before the closing barrier)
         barrier()
-        dt = time.perf_counter() - t0
+        dt = mine                             # (MAX over ranks below: see run_mode)
         if use_pg:
             t = torch.tensor([dt, mine], device=device, dtype=torch.float64)
             every = [torch.zeros_like(t) for _ in range(world)]
@@ -817,8 +817,12 @@ def main():
         m.hip_flush()                   # every batch's range check settled, in submission order
         if gatherer is not None:
             gatherer.flush()            # last batch's gather is inside the timed region
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0   # this rank's K steps (and their gathers) are complete
+        # closing barrier of the bracket; the region's time is the MAX over ranks of their completion times from
+        # the common start - what the barrier would read, less the barrier collective's own host latency (0.2-0.45 ms
+        # under RCCL: 4-9 % of a 20-step region of 5 ms; `profiles/r5_pg_streams.txt`)
         barrier()
-        dt = time.perf_counter() - t0
         if use_pg:
             t = torch.tensor([dt, -dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1034,7 +1038,7 @@ def main():
     if use_pg:
         out['process_group'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
                                 'forced_at_world_1': bool(force_pg and world == 1),
-                                'collective': 'all_gather_into_tensor of [n_local,2,4] boxes per step (BoxGatherer, async)'}
+                                'collective': 'all_gather_into_tensor of [n_local,2,4] boxes per step (BoxGatherer: blocking on the batch\'s side stream in the throughput mode, asynchronous on the group\'s stream in the serial mode)'}
     if use_pg:
         dist.destroy_process_group()
     # RCCL prints a version banner through C stdio: flush it BEFORE the one JSON line, which is
