@@ -655,8 +655,8 @@ class HotPathEngine:
         ws = self.workspace(n, hf1, wf1, hf2, wf2)
         self._pos_loaded.pop(torch.cuda.current_stream(self.device).cuda_stream, None)
         dev = self.device
-        box1 = torch.empty(n, 4, device=dev)
-        box2 = torch.empty(n, 4, device=dev)
+        both = torch.empty(2, n, 4, device=dev)   # one [2,n,4] block: what parallel.BoxGatherer sends, without a copy
+        box1, box2 = both[0], both[1]
         args = [self._h, feat1.data_ptr(), feat2.data_ptr(), pos1.data_ptr(),
                 pos2.data_ptr(), n, hf1, wf1, hf2, wf2, int(img_hw1[0]),
                 int(img_hw1[1]), int(img_hw2[0]), int(img_hw2[1]),
@@ -742,8 +742,8 @@ class HotPathEngine:
         (``token_buffers``): -> (box1, box2) [n,4]."""
         ws = self.workspace(n, hf1, wf1, hf2, wf2)
         dev = self.device
-        box1 = torch.empty(n, 4, device=dev)
-        box2 = torch.empty(n, 4, device=dev)
+        both = torch.empty(2, n, 4, device=dev)   # one [2,n,4] block: what parallel.BoxGatherer sends, without a copy
+        box1, box2 = both[0], both[1]
         with torch.cuda.device(dev):
             _check(self.lib, self.lib.oetr_forward_tokens(
                 self._h, n, hf1, wf1, hf2, wf2, int(img_hw1[0]), int(img_hw1[1]),

@@ -65,6 +65,18 @@ def gather_boxes(box1, box2, n_pairs, group=None):
     return full[:, 0].contiguous(), full[:, 1].contiguous()
 
 
+def _adjacent(box1, box2):
+    """``[2, n, 4]`` of the two box tensors: a VIEW when they are the two halves of one block (what the engine
+    returns), else a stacked copy."""
+    n = box1.shape[0]
+    if (box1.is_contiguous() and box2.is_contiguous() and box1.shape == box2.shape and box1.dtype == box2.dtype
+            and box1.device == box2.device and n > 0
+            and box1.untyped_storage().data_ptr() == box2.untyped_storage().data_ptr()
+            and box2.storage_offset() == box1.storage_offset() + box1.numel()):
+        return torch.as_strided(box1, (2, n, 4), (n * 4, 4, 1))
+    return torch.stack((box1, box2))
+
+
 class BoxGatherer:
     """Pipelined box all-gather for a stream of batches: the collective of
     batch k is issued asynchronously (RCCL's own stream) and completed when
@@ -133,7 +145,7 @@ class BoxGatherer:
         if n_pairs is None or n_pairs % world == 0:
             if n_pairs is not None and box1.shape[0] * world != n_pairs:
                 raise ValueError(f'this rank holds {box1.shape[0]} pairs, expected {n_pairs // world}')
-            mine = torch.stack((box1, box2))                          # [2, n_local, 4]
+            mine = _adjacent(box1, box2)                              # [2, n_local, 4]
             flat = torch.empty((world * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype,
                                device=mine.device)             # concatenation along dim 0
             work = self._collective(flat, mine)

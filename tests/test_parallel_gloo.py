@@ -329,3 +329,16 @@ def test_gather_is_identity_without_process_group():
     b1, b2 = torch.rand(3, 4), torch.rand(3, 4)
     g1, g2 = gather_boxes(b1, b2, 3)
     assert g1 is b1 and g2 is b2
+
+
+def test_adjacent_box_block_is_a_view():
+    """The engine returns box1 / box2 as the halves of one [2,n,4] block: BoxGatherer sends that block as it is
+    (no stack kernel on the batch's stream); unrelated tensors are stacked."""
+    from imagematching_oetr_amd.parallel import _adjacent
+    both = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)
+    v = _adjacent(both[0], both[1])
+    assert v.data_ptr() == both.data_ptr() and torch.equal(v, both)
+    x, y = torch.rand(3, 4), torch.rand(3, 4)
+    s = _adjacent(x, y)
+    assert s.data_ptr() not in (x.data_ptr(), y.data_ptr()) and torch.equal(s, torch.stack((x, y)))
+    assert torch.equal(_adjacent(both[1], both[0]), torch.stack((both[1], both[0])))     # wrong order: copied
