@@ -63,6 +63,9 @@ MODE_ID = {'f32': 0, 'f32_split_f16': 1, 'f16': 2, 'bf16': 3, 'f32_split_qk16': 
 POLICY_ID = {'f32_split_qk16': 1}
 
 # MFMA products executed per algorithmic product, and the pipe they run on
+# What MI355X SUSTAINS on back-to-back dense f16 MFMAs: 1642 TFLOP/s at the 1.69 GHz its 1400-W socket cap leaves
+# (tools/energy/energy_probe.hip, profiles/r5_energy_prices.txt) - the roof a power-bound kernel can actually reach.
+F16_MFMA_SUSTAINED_TFLOPS = 1642.0
 MFMA_COST = {'f32': (1, F32_MFMA_PEAK_TFLOPS, 'f32 MFMA (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s'),
              'f32_split_f16': (3, F16_MFMA_PEAK_TFLOPS,
                                'dense f16 MFMA 2500 TFLOP/s / 3 MFMA products per fp32-class product'),
@@ -321,6 +324,9 @@ def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_work
         'tile_rows': tile, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1),
         'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'peak_basis': basis,
         'executed_mfma_tflops': round(ach * cost, 2),
+        # (second yardstick, f16-pipe modes: the dense-MFMA rate the chip sustains at its power cap - measured, not nominal)
+        **({'sustained_peak': round(F16_MFMA_SUSTAINED_TFLOPS / cost, 1),
+            'frac_of_sustained_peak': round(ach / (F16_MFMA_SUSTAINED_TFLOPS / cost), 4)} if pipe_peak == F16_MFMA_PEAK_TFLOPS else {}),
         'avg_launch_us': round(avg_ms * 1e3, 2), 'launches': launches, 'flop_per_launch': flop,
         'share_of_step': round(total_ms / (traced_s * 1e3), 4),
         'traced_ms_per_step': round(traced_s / steps * 1e3, 4)}
