@@ -632,7 +632,7 @@ def bench_mixed(args, device, world, rank, use_pg, pkg):
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0       # this rank's own time (before the closing barrier)
         barrier()
-        dt = mine                             # (MAX over ranks below: see run_mode)
+        dt = time.perf_counter() - t0
         if use_pg:
             t = torch.tensor([dt, mine], device=device, dtype=torch.float64)
             every = [torch.zeros_like(t) for _ in range(world)]
@@ -823,12 +823,9 @@ def main():
         m.hip_flush()                   # every batch's range check settled, in submission order
         if gatherer is not None:
             gatherer.flush()            # last batch's gather is inside the timed region
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0   # this rank's K steps (and their gathers) are complete
-        # closing barrier of the bracket; the region's time is the MAX over ranks of their completion times from
-        # the common start - what the barrier would read, less the barrier collective's own host latency (0.2-0.45 ms
-        # under RCCL: 4-9 % of a 20-step region of 5 ms; `profiles/r5_pg_streams.txt`)
-        barrier()
+        barrier()                       # closing barrier + synchronise of the bracket: inside the timed region
+        dt = time.perf_counter() - t0   # (under RCCL the barrier collective's own host latency is 0.2-0.45 ms: 4-9 % of a
+                                        #  20-step region of 5 ms, nothing at --steps 200; profiles/r5_pg_streams.txt)
         if use_pg:
             t = torch.tensor([dt, -dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
