@@ -291,6 +291,7 @@ HeatLaunch heat_launch(const oetr_ctx* h, const Geom& g, const Workspace& w, con
   p.box[0] = p.box[1] = nullptr;
   p.img_w[0] = p.img_w[1] = 0;
   p.flags = w.flags;
+  p.publish = nullptr;
   p.force_staged_conv = h->tail_mode == 3;
   p.convp_units = 9;
   p.mask[0] = p.mask[1] = nullptr;
@@ -742,7 +743,7 @@ oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
                          int img_w2, void* workspace, size_t workspace_bytes,
                          float* box1, float* box2, const oetr_stage_outputs* st,
                          void* stream, bool resident, const float* mask1 = nullptr,
-                         const float* mask2 = nullptr) {
+                         const float* mask2 = nullptr, uint32_t* publish = nullptr) {
   if (!h || (!resident && (!feat1 || !feat2 || !pos1 || !pos2)))
     return fail(OETR_ERR_BAD_ARG, "oetr_forward: NULL handle/input");
   if (oetr_status mrc = check_masks(h, mask1, mask2, true)) return mrc;
@@ -786,6 +787,7 @@ oetr_status forward_impl(oetr_handle h, const float* feat1, const float* feat2,
   hp.mask[0] = mask1; hp.mask[1] = mask2;
   hp.box[0] = box1; hp.box[1] = box2;
   hp.img_w[0] = img_w1; hp.img_w[1] = img_w2;
+  hp.publish = publish;
   // Small batches: decoder || P_tap = W_tap.memory in one launch (the decoder chain, 50 us on 2N CUs, hides
   // behind the conv GEMMs), then the att-weighted combine.  Large batches (two-plane mode): the P buffer's
   // traffic (9 x rows x 1 KB written and read) costs more than the chain - decoder first, then the conv in
@@ -833,6 +835,41 @@ oetr_status oetr_forward_masked(oetr_handle h, const float* feat1, const float* 
   return forward_impl(h, feat1, feat2, pos1, pos2, n_pairs, hf1, wf1, hf2, wf2, img_h1, img_w1,
                       img_h2, img_w2, workspace, workspace_bytes, box1, box2, st, stream, false,
                       mask1, mask2);
+}
+
+oetr_status oetr_flagslot_device_pointer(void* host_slot, uint32_t** device_slot) {
+  if (!host_slot || !device_slot) return fail(OETR_ERR_BAD_ARG, "oetr_flagslot_device_pointer: NULL argument");
+  void* d = nullptr;
+  const hipError_t e = hipHostGetDevicePointer(&d, host_slot, 0);
+  if (e != hipSuccess || !d) {
+    (void)hipGetLastError();
+    return fail(OETR_ERR_BAD_ARG, "oetr_flagslot_device_pointer: not mapped host memory (hipHostMalloc / "
+                                  "hipHostRegister with the mapped attribute)");
+  }
+  *device_slot = static_cast<uint32_t*>(d);
+  return OETR_OK;
+}
+
+oetr_status oetr_forward_flagslot(oetr_handle h, const float* feat1, const float* feat2,
+                                  const float* pos1, const float* pos2, const float* mask1,
+                                  const float* mask2, int n_pairs, int hf1, int wf1, int hf2, int wf2,
+                                  int img_h1, int img_w1, int img_h2, int img_w2, void* workspace,
+                                  size_t workspace_bytes, float* box1, float* box2,
+                                  uint32_t* flag_slot, void* stream) {
+  if (!flag_slot) return fail(OETR_ERR_BAD_ARG, "oetr_forward_flagslot: NULL flag_slot");
+  return forward_impl(h, feat1, feat2, pos1, pos2, n_pairs, hf1, wf1, hf2, wf2, img_h1, img_w1,
+                      img_h2, img_w2, workspace, workspace_bytes, box1, box2, nullptr, stream, false,
+                      mask1, mask2, flag_slot);
+}
+
+oetr_status oetr_forward_tokens_flagslot(oetr_handle h, int n_pairs, int hf1, int wf1, int hf2, int wf2,
+                                         int img_h1, int img_w1, int img_h2, int img_w2, void* workspace,
+                                         size_t workspace_bytes, float* box1, float* box2,
+                                         uint32_t* flag_slot, void* stream) {
+  if (!flag_slot) return fail(OETR_ERR_BAD_ARG, "oetr_forward_tokens_flagslot: NULL flag_slot");
+  return forward_impl(h, nullptr, nullptr, nullptr, nullptr, n_pairs, hf1, wf1, hf2, wf2, img_h1,
+                      img_w1, img_h2, img_w2, workspace, workspace_bytes, box1, box2, nullptr,
+                      stream, true, nullptr, nullptr, flag_slot);
 }
 
 oetr_status oetr_token_buffers(oetr_handle h, int n_pairs, int hf1, int wf1, int hf2, int wf2,
@@ -1199,7 +1236,8 @@ size_t oetr_neck_workspace_bytes(oetr_neck_handle h, int n_images, int hb, int w
 namespace {
 oetr_status neck_forward_impl(oetr_neck_handle h, const float* backbone_feat, int n_images,
                               int hb, int wb, void* workspace, size_t workspace_bytes,
-                              float* feat_out, void* stream, bool token_major) {
+                              float* feat_out, void* stream, bool token_major,
+                              uint32_t* status_word = nullptr) {
   if (!h || !backbone_feat || !feat_out)
     return fail(OETR_ERR_BAD_ARG, "oetr_neck_forward: NULL argument");
   NeckGeom g;
@@ -1220,7 +1258,7 @@ oetr_status neck_forward_impl(oetr_neck_handle h, const float* backbone_feat, in
   for (int kh = 0; kh < 2; ++kh) { pp.wh[kh] = h->proj_wh[kh]; pp.wl[kh] = h->proj_wl[kh]; }
   pp.bias = h->proj_b; pp.ln_w = h->ln_w; pp.ln_b = h->ln_b;
   pp.xh = w.xh; pp.xl = w.xl;
-  pp.flags = w.flags;
+  pp.flags = status_word ? status_word : w.flags;
   TRACED(h, s, K_NECK_PROJ, launch_neck_proj(pp, s));
 
   NeckConvLaunch cp;
@@ -1258,7 +1296,7 @@ oetr_status neck_forward_impl(oetr_neck_handle h, const float* backbone_feat, in
   op.wh = h->out_wh; op.wl = h->out_wl; op.bias2 = h->out_b;
   op.feat = token_major ? nullptr : feat_out;
   op.tokens = token_major ? feat_out : nullptr;
-  op.flags = w.flags;
+  op.flags = status_word ? status_word : w.flags;
   TRACED(h, s, K_NECK_OUT, launch_neck_out(op, s));
   return OETR_OK;
 }
@@ -1276,6 +1314,14 @@ oetr_status oetr_neck_forward_tokens(oetr_neck_handle h, const float* backbone_f
                                      float* tokens_out, void* stream) {
   return neck_forward_impl(h, backbone_feat, n_images, hb, wb, workspace, workspace_bytes,
                            tokens_out, stream, true);
+}
+
+oetr_status oetr_neck_forward_tokens_status(oetr_neck_handle h, const float* backbone_feat, int n_images,
+                                            int hb, int wb, void* workspace, size_t workspace_bytes,
+                                            float* tokens_out, uint32_t* status_word, void* stream) {
+  if (!status_word) return fail(OETR_ERR_BAD_ARG, "oetr_neck_forward_tokens_status: NULL status_word");
+  return neck_forward_impl(h, backbone_feat, n_images, hb, wb, workspace, workspace_bytes,
+                           tokens_out, stream, true, status_word);
 }
 
 namespace {

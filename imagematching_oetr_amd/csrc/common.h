@@ -426,6 +426,7 @@ __device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
 // oetr_query_flags() / oetr_read_flags_async().  Weights are checked at create.
 constexpr uint32_t FLAG_F16_RANGE = 1u;   // == OETR_FLAG_F16_RANGE
 constexpr uint32_t FLAG_EXCHANGE = 2u;    // == OETR_FLAG_EXCHANGE (decoder.hip: exchange_sum)
+constexpr uint32_t FLAG_PUBLISHED = 0x80000000u;   // == OETR_FLAG_PUBLISHED: set in every word stored into a flag slot
 // Status block of a workspace (include/oetr_hip.h: OETR_WORKSPACE_STATUS_BYTES, zeroed by
 // oetr_workspace_init): word 0 = flags; words 16..31 = per-image call counters of the split
 // decoder; from byte 256 its exchange granules [16 images][5][4][256] x 8 bytes.
@@ -1281,6 +1282,7 @@ struct HeatLaunch {
   float* box[2];           // [N][4] per side, or NULL
   int img_w[2];
   uint32_t* flags;         // the handle's status word (FLAG_F16_RANGE)
+  uint32_t* publish;       // ABI 6 (oetr_forward*_flagslot): mapped host word k_heat_final moves the status word into, or NULL
   int force_staged_conv;   // direct form: k_heat_conv64 (per-tap staging) even where the halo-resident form fits
   int convp_units;         // (tile, tap) units per conv-P work item, 3 .. 9 (conv_p.h), set by launch_decoder_convp from DecLaunch
   const float* mask[2];    // forward_dummy's masks per side [N][L] or NULL: logits of tokens with mask == 0

@@ -831,6 +831,14 @@ __global__ __launch_bounds__(64) void k_heat_final(HeatLaunch p) {
   const int side = img >= g.N, n = side ? img - g.N : img;
   const int nts = g.nt[side];
   const float* part = p.sm_part + (size_t)(g.tile0[side] + n * nts) * 4;
+  // Deferred check without runtime dispatches (include/oetr_hip.h, ABI 6): every kernel of this forward
+  // that can set a status bit has completed (same stream, this kernel sets none), so one lane moves the
+  // word into the caller's mapped host slot - system-scope store, visible to the host once an event
+  // behind this launch has completed - and leaves 0 behind for the next call on the workspace.
+  if (p.publish && img == 0 && lane == 0) {
+    const uint32_t word = __hip_atomic_exchange(p.flags, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.publish, word | FLAG_PUBLISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   float tl = 0.f;
   if (p.box[side] && lane < 4) tl = p.tlbr[side][4 * n + lane];
   float m = -INFINITY, se = 0.f, sx = 0.f, sy = 0.f;

@@ -6,6 +6,7 @@ there is no fallback implementation.
 """
 import ctypes as C
 import os
+import time
 from pathlib import Path
 
 import torch
@@ -67,7 +68,7 @@ class _CropInfo(C.Structure):
                 ('ratio', (C.c_double * 2) * 2), ('sbox', (C.c_float * 4) * 2)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 # OETR_WORKSPACE_STATUS_BYTES: the block that opens a workspace - status word, the split decoder's
 # call counters and exchange granules; zero it once (oetr_workspace_init), the library owns it after
 WORKSPACE_STATUS_BYTES = 256 + 16 * 5 * 4 * 256 * 8
@@ -87,11 +88,14 @@ EXPORTS = (
     'oetr_workspace_init', 'oetr_read_flags_async', 'oetr_neck_read_flags_async',
     'oetr_set_state_prereduce', 'oetr_set_tail_mode', 'oetr_set_decoder_split', 'oetr_overlap_frame', 'oetr_read_overlap_image',
     'oetr_forward_masked', 'oetr_feature_correlation_masked', 'oetr_center_estimation_masked',
-    'oetr_linear_attention_masked', 'oetr_debug_decoder_fault')
+    'oetr_linear_attention_masked', 'oetr_debug_decoder_fault',
+    'oetr_flagslot_device_pointer', 'oetr_forward_flagslot', 'oetr_forward_tokens_flagslot',
+    'oetr_neck_forward_tokens_status')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 FLAG_EXCHANGE = 2    # OETR_FLAG_EXCHANGE: the split decoder's workgroups were not resident together
 FLAG_INVALID = FLAG_F16_RANGE | FLAG_EXCHANGE   # either bit: that call's outputs are invalid
+FLAG_PUBLISHED = 0x80000000   # OETR_FLAG_PUBLISHED: set in every word a *_flagslot call stores into its slot
 
 
 def hot_path_keys():
@@ -246,6 +250,15 @@ def load_library(path=None):
         fn.argtypes = [vp, vp, vp, i, vp]                         # handle, workspace, host word, clear, stream
     lib.oetr_workspace_init.restype = i
     lib.oetr_workspace_init.argtypes = [vp, sz, vp]
+    # ABI 6: the status word published by the call's last kernel (no runtime dispatch behind it)
+    lib.oetr_flagslot_device_pointer.restype = i
+    lib.oetr_flagslot_device_pointer.argtypes = [vp, C.POINTER(vp)]
+    lib.oetr_forward_flagslot.restype = i
+    lib.oetr_forward_flagslot.argtypes = fwd[:5] + [vp, vp] + fwd[5:] + [vp, vp]       # ..., flag_slot, stream
+    lib.oetr_forward_tokens_flagslot.restype = i
+    lib.oetr_forward_tokens_flagslot.argtypes = [vp, i, i, i, i, i, i, i, i, i, vp, sz, vp, vp, vp, vp]
+    lib.oetr_neck_forward_tokens_status.restype = i
+    lib.oetr_neck_forward_tokens_status.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp, vp]
     lib.oetr_overlap_crop_capacity.restype = sz
     lib.oetr_overlap_crop_capacity.argtypes = [i, i, i, i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.oetr_overlap_crop.restype = i
@@ -303,22 +316,48 @@ def _query_flags(lib, fn, handle, ws, device, clear):
 
 
 class FlagTicket:
-    """A status word on its way to the host: the copy was ENQUEUED (``oetr_read_flags_async``)
-    behind the calls it reports on, nothing has synchronised.  ``value()`` waits for that copy
-    only (an event recorded right behind it) - by the time the next batch is submitted it has
-    long completed."""
+    """A status word on its way to the host, nothing has synchronised.  Two kinds:
 
-    def __init__(self, slot, event, owner=None, index=None):
+    * published (``oetr_forward*_flagslot``, ABI 6): the forward call's last kernel stores the word,
+      with ``FLAG_PUBLISHED`` set, into a mapped pinned host word that was zeroed before the call.
+      No dispatch and NO EVENT behind the batch (an event record is a marker packet on the stream:
+      measured 6 us of idle chip in front of the next batch's first kernel): ``value()`` polls the
+      word - by the time the next batch is submitted it has long arrived - and falls back to
+      synchronising the stream the call was enqueued on if it has not after ``POLL_S``.
+    * copied (``oetr_read_flags_async``): a 4-byte copy was ENQUEUED behind the calls it reports
+      on; ``value()`` waits for an event recorded right behind that copy."""
+
+    POLL_S = 0.05
+
+    def __init__(self, slot, event, owner=None, index=None, stream=None, published=False):
         self._slot, self._event = slot, event
         self._owner, self._index = owner, index     # graph words: handed back by release()
+        self._stream, self._published = stream, published
 
     def ready(self):
+        if self._published and self._stream is not None:
+            return bool(int(self._slot.item()) & FLAG_PUBLISHED)
         return self._event is None or self._event.query()
 
     def value(self):
         if self._event is not None:
             self._event.synchronize()
-        return int(self._slot.item())
+        if not self._published:
+            return int(self._slot.item())
+        word = int(self._slot.item()) & 0xffffffff
+        if not word & FLAG_PUBLISHED and self._stream is not None:     # eager call: poll, then synchronise
+            deadline = time.perf_counter() + self.POLL_S
+            while not word & FLAG_PUBLISHED and time.perf_counter() < deadline:
+                word = int(self._slot.item()) & 0xffffffff
+            if not word & FLAG_PUBLISHED:
+                self._stream.synchronize()
+                word = int(self._slot.item()) & 0xffffffff
+        if not word & FLAG_PUBLISHED:
+            if self._stream is None:
+                return 0      # captured into a graph that has not been replayed yet: nothing ran
+            raise OetrError('the status word of a forward call never reached its flag slot (the call has '
+                            'completed): the slot is not device-visible host memory')
+        return word & ~FLAG_PUBLISHED
 
     def release(self):
         """Hand a word captured into a HIP graph back to its reader (the graph was discarded:
@@ -345,6 +384,7 @@ class _FlagReader:
         self._next = 0
         self._pages = []          # pinned pages of graph words (kept alive here)
         self._free = []           # (page, index) pairs not handed out
+        self._dev_base = {}       # pinned block (host address) -> its device address
         self.reserve_graph_words(self.GRAPH_PAGE)
 
     def reserve_graph_words(self, n):
@@ -359,6 +399,48 @@ class _FlagReader:
 
     def _release(self, key):
         self._free.append(key)
+
+    def _device_address(self, lib, slot):
+        """Device address of a pinned word (``oetr_flagslot_device_pointer``; resolved once per
+        pinned block, raises if torch's pinned memory is not mapped into the device)."""
+        base = slot._base if slot._base is not None else slot
+        key = base.data_ptr()
+        dev = self._dev_base.get(key)
+        if dev is None:
+            out = C.c_void_p()
+            _check(lib, lib.oetr_flagslot_device_pointer(key, C.byref(out)), 'oetr_flagslot_device_pointer')
+            dev = self._dev_base[key] = out.value
+        return dev + (slot.data_ptr() - key)
+
+    def publish_slot(self, lib):
+        """Reserve a word for a ``*_flagslot`` forward call: -> (slot, device address, owner, key).
+        Hand all four to :meth:`published` right after the call was enqueued."""
+        capturing = torch.cuda.is_current_stream_capturing()
+        owner = key = None
+        if capturing:
+            if not self._free:
+                raise OetrError('no free status word for a forward call captured into a HIP graph: release '
+                                'the tickets of discarded graphs (OETR.hip_graph_release) or reserve more '
+                                'outside capture (reserve_graph_words)')
+            key = self._free.pop(0)
+            slot = self._pages[key[0]][key[1]:key[1] + 1]
+            owner = self
+        else:
+            if len(self._free) < self.GRAPH_PAGE // 2:
+                self.reserve_graph_words(self.GRAPH_PAGE)      # top up while pinning is allowed
+            i = self._next
+            self._next = (self._next + 1) % self.SLOTS
+            slot = self._words[i:i + 1]
+        if not capturing:
+            slot.zero_()      # (host store to pinned memory, before the call is enqueued: the ticket polls for FLAG_PUBLISHED)
+        return slot, self._device_address(lib, slot), owner, key
+
+    def published(self, slot, owner, key, device):
+        """The ticket of a ``*_flagslot`` call just enqueued on the current stream of ``device``."""
+        if torch.cuda.is_current_stream_capturing():
+            # valid once a replay has been synchronised (every replay rewrites the word)
+            return FlagTicket(slot, None, owner, key, published=True)
+        return FlagTicket(slot, None, stream=torch.cuda.current_stream(device), published=True)
 
     def read(self, lib, fn, handle, ws, device, clear):
         capturing = torch.cuda.is_current_stream_capturing()
@@ -639,11 +721,14 @@ class HotPathEngine:
 
     # -------------------------------------------------------------- calls
     def forward(self, feat1, feat2, pos1, pos2, img_hw1, img_hw2, stages=None,
-                enc_layers=N_ENC, mask1=None, mask2=None):
+                enc_layers=N_ENC, mask1=None, mask2=None, publish=False):
         """feats [N,256,hf,wf] + pos [1,256,hf,wf] -> (box1, box2) [N,4].
         With ``stages=True`` returns a dict of intermediates as well.
         ``mask1`` / ``mask2``: forward_dummy's optional masks at the token grid's resolution
-        (``oetr_forward_masked``; with them ``logits`` holds -1e9 at masked tokens)."""
+        (``oetr_forward_masked``; with them ``logits`` holds -1e9 at masked tokens).
+        ``publish=True`` (not with ``stages``): -> ((box1, box2), FlagTicket) - the call's last
+        kernel moves the workspace's status word into a pinned host word
+        (``oetr_forward_flagslot``), the deferred check without a dispatch of its own."""
         feat1, feat2 = _dev(feat1, 'feat1'), _dev(feat2, 'feat2')
         pos1, pos2 = _dev(pos1, 'pos1'), _dev(pos2, 'pos2')
         n = int(feat1.shape[0])
@@ -665,6 +750,14 @@ class HotPathEngine:
         if mask1 is not None:
             margs = args[:5] + [mask1.data_ptr(), mask2.data_ptr()] + args[5:]
         with torch.cuda.device(dev):
+            if publish:
+                if stages:
+                    raise ValueError('publish=True has no stage outputs (oetr_forward_flagslot)')
+                slot, dptr, owner, key = self._flag_reader.publish_slot(self.lib)
+                fargs = margs if margs is not None else args[:5] + [None, None] + args[5:]
+                _check(self.lib, self.lib.oetr_forward_flagslot(*fargs, dptr, _stream(dev)),
+                       'oetr_forward_flagslot')
+                return (box1, box2), self._flag_reader.published(slot, owner, key, dev)
             if not stages:
                 if margs is not None:
                     _check(self.lib, self.lib.oetr_forward_masked(*margs, None, _stream(dev)),
@@ -737,14 +830,22 @@ class HotPathEngine:
             bufs['pos2'].copy_(pos2.reshape(D_MODEL, -1).t())
             self._pos_loaded[skey] = key
 
-    def forward_tokens(self, n, hf1, wf1, hf2, wf2, img_hw1, img_hw2):
+    def forward_tokens(self, n, hf1, wf1, hf2, wf2, img_hw1, img_hw2, publish=False):
         """``forward`` on the tokens / position tables the workspace holds
-        (``token_buffers``): -> (box1, box2) [n,4]."""
+        (``token_buffers``): -> (box1, box2) [n,4]; ``publish=True``: -> ((box1, box2),
+        FlagTicket) as in :meth:`forward` (``oetr_forward_tokens_flagslot``)."""
         ws = self.workspace(n, hf1, wf1, hf2, wf2)
         dev = self.device
         both = torch.empty(2, n, 4, device=dev)   # one [2,n,4] block: what parallel.BoxGatherer sends, without a copy
         box1, box2 = both[0], both[1]
         with torch.cuda.device(dev):
+            if publish:
+                slot, dptr, owner, key = self._flag_reader.publish_slot(self.lib)
+                _check(self.lib, self.lib.oetr_forward_tokens_flagslot(
+                    self._h, n, hf1, wf1, hf2, wf2, int(img_hw1[0]), int(img_hw1[1]),
+                    int(img_hw2[0]), int(img_hw2[1]), ws.data_ptr(), ws.numel(),
+                    box1.data_ptr(), box2.data_ptr(), dptr, _stream(dev)), 'oetr_forward_tokens_flagslot')
+                return (box1, box2), self._flag_reader.published(slot, owner, key, dev)
             _check(self.lib, self.lib.oetr_forward_tokens(
                 self._h, n, hf1, wf1, hf2, wf2, int(img_hw1[0]), int(img_hw1[1]),
                 int(img_hw2[0]), int(img_hw2[1]), ws.data_ptr(), ws.numel(),
@@ -897,9 +998,12 @@ class NeckEngine:
                 feat.data_ptr(), _stream(self.device)), 'oetr_neck_forward')
         return feat
 
-    def forward_tokens(self, backbone_feat, tokens_out):
+    def forward_tokens(self, backbone_feat, tokens_out, status_word=None):
         """Same as ``forward`` with the result stored token-major into ``tokens_out``
-        [n*(hb//2)*(wb//2), 256] (a ``HotPathEngine.token_buffers`` view)."""
+        [n*(hb//2)*(wb//2), 256] (a ``HotPathEngine.token_buffers`` view).  ``status_word``: a
+        device tensor whose first 4 bytes take the neck's range bit instead of the neck
+        workspace's own word (``oetr_neck_forward_tokens_status``) - pass the hot-path workspace
+        the tokens go into, and the forward call behind publishes one word for both stages."""
         x = _dev(backbone_feat, 'backbone_feat')
         if x.dim() != 4 or x.shape[1] != self.BACKBONE_C:
             raise ValueError(f'backbone_feat must be [n,{self.BACKBONE_C},hb,wb], '
@@ -914,6 +1018,14 @@ class NeckEngine:
             raise ValueError(f'invalid neck shape n={n} grid {hb}x{wb}')
         ws = self._workspace(need)
         with torch.cuda.device(self.device):
+            if status_word is not None:
+                if not status_word.is_cuda or status_word.device != tokens_out.device:
+                    raise ValueError('status_word must live on the device of tokens_out')
+                _check(self.lib, self.lib.oetr_neck_forward_tokens_status(
+                    self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
+                    tokens_out.data_ptr(), status_word.data_ptr(), _stream(self.device)),
+                    'oetr_neck_forward_tokens_status')
+                return tokens_out
             _check(self.lib, self.lib.oetr_neck_forward_tokens(
                 self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
                 tokens_out.data_ptr(), _stream(self.device)), 'oetr_neck_forward_tokens')

@@ -132,8 +132,8 @@ class OETR(nn.Module):
         #: 'f32' = redo the batch with exact-fp32 MFMA (neck: the torch modules),
         #: 'raise' = OetrRangeError, 'ignore' = do not check
         self.hip_on_overflow = 'f32'
-        #: True (default): forward_dummy only ENQUEUES - the status word of batch i travels to a
-        #: pinned host word behind the batch (oetr_read_flags_async) and is examined when batch
+        #: True (default): forward_dummy only ENQUEUES - the status word of batch i is stored into a
+        #: pinned host word by the batch's LAST KERNEL (oetr_forward*_flagslot) and is examined when batch
         #: i+2 is submitted (one batch stays in flight behind the one being submitted, so the host
         #: never waits for the device), or by hip_flush(); a tripped batch is then re-run ('f32': its box
         #: tensors are overwritten in place, in stream order) or reported ('raise').  The boxes
@@ -448,14 +448,20 @@ class OETR(nn.Module):
         def enqueue():
             bufs = eng.token_buffers(n, hf1, wf1, hf2, wf2)
             eng.load_pos_tokens(bufs, pos1, pos2)
+            # checked: the neck ORs its range bit into the hot-path workspace's status word, and the
+            # forward call's last kernel publishes that ONE word into a pinned host slot (ABI 6: no
+            # copy / fill dispatch behind the batch).  The engine's word is read in every checked
+            # precision: OETR_FLAG_EXCHANGE is not a range matter.
+            word = eng._current_ws() if checked else None
             if both is not None:
-                neck.forward_tokens(both, bufs['tokens'])
+                neck.forward_tokens(both, bufs['tokens'], status_word=word)
             else:
-                neck.forward_tokens(bb1, bufs['tokens1'])
-                neck.forward_tokens(bb2, bufs['tokens2'])
-            boxes = eng.forward_tokens(n, hf1, wf1, hf2, wf2, hw1, hw2)
-            # (the engine's word is read in every checked precision: OETR_FLAG_EXCHANGE is not a range matter)
-            return boxes, ([neck.read_flags_async(), eng.read_flags_async()] if checked else [])
+                neck.forward_tokens(bb1, bufs['tokens1'], status_word=word)
+                neck.forward_tokens(bb2, bufs['tokens2'], status_word=word)
+            if not checked:
+                return eng.forward_tokens(n, hf1, wf1, hf2, wf2, hw1, hw2), []
+            boxes, ticket = eng.forward_tokens(n, hf1, wf1, hf2, wf2, hw1, hw2, publish=True)
+            return boxes, [ticket]
 
         def rerun(exchange_only=False):   # the unfused route carries the per-stage handling (raise / exact fp32)
             feat1, feat2 = self.neck(bb1), self.neck(bb2)
@@ -629,8 +635,11 @@ class OETR(nn.Module):
         self._decoder_policy(eng, checked)
 
         def enqueue():
-            boxes = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2)
-            return boxes, ([eng.read_flags_async()] if checked else [])
+            if not checked:
+                return eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2), []
+            boxes, ticket = eng.forward(feat1, feat2, pos1, pos2, hw1, hw2, mask1=mask1, mask2=mask2,
+                                        publish=True)       # status word published by the last kernel
+            return boxes, [ticket]
 
         def rerun(exchange_only=False):
             if exchange_only:

@@ -45,8 +45,11 @@ extern "C" {
  * 4: forward_dummy's optional masks: oetr_forward_masked, oetr_feature_correlation_masked,
  *    oetr_center_estimation_masked, oetr_linear_attention_masked (new exports; nothing else changed)
  * 5: oetr_debug_decoder_fault (new export, tests only); a timed-out split decoder publishes nothing
- *    further and the caller re-initialises the status block (OETR_FLAG_EXCHANGE below) */
-#define OETR_ABI_VERSION 5
+ *    further and the caller re-initialises the status block (OETR_FLAG_EXCHANGE below)
+ * 6: the status word is PUBLISHED BY THE LAST KERNEL of a forward call instead of by two runtime
+ *    dispatches behind it: oetr_flagslot_device_pointer, oetr_forward_flagslot,
+ *    oetr_forward_tokens_flagslot, oetr_neck_forward_tokens_status (new exports; nothing else changed) */
+#define OETR_ABI_VERSION 6
 #define OETR_D_MODEL 256
 #define OETR_N_HEAD 8
 #define OETR_N_ENC 8 /* self,cross x4  - reference src/models/transformer.py:295 */
@@ -207,12 +210,29 @@ void oetr_destroy(oetr_handle h);
  * in the fp32 reference; it guards the reduced-range operand formats. */
 #define OETR_FLAG_F16_RANGE 1u
 #define OETR_FLAG_EXCHANGE 2u
+#define OETR_FLAG_PUBLISHED 0x80000000u /* flag slots only (ABI 6): "this slot was written by the call" */
 #define OETR_WORKSPACE_STATUS_BYTES (256 + 16 * 5 * 4 * 256 * 8)
 oetr_status oetr_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 oetr_status oetr_query_flags(oetr_handle h, void *workspace, void *stream,
                              uint32_t *flags, int clear);
 oetr_status oetr_read_flags_async(oetr_handle h, void *workspace,
                                   uint32_t *host_flags, int clear, void *stream);
+/* ABI 6 - the deferred check WITHOUT its two runtime dispatches.  oetr_read_flags_async costs one
+ * 4-byte copy kernel and one 4-byte fill kernel per batch (rocprofv3: __amd_rocclr_copyBuffer 5.3 us +
+ * __amd_rocclr_fillBufferAligned 4.2 us and two launch boundaries in a 343-us step).  The _flagslot
+ * forms of the forward calls (below) take a FLAG SLOT instead: one uint32_t of host memory the device can
+ * write (hipHostMalloc / hipHostRegister with the mapped attribute; torch's pinned memory is), passed by
+ * its DEVICE address.  The last kernel of the call (k_heat_final; every kernel that can set a bit has
+ * completed by then - same stream) exchanges the workspace's status word with 0 and stores the old
+ * value, with OETR_FLAG_PUBLISHED set, into the slot at system scope.  The slot holds the word of THAT
+ * call (and of earlier calls on the workspace that nobody read) once the call has completed: wait for an
+ * event recorded behind it, or - cheaper, an event costs the stream a marker packet and ~6 us of idle
+ * chip in front of the next kernel - zero the slot before the call and poll it for OETR_FLAG_PUBLISHED
+ * (fall back to a stream synchronisation if the poll outlasts your patience).  Nothing else is
+ * enqueued.  hipGraph-capturable like every forward call (the slot address is a kernel argument).
+ * oetr_flagslot_device_pointer: hipHostGetDevicePointer for callers without HIP bindings - the address
+ * the device uses for mapped host memory `host_slot` (OETR_ERR_BAD_ARG when it is not mapped). */
+oetr_status oetr_flagslot_device_pointer(void *host_slot, uint32_t **device_slot);
 
 /* Token rows per encoder workgroup: 0 = auto (default), 32 or 64.  64 exists in
  * the 16-bit-operand dtypes only (ignored for OETR_DTYPE_F32): fewer
@@ -322,6 +342,23 @@ oetr_status oetr_forward_tokens(oetr_handle h, int n_pairs, int hf1, int wf1,
                                 int img_h2, int img_w2, void *workspace,
                                 size_t workspace_bytes, float *box1,
                                 float *box2, void *stream);
+
+/* oetr_forward (mask1 == mask2 == NULL) / oetr_forward_masked without stages, and oetr_forward_tokens,
+ * publishing the workspace's status word into `flag_slot` (device address of mapped host memory, see
+ * oetr_flagslot_device_pointer above) from their last kernel, which also clears the word.  Same
+ * arguments, same results, same error behaviour otherwise; flag_slot must not be NULL. */
+oetr_status oetr_forward_flagslot(oetr_handle h, const float *feat1, const float *feat2,
+                                  const float *pos1, const float *pos2,
+                                  const float *mask1, const float *mask2, int n_pairs,
+                                  int hf1, int wf1, int hf2, int wf2, int img_h1,
+                                  int img_w1, int img_h2, int img_w2, void *workspace,
+                                  size_t workspace_bytes, float *box1, float *box2,
+                                  uint32_t *flag_slot, void *stream);
+oetr_status oetr_forward_tokens_flagslot(oetr_handle h, int n_pairs, int hf1, int wf1,
+                                         int hf2, int wf2, int img_h1, int img_w1,
+                                         int img_h2, int img_w2, void *workspace,
+                                         size_t workspace_bytes, float *box1,
+                                         float *box2, uint32_t *flag_slot, void *stream);
 
 /* Same as oetr_forward, additionally exporting intermediates. box1/box2 may
  * be NULL when stages->enc_layers < 8. */
@@ -479,6 +516,16 @@ oetr_status oetr_neck_forward_tokens(oetr_neck_handle h,
                                      int hb, int wb, void *workspace,
                                      size_t workspace_bytes, float *tokens_out,
                                      void *stream);
+/* ABI 6: oetr_neck_forward_tokens whose range bit (OETR_FLAG_F16_RANGE) goes into a status word of the
+ * CALLER'S choice instead of the neck workspace's own: `status_word` = device address of a 4-byte word,
+ * normally the first word of the hot-path workspace the tokens are stored into - the forward call that
+ * consumes them (oetr_forward_tokens_flagslot) then publishes ONE word for both stages and the neck needs
+ * no read of its own.  The word is only ever OR-ed into. */
+oetr_status oetr_neck_forward_tokens_status(oetr_neck_handle h,
+                                            const float *backbone_feat, int n_images,
+                                            int hb, int wb, void *workspace,
+                                            size_t workspace_bytes, float *tokens_out,
+                                            uint32_t *status_word, void *stream);
 /* Output positions per workgroup of the fused PatchMerging conv kernel: 0 = auto
  * (default: the shape with the fewest workgroup rounds over the CUs for this problem
  * size), or 256 / 192 / 128.  Results are identical in every shape (same summation

@@ -23,7 +23,7 @@ def header_functions():
 def test_library_exports_every_declared_symbol():
     lib = pkg.load_library()
     names = header_functions()
-    assert len(names) == 48, names
+    assert len(names) == 52, names
     assert set(names) == set(hip_engine.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/oetr_hip.h but not exported'
@@ -94,6 +94,17 @@ def test_null_arguments_are_rejected_not_crashed():
     assert lib.oetr_center_estimation_masked(None, None, None, None, None, None, None, 1, 20, 20, 20, 20,
                                              640, 640, None, 0, None, None, None) == 1
     assert lib.oetr_linear_attention_masked(None, None, None, None, None, 1, 4, 4, None, None, 0, None) == 1
+    # the flag-slot entries (ABI 6): a NULL slot is refused before anything else is looked at
+    st = lib.oetr_forward_flagslot(None, None, None, None, None, None, None, 1, 20, 20, 20, 20, 640,
+                                   640, 640, 640, None, 0, None, None, None, None)
+    assert st == 1 and b'flag_slot' in lib.oetr_last_error()
+    st = lib.oetr_forward_tokens_flagslot(None, 1, 20, 20, 20, 20, 640, 640, 640, 640, None, 0, None, None,
+                                          None, None)
+    assert st == 1 and b'flag_slot' in lib.oetr_last_error()
+    assert lib.oetr_neck_forward_tokens_status(None, None, 1, 40, 40, None, 0, None, None, None) == 1
+    assert b'status_word' in lib.oetr_last_error()
+    out = ctypes.c_void_p()
+    assert lib.oetr_flagslot_device_pointer(None, ctypes.byref(out)) == 1
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -236,6 +236,47 @@ def test_neck_stores_tokens_straight_into_the_hot_path(gpu):
         model.boxes_from_backbone(bb[:2] * 1e6, bb[2:] * 1e6, (640, 640), (640, 640))
 
 
+def test_status_word_is_published_by_the_last_kernel(gpu):
+    """ABI 6 (``oetr_forward_flagslot`` / ``oetr_forward_tokens_flagslot`` /
+    ``oetr_neck_forward_tokens_status``): the forward call's last kernel moves the workspace's
+    status word into a pinned host word and leaves 0 behind - same word ``oetr_query_flags``
+    would have read, same boxes as the plain call, nothing else enqueued."""
+    w = orc.make_hot_weights(7, sharpen=True)
+    eng = pkg.HotPathEngine(w, device=gpu)
+    f1, f2 = orc.make_features(70, 2, 8, 8).to(gpu), orc.make_features(71, 2, 5, 7).to(gpu)
+    p1, p2 = orc.position_table(8, 8).to(gpu), orc.position_table(5, 7).to(gpu)
+    want = eng.forward(f1, f2, p1, p2, (256, 256), (160, 224))
+    assert eng.query_flags() == 0
+    got, ticket = eng.forward(f1, f2, p1, p2, (256, 256), (160, 224), publish=True)
+    assert ticket.value() == 0
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # an operand beyond the f16 range: the bit arrives in the slot and the device word is clear again
+    _, ticket = eng.forward(f1 * 1e6, f2, p1, p2, (256, 256), (160, 224), publish=True)
+    assert ticket.value() & pkg.hip_engine.FLAG_F16_RANGE
+    assert eng.query_flags(clear=False) == 0
+    # ... and a clean call behind it reports clean (the slot ring moved on, the word was reset)
+    got, ticket = eng.forward(f1, f2, p1, p2, (256, 256), (160, 224), publish=True)
+    assert ticket.value() == 0 and torch.equal(got[0], want[0])
+    # masks take the same entry
+    m1, m2 = orc.make_masks(73, 2, 8, 8, 'holes'), orc.make_masks(74, 2, 5, 7, 'pad')
+    wm = eng.forward(f1, f2, p1, p2, (256, 256), (160, 224), mask1=m1, mask2=m2)
+    gm, ticket = eng.forward(f1, f2, p1, p2, (256, 256), (160, 224), mask1=m1, mask2=m2, publish=True)
+    assert ticket.value() == 0 and torch.equal(gm[0], wm[0]) and torch.equal(gm[1], wm[1])
+    with pytest.raises(ValueError):
+        eng.forward(f1, f2, p1, p2, (256, 256), (160, 224), stages=True, publish=True)
+    # neck -> tokens: the neck's range bit lands in the hot-path workspace's word, one slot for both stages
+    neck = pkg.NeckEngine(orc.make_neck_weights(8), device=gpu)
+    bb = orc.make_backbone_features(72, 4, 10, 12).to(gpu)
+    for scale, bit in ((1.0, 0), (1e6, pkg.hip_engine.FLAG_F16_RANGE)):
+        bufs = eng.token_buffers(2, 5, 6, 5, 6)
+        eng.load_pos_tokens(bufs, orc.position_table(5, 6).to(gpu), orc.position_table(5, 6).to(gpu))
+        neck.forward_tokens(bb * scale, bufs['tokens'], status_word=eng._current_ws())
+        assert neck.query_flags() == 0                      # nothing went into the neck's own word
+        _, ticket = eng.forward_tokens(2, 5, 6, 5, 6, (160, 192), (160, 192), publish=True)
+        assert ticket.value() & pkg.hip_engine.FLAG_F16_RANGE == bit
+        assert eng.query_flags(clear=False) == 0
+
+
 def test_forward_dummy_to_crop_is_one_hip_graph_with_the_default_guard(gpu):
     """with the DEFAULT settings (hip_on_overflow='f32', deferred check)
     ``forward_dummy -> overlap_crop`` is enqueue-only - one batch captured into a single HIP
