@@ -62,10 +62,12 @@ DOMINANT = 'k_encoder<B,A>'
 MODE_ID = {'f32': 0, 'f32_split_f16': 1, 'f16': 2, 'bf16': 3, 'f32_split_qk16': 1}   # GM_* id in mangled kernel names
 POLICY_ID = {'f32_split_qk16': 1}
 
+# What MI355X SUSTAINS on back-to-back dense f16 MFMAs at its socket power cap - the roof a power-bound kernel can
+# actually reach - is MEASURED in the run that quotes it (oetr_debug_mfma_rate, ~1 s, N = 1): CALIB['f16_sustained']
+# stays None (and the second yardstick is left out) when the calibration did not run.  Round 5 carried a constant here
+# (1 642 TFLOP/s, one box, a stand-alone probe: profiles/r5_energy_prices.txt).
+CALIB = {'f16_sustained': None, 'event_pair_us': 0.0}
 # MFMA products executed per algorithmic product, and the pipe they run on
-# What MI355X SUSTAINS on back-to-back dense f16 MFMAs: 1642 TFLOP/s at the 1.69 GHz its 1400-W socket cap leaves
-# (tools/energy/energy_probe.hip, profiles/r5_energy_prices.txt) - the roof a power-bound kernel can actually reach.
-F16_MFMA_SUSTAINED_TFLOPS = 1642.0
 MFMA_COST = {'f32': (1, F32_MFMA_PEAK_TFLOPS, 'f32 MFMA (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s'),
              'f32_split_f16': (3, F16_MFMA_PEAK_TFLOPS,
                                'dense f16 MFMA 2500 TFLOP/s / 3 MFMA products per fp32-class product'),
@@ -130,6 +132,8 @@ def parse_args(argv=None):
                     help='oetr_set_state_prereduce for the overlapped run (-1 = the library rule; A/Bs)')
     ap.add_argument('--decoder-split', type=int, default=0, choices=[0, 1, 4],
                     help='oetr_set_decoder_split for the serial run (0 = the library rule; A/Bs)')
+    ap.add_argument('--no-rccl-world1', action='store_true',
+                    help='N = 1: skip the regions with an RCCL process group of one rank (roofline.other_configs.c1_rccl_world1)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the short driver-timed regions of BASELINE configs[2] / [3] / [4] (N=1, default '
                          'workload only; about 20 s)')
@@ -310,13 +314,21 @@ def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_work
     if not kern or DOMINANT not in kern:
         return None
     launches, total_ms = kern[DOMINANT]
-    avg_ms = total_ms / launches
+    raw_ms = total_ms / launches
+    # the library brackets every launch with two HIP events on its stream; an event pair with NOTHING between
+    # measures CALIB['event_pair_us'] on this box (main(): median of 200), and about three quarters of that is
+    # what a bracket adds to the kernel it surrounds (the closing marker is fetched while the kernel still
+    # runs) - same-process comparison with rocprofv3, profiles/r6_event_bracket.txt: k_encoder32m<B,A> 39.99 us
+    # from the brackets, 35.59 us from rocprofv3, empty pair 5.64 us -> 0.78.  `frac` uses the net figure (the
+    # one comparable with the committed rocprofv3 summaries), `frac_events_raw` the bracket as it reads
+    avg_ms = max(raw_ms - 0.75 * CALIB['event_pair_us'] * 1e-3, 0.5 * raw_ms)
     flop = ENC_FLOP_PER_TOKEN * tokens + extra_flop   # algorithmic, both sides
     cost, pipe_peak, basis = MFMA_COST[precision]
     # `achieved` is ALGORITHMIC FLOP/s; the MFMA roof for a scheme that spends `cost`
     # MFMA products per algorithmic product is the pipe's dense peak / cost.
     peak = pipe_peak / cost
     ach = flop / (avg_ms * 1e-3) / 1e12
+    sustained = CALIB['f16_sustained'] if pipe_peak == F16_MFMA_PEAK_TFLOPS else None
     block = {
         'kernel': ('k_encoder64<B,A>' if tile == 64 else
                    'k_encoder32m<B,A>' if precision in ('f32_split_f16', 'f32_split_qk16') and attention == 'linear'
@@ -325,9 +337,12 @@ def roofline_block(kern, precision, tokens, tile, steps, traced_s, standard_work
         'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'peak_basis': basis,
         'executed_mfma_tflops': round(ach * cost, 2),
         # (second yardstick, f16-pipe modes: the dense-MFMA rate the chip sustains at its power cap - measured, not nominal)
-        **({'sustained_peak': round(F16_MFMA_SUSTAINED_TFLOPS / cost, 1),
-            'frac_of_sustained_peak': round(ach / (F16_MFMA_SUSTAINED_TFLOPS / cost), 4)} if pipe_peak == F16_MFMA_PEAK_TFLOPS else {}),
-        'avg_launch_us': round(avg_ms * 1e3, 2), 'launches': launches, 'flop_per_launch': flop,
+        **({'sustained_peak_measured': round(sustained / cost, 1),
+            'frac_of_sustained_peak': round(ach / (sustained / cost), 4)} if sustained else {}),
+        'avg_launch_us': round(avg_ms * 1e3, 2), 'avg_launch_us_events_raw': round(raw_ms * 1e3, 2),
+        'event_pair_us': round(CALIB['event_pair_us'], 2), 'event_bracket_overhead_us': round(0.75 * CALIB['event_pair_us'], 2),
+        'frac_events_raw': round(flop / (raw_ms * 1e-3) / 1e12 / peak, 4),
+        'launches': launches, 'flop_per_launch': flop,
         'share_of_step': round(total_ms / (traced_s * 1e3), 4),
         'traced_ms_per_step': round(traced_s / steps * 1e3, 4)}
     if grids:   # one workgroup per CU (LDS): how much of the chip a launch of this batch can occupy
@@ -749,12 +764,14 @@ def main():
     # attention='full' adds QK^T and PV: 4*L*S*C per encoder call and image (self / cross average)
     extra_flop = 0 if args.attention == 'linear' else 4 * 256 * n * (L1 * L1 + L2 * L2 + 2 * L1 * L2) // 2
 
-    gatherer = BoxGatherer(on_stream={'auto': None, '0': False, '1': True}[args.gather_on_stream]) if use_pg else None
+    # (mutable: the RCCL-at-world-1 region of an N = 1 run brings a group up for one measurement, below)
+    pg = {'use': use_pg,
+          'gatherer': BoxGatherer(on_stream={'auto': None, '0': False, '1': True}[args.gather_on_stream]) if use_pg else None}
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
 
     def barrier():
-        if use_pg:
+        if pg['use']:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -809,11 +826,14 @@ def main():
             # consecutive steps alternate over the model's streams (one workspace per stream in
             # the engine); every step is a full batch of n pairs through the whole path
             b1, b2 = m.boxes_from_features(feat1, feat2, pos, pos2, hw, hw2)
+            gatherer = pg['gatherer']
             if gatherer is not None:
-                # the all-gather of this batch's boxes is enqueued right behind the batch: on the batch's
-                # own side stream in the throughput mode (a blocking collective there - the other side
-                # streams carry on), on RCCL's stream under the next batch's kernels in the serial
-                # mode; it is completed at the next submit / the flush
+                # the all-gather of a batch's boxes is ISSUED once the model has settled that batch's deferred
+                # check (BoxGatherer(model=...): k batches later, from this submit - no rank ever receives boxes
+                # that are corrected afterwards): on that batch's own side stream in the throughput mode (a
+                # blocking collective there - the other side streams carry on), on RCCL's stream under the
+                # next batch's kernels in the serial mode; completed at a later submit / the flush
+                gatherer.model = m
                 with torch.cuda.stream(m.hip_batch_stream()):
                     gatherer.submit(b1, b2)
         barrier()
@@ -821,12 +841,12 @@ def main():
         for i in range(args.steps):
             step(i)
         m.hip_flush()                   # every batch's range check settled, in submission order
-        if gatherer is not None:
-            gatherer.flush()            # last batch's gather is inside the timed region
+        if pg['gatherer'] is not None:
+            pg['gatherer'].flush()      # the last batches' gathers are inside the timed region
         barrier()                       # closing barrier + synchronise of the bracket: inside the timed region
         dt = time.perf_counter() - t0   # (under RCCL the barrier collective's own host latency is 0.2-0.45 ms: 4-9 % of a
                                         #  20-step region of 5 ms, nothing at --steps 200; profiles/r5_pg_streams.txt)
-        if use_pg:
+        if pg['use']:
             t = torch.tensor([dt, -dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             step_spread['last'] = (float(-t[1].item()), float(t[0].item()))   # (fastest, slowest) rank
@@ -869,6 +889,25 @@ def main():
             res['trace_serial_shape'] = traced(m, eng)
         return res
 
+    if world == 1 and not use_pg and not args.no_trace:
+        # the two yardsticks that belong to THIS box and THIS run: what an empty HIP-event bracket reads, and the
+        # dense f16 MFMA rate the chip sustains at its power cap (with the clock it held, from rocm-smi beside it)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record()
+            b.record()
+        torch.cuda.synchronize()
+        CALIB['event_pair_us'] = statistics.median(a.elapsed_time(b) for a, b in evs) * 1e3
+        if not args.no_power:
+            try:
+                from imagematching_oetr_amd.hip_engine import sustained_mfma_tflops
+                rates = []
+                CALIB['f16_sustained_power'] = power_sample(lambda k: rates.append(sustained_mfma_tflops(device, 0.5)),
+                                                            seconds=1.5)
+                CALIB['f16_sustained'] = statistics.median(rates) if rates else None
+            except Exception as e:
+                print(f'[bench] MFMA-rate calibration failed: {e!r}', file=sys.stderr)
     main_res = measure(args.precision, with_serial_trace=True)
     eng = main_res['engine']
     power = None
@@ -890,6 +929,60 @@ def main():
     exact_res = None
     if args.precision == 'f32_split_f16' and not args.no_exact_f32 and args.attention == 'linear':
         exact_res = measure('f32', with_serial_trace=False)
+    # RCCL on the N = 1 line: the same two regions with a process group of ONE rank up -
+    # librccl loaded and bound to the device, the box all-gather of every batch issued by BoxGatherer, the
+    # bracket's dist.barrier() and the timing all-reduce executed - exactly the code an N > 1 launch runs.
+    # 5 x --steps per region (the barrier collective's own host latency, 0.2-0.45 ms, is a fixed cost per
+    # region: profiles/r5_pg_streams.txt).  RCCL's banner goes through C stdio: stdout is parked on stderr.
+    rccl_w1 = None
+    if world == 1 and not use_pg and standard and args.precision == 'f32_split_f16' and not args.no_rccl_world1:
+        saved_fd, saved_steps = os.dup(1), args.steps
+        try:
+            sys.stdout.flush()
+            os.dup2(2, 1)
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{free_port()}', rank=0, world_size=1,
+                                    device_id=device)
+            pg['use'], pg['gatherer'] = True, BoxGatherer()
+            m = main_res['model']
+            args.steps = 5 * saved_steps
+            configure(m, n_streams, n_streams > 1)
+            warm(m, n_streams)
+            ov = repeated(m, n_streams)
+            configure(m, 1, False)
+            warm(m, 1)
+            se = repeated(m, 1)
+            args.steps = saved_steps
+            pg['use'], pg['gatherer'] = False, None
+            configure(m, n_streams, n_streams > 1)       # the same 5 x regions without the group: the comparison
+            args.steps = 5 * saved_steps
+            warm(m, n_streams)
+            ov0 = repeated(m, n_streams)
+            with open('/proc/self/maps') as f:
+                mapped = any('librccl' in line for line in f)
+            rccl_w1 = {'pairs_per_s': round(n_total * args.steps / ov[0], 1),
+                       'serial_pairs_per_s': round(n_total * args.steps / se[0], 1),
+                       'pairs_per_s_no_group_same_region': round(n_total * args.steps / ov0[0], 1),
+                       'steps_per_region': args.steps, 'librccl_mapped': mapped,
+                       'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                       'collective': 'all_gather_into_tensor of the [2,n,4] box block per batch, issued once the '
+                                     'batch\'s deferred check has settled (BoxGatherer(model=...))'}
+        except Exception as e:
+            rccl_w1 = {'error': repr(e)[:300]}
+        finally:
+            args.steps = saved_steps
+            pg['use'], pg['gatherer'] = False, None
+            try:
+                if dist.is_initialized():
+                    torch.cuda.synchronize()
+                    dist.destroy_process_group()
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     if rank != 0:
         if use_pg:
@@ -902,8 +995,8 @@ def main():
     cost, pipe_peak, _ = MFMA_COST[args.precision]
     pair_gflop = PAIR_GFLOP_640 * (hf * hf + hf2 * hf2) / 800
     tile_overlap = main_res['tile_overlap']
-    dtype = {'f32': 'f32', 'f32_split_f16': 'f32', 'f16': 'f16', 'bf16': 'bf16',
-             'f32_split_qk16': 'f32 (Q/K projections f16)'}[args.precision]
+    dtype = {'f32': 'f32', 'f32_split_f16': 'f32 (3xf16-split operands, fp32 accumulate)', 'f16': 'f16', 'bf16': 'bf16',
+             'f32_split_qk16': 'f32 (3xf16-split operands, fp32 accumulate; Q/K projections single f16)'}[args.precision]
     tag = ''
     if standard and args.precision in ('f32', 'f32_split_f16'):
         tag = 'BASELINE configs[1]: '
@@ -969,8 +1062,8 @@ def main():
             if out.get('power', {}).get('overlapped'):   # (kept keys of the driver's record: roofline, config)
                 pw = out['power']['overlapped']
                 rb['socket_w_cap_w_sclk_mhz'] = [pw['socket_w'], pw['cap_w'], pw['sclk_mhz']]
-                rb['power_note'] = ('the socket draws within a few percent of its power cap while this mode runs (sustained: '
-                                    'profiles/r5_power.txt); peak is quoted at the nominal 2400 MHz, the cap leaves sclk_mhz')
+                rb['power_note'] = ('socket power / cap / shader clock while this mode runs (rocm-smi beside a 2.5-s run, outside the '
+                                    'timed regions); `peak` is quoted at the nominal 2400 MHz')
             out['kernels_us'] = {k: [v[0] // args.steps, round(v[1] / v[0] * 1e3, 2)]
                                  for k, v in kern.items()}
             out['kernels_us_sum'] = round(sum(v[1] for v in kern.values()) / args.steps * 1e3, 1)
@@ -998,6 +1091,27 @@ def main():
             rb = roofline_block(kern, 'f32', tokens, 32, args.steps, t_s, standard)
             if rb:
                 out['exact_f32']['roofline'] = rb
+    if 'roofline' in out:
+        # the stored record keeps `roofline` and `config` whole and drops other top-level keys: what a reader of that
+        # record needs beside the headline goes in here, compact
+        r = out['roofline']
+        r['serial'] = [out['serial']['pairs_per_s'], out['serial']['ms_per_step']]          # [pairs/s, ms per step]
+        if exact_res is not None:
+            xr = out['exact_f32'].get('roofline') or {}
+            # the strict-fp32 build (v_mfma_f32_32x32x2_f32 products): [pairs/s overlapped, pairs/s serial, frac of the 157.3-TFLOP/s fp32 MFMA peak]
+            r['exact_f32'] = [out['exact_f32']['pairs_per_s'], out['exact_f32']['serial_pairs_per_s'], xr.get('frac')]
+        if CALIB.get('f16_sustained'):
+            pw = CALIB.get('f16_sustained_power') or {}
+            r['sustained_f16_mfma_measured'] = {'tflops': round(CALIB['f16_sustained'], 1),
+                                                'socket_w_cap_w_sclk_mhz': [pw.get('socket_w'), pw.get('cap_w'), pw.get('sclk_mhz')],
+                                                'how': 'oetr_debug_mfma_rate: every CU on back-to-back v_mfma_f32_32x32x16_f16 for 3 x 0.5 s '
+                                                       'in this run, rocm-smi beside it; nominal dense peak 2500'}
+        if rccl_w1 is not None:
+            r.setdefault('other_configs', {})['c1_rccl_world1'] = (
+                [rccl_w1['pairs_per_s'], rccl_w1['serial_pairs_per_s'], rccl_w1['pairs_per_s_no_group_same_region'],
+                 rccl_w1['librccl_mapped']] if 'error' not in rccl_w1 else rccl_w1)
+    if rccl_w1 is not None:
+        out['rccl_world1'] = rccl_w1
     if not args.no_cpu_baseline and world == 1:   # host-core baseline: rank 0 at N=1 only
         base, ref_boxes = cpu_baseline(weights, feat1, feat2, args.size, size2)
         out['cpu_baseline'] = base
@@ -1030,12 +1144,12 @@ def main():
                             return [v['pairs_per_s'], r.get('frac'), r.get('avg_launch_us'), v['serial_pairs_per_s']]
                     return None
                 # [pairs/s overlapped, frac of the dominant kernel's roof, its average launch us, pairs/s serial]
-                out['roofline']['other_configs'] = {
+                out['roofline'].setdefault('other_configs', {}).update({
                     'c3_32p_1024': compact('configs[3] 32 pairs @1024x1024, auto'),
                     'c3_32p_1024_tile32': compact('configs[3] 32 pairs @1024x1024, 32-row'),
                     'c4_8p_640v1280': compact('configs[4] share: 8 pairs 640x640 vs 1280x1280, default'),
                     'c4_policy': compact('configs[4] share: 8 pairs 640x640 vs 1280x1280, precision policy'),
-                    'c2_policy': compact('configs[2] share')}
+                    'c2_policy': compact('configs[2] share')})
         except Exception as e:
             out['other_configs_error'] = repr(e)[:300]
     if use_pg:

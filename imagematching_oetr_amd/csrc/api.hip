@@ -1446,6 +1446,23 @@ oetr_status oetr_debug_decoder_fault(oetr_handle h, int on) {
   return OETR_OK;
 }
 
+oetr_status oetr_debug_mfma_rate(int device, double seconds, double* tflops, void* stream) {
+  if (!tflops || !(seconds > 0.0) || seconds > 30.0)
+    return fail(OETR_ERR_BAD_ARG, "oetr_debug_mfma_rate: NULL output or seconds outside (0, 30]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+    return fail(OETR_ERR_NO_DEVICE, "no HIP device " + std::to_string(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = measure_mfma_rate(prop.multiProcessorCount, seconds, tflops, static_cast<hipStream_t>(stream));
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) return hip_fail(e, "oetr_debug_mfma_rate");
+  return OETR_OK;
+}
+
 oetr_status oetr_set_state_prereduce(oetr_handle h, int on) {
   if (!h) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: NULL handle");
   if (on < -1 || on > 1) return fail(OETR_ERR_BAD_ARG, "oetr_set_state_prereduce: -1 (auto), 0 (off) or 1 (a reduction launch between the encoder launches)");

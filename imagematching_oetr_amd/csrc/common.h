@@ -1355,6 +1355,9 @@ hipError_t launch_neck_conv(const NeckConvLaunch& p, hipStream_t s);
 int neck_conv_rows(int M, int items_per_mt, int num_cus, int max_rows);
 hipError_t launch_neck_out(const NeckOutLaunch& p, hipStream_t s);
 
+// calib.hip (oetr_debug_mfma_rate): dense f16 MFMA rate the chip sustains, TFLOP/s; synchronises `s`
+hipError_t measure_mfma_rate(int num_cus, double seconds, double* tflops, hipStream_t s);
+
 hipError_t launch_linear_attention(const float* q, const float* k, const float* v, const float* q_mask,
                                    const float* kv_mask, int n, int L, int S, float* out, float* state,
                                    hipStream_t s);

@@ -551,7 +551,15 @@ __device__ __forceinline__ void decoder_body4(const DecLaunch& p, int img, int j
   // publish anything: workgroup 0 may have advanced the image's call counter by then, and granules
   // tagged counter + 1 would be taken for the NEXT call's.  The call's outputs are invalid either
   // way; the host re-zeroes the status block before it submits again (hip_engine.py: settle_exchange).
-  if (__hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_EXCHANGE) return;
+  // (ONE lane reads the word and the workgroup decides together: per-thread loads could straddle a
+  //  peer's atomicOr - part of the workgroup gone, the rest publishing under the tag.  smem[M::VEC]
+  //  is free here; the barrier behind the read also fences it against the first stage's writes.)
+  if (threadIdx.x == 0)
+    smem[M::VEC] = __builtin_bit_cast(float, __hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();
+  const bool late = (__builtin_bit_cast(uint32_t, smem[M::VEC]) & FLAG_EXCHANGE) != 0;
+  __syncthreads();
+  if (late) return;
   const unsigned tag = __hip_atomic_load(p.xch_epoch + img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;   // never 0; workgroup 0 stores it back at the end
   bool dead = false;
 

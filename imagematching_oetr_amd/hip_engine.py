@@ -90,7 +90,7 @@ EXPORTS = (
     'oetr_forward_masked', 'oetr_feature_correlation_masked', 'oetr_center_estimation_masked',
     'oetr_linear_attention_masked', 'oetr_debug_decoder_fault',
     'oetr_flagslot_device_pointer', 'oetr_forward_flagslot', 'oetr_forward_tokens_flagslot',
-    'oetr_neck_forward_tokens_status')
+    'oetr_neck_forward_tokens_status', 'oetr_debug_mfma_rate')
 
 FLAG_F16_RANGE = 1   # OETR_FLAG_F16_RANGE
 FLAG_EXCHANGE = 2    # OETR_FLAG_EXCHANGE: the split decoder's workgroups were not resident together
@@ -257,6 +257,8 @@ def load_library(path=None):
     lib.oetr_forward_flagslot.argtypes = fwd[:5] + [vp, vp] + fwd[5:] + [vp, vp]       # ..., flag_slot, stream
     lib.oetr_forward_tokens_flagslot.restype = i
     lib.oetr_forward_tokens_flagslot.argtypes = [vp, i, i, i, i, i, i, i, i, i, vp, sz, vp, vp, vp, vp]
+    lib.oetr_debug_mfma_rate.restype = i
+    lib.oetr_debug_mfma_rate.argtypes = [i, C.c_double, C.POINTER(C.c_double), vp]
     lib.oetr_neck_forward_tokens_status.restype = i
     lib.oetr_neck_forward_tokens_status.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp, vp]
     lib.oetr_overlap_crop_capacity.restype = sz
@@ -1024,7 +1026,7 @@ class NeckEngine:
                 _check(self.lib, self.lib.oetr_neck_forward_tokens_status(
                     self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
                     tokens_out.data_ptr(), status_word.data_ptr(), _stream(self.device)),
-                    'oetr_neck_forward_tokens_status')
+                    'oetr_neck_forward_tokens_status', 'oetr_debug_mfma_rate')
                 return tokens_out
             _check(self.lib, self.lib.oetr_neck_forward_tokens(
                 self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
@@ -1104,6 +1106,18 @@ class KernelTrace:
                 self.lib.oetr_trace_destroy(t)
             except Exception:
                 pass
+
+
+def sustained_mfma_tflops(device, seconds=1.0):
+    """``oetr_debug_mfma_rate``: the dense f16 MFMA rate (TFLOP/s) ``device`` sustains right now -
+    about ``seconds`` of back-to-back MFMAs on every CU (measurements only; synchronises)."""
+    device = torch.device(device)
+    lib = load_library()
+    out = C.c_double(0.0)
+    with torch.cuda.device(device):
+        _check(lib, lib.oetr_debug_mfma_rate(device.index or 0, float(seconds), C.byref(out), _stream(device)),
+               'oetr_debug_mfma_rate')
+    return float(out.value)
 
 
 def box_tlbr_to_xyxy(cxy, tlbr, max_h, max_w):

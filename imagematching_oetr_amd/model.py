@@ -408,7 +408,10 @@ class OETR(nn.Module):
         (box1, box2), each [N,4] xyxy pixels.  ``mask1`` / ``mask2`` [N,hf,wf]: the
         reference's optional masks at the token grid's resolution (padded batches)."""
         masked = self._check_masks(mask1, mask2)
-        self._settle_down_to(max(1, int(self.hip_streams)) - 1)   # the deferred checks of earlier batches, oldest first
+        # the deferred checks of earlier batches, oldest first - the same count _submit keeps in flight
+        # (latency mode: ONE batch stays behind the one being submitted, the host never waits for the device)
+        k = self._stream_count()
+        self._settle_down_to(k - 1 if k > 1 else (1 if self.hip_defer_check else 0))
         h1, w1 = image1.shape[1:3]
         h2, w2 = image2.shape[1:3]
         self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
@@ -470,6 +473,17 @@ class OETR(nn.Module):
         return self._submit(enqueue, rerun if checked else None, [bb1, bb2] if both is None else [both])
 
     # -------------------------------------- submission, deferred range check
+    #: the status-word ring of an engine holds 16 words (hip_engine._FlagReader.SLOTS), the automatic decoder
+    #: rule assumes at most four forwards in flight, and the HIP runtime carries four streams without sharing
+    #: a hardware queue: more than eight in flight has no use and would overrun the ring
+    MAX_STREAMS = 8
+
+    def _stream_count(self):
+        k = int(self.hip_streams)
+        if not 1 <= k <= self.MAX_STREAMS:
+            raise ValueError(f'hip_streams must be in 1..{self.MAX_STREAMS}, got {self.hip_streams}')
+        return k
+
     def _streams(self, k):
         dev = self.engine().device
         while len(self._side_streams) < k:
@@ -482,7 +496,7 @@ class OETR(nn.Module):
         deferred check of the previous batch.  ``hip_streams`` = k > 1: on side stream (batch index
         mod k), which first waits for the caller's stream (the batch's inputs); at most k batches
         stay in flight, their checks are settled oldest first.  ``rerun`` None: nothing to check."""
-        k = max(1, int(self.hip_streams))
+        k = self._stream_count()
         capturing = torch.cuda.is_current_stream_capturing()
         if k == 1 or capturing:
             # one batch stays in flight behind the one being submitted (its status word is still on
@@ -510,6 +524,13 @@ class OETR(nn.Module):
         if not self.hip_defer_check:
             self._settle_down_to(0)
         return boxes
+
+    def hip_settled(self, boxes):
+        """True once the deferred check of the batch that returned ``boxes`` (either of its two
+        tensors) has been settled - its values are final (``parallel.BoxGatherer(model=...)``
+        issues a batch's all-gather only then).  Batches settle oldest first: when k more have
+        been submitted (``hip_streams = k``; two in the latency mode) or at ``hip_flush()``."""
+        return not any(boxes is e[0][0] or boxes is e[0][1] for e in self._inflight)
 
     def hip_batch_stream(self):
         """The HIP stream the most recently submitted batch was enqueued on (throughput mode:

@@ -82,19 +82,30 @@ class BoxGatherer:
     batch k is issued asynchronously (RCCL's own stream) and completed when
     batch k+1 is submitted, so the latency-bound gather runs under the next
     batch's compute.  ``submit`` returns the gathered boxes of
-    the PREVIOUS batch (None the first time); ``flush`` returns the last one.
+    the OLDEST batch whose collective was issued by an earlier call (None while there is
+    none); ``flush`` issues and completes everything outstanding and returns the LAST
+    batch's boxes (``flush_all``: every outstanding batch's, in submission order).
 
     ``submit(box1, box2)``: every rank holds the same number of pairs (the bench's weak
     scaling).  ``submit(box1, box2, n_pairs=N)``: the ranks hold the contiguous
     ``shard_bounds`` slices of N pairs (sizes differ by at most one); shards are padded to
     the largest and the padding dropped after the gather, like ``gather_boxes``.
 
-    The gather copies VALUES: boxes that come from ``OETR.forward_dummy`` with the deferred
-    range check (``hip_defer_check``, the default) must be settled first - call
-    ``model.hip_flush()`` before ``submit`` (or pass ``settle=model.hip_flush``), otherwise
-    a batch that is corrected in place afterwards leaves its stale boxes on the other ranks."""
+    The gather copies VALUES, and ``OETR.forward_dummy`` with the deferred range check
+    (``hip_defer_check``, the default) corrects a tripped batch IN PLACE later.  Three ways to
+    keep stale boxes off the other ranks:
 
-    def __init__(self, group=None, settle=None, on_stream=None):
+    * ``model=`` (the throughput recipe): the collective of a batch is ISSUED only once the
+      model has settled that batch (``OETR.hip_settled``) - i.e. at the ``submit`` that follows
+      the settling, k batches later under ``hip_streams = k``, or at ``flush``.  Every rank
+      submits and settles in the same order, so the collectives line up whatever tripped
+      where; the in-place correction is ordered before the collective (the model orders the
+      batch's side stream behind the caller's stream before it enqueues there again).
+    * ``settle=model.hip_flush``: settle before every ``submit`` (serialises the streams).
+    * neither: only valid with ``hip_on_overflow = 'ignore'`` or precisions without a range
+      guard, or when the caller has flushed the model itself."""
+
+    def __init__(self, group=None, settle=None, on_stream=None, model=None):
         """``on_stream``: False = the collective is asynchronous (the process group's own stream) and
         completed at the next ``submit`` - right for ONE stream of batches (latency mode), where it runs
         under the next batch's kernels.  True = a blocking collective, ordered behind the batch on the
@@ -104,21 +115,28 @@ class BoxGatherer:
         runtime's default of four hardware queues carries without sharing (measured, MI355X, world 1:
         32.5 k pairs/s without a gather, 32.3 k with the on-stream one, 14.9 k with the asynchronous one -
         two streams on one queue serialise; `profiles/r5_pg_streams.txt`).  None (default) = True when
-        ``submit`` is called from a stream other than the device's default stream."""
+        ``submit`` is called from a stream other than the device's default stream.
+
+        The gathered tensors are ordered on the stream ``submit`` / ``flush`` ran on when it handed
+        them out (that stream waited for the collective, and the buffer is recorded on it): consume
+        them there, or order your stream behind that one."""
         self.settle = settle
         self.group = group
         self.on_stream = on_stream
-        self._pending = None
+        self.model = model
+        self._waiting = []        # submitted, collective not issued yet (model has not settled them)
+        self._issued = []         # (work, everyone, n_pairs, keep), oldest first
 
-    def _finish(self):
-        if self._pending is None:
-            return None
-        work, everyone, n_pairs, keep = self._pending
-        self._pending = None
+    def _finish(self, entry):
+        work, everyone, n_pairs, keep = entry
         if isinstance(work, torch.cuda.Event):                 # on-stream collective: order the consumer behind it
-            torch.cuda.current_stream(everyone.device).wait_event(work)
+            cur = torch.cuda.current_stream(everyone.device)
+            cur.wait_event(work)
+            everyone.record_stream(cur)                        # allocated on the submitting (side) stream, read here
         elif work is not None:
             work.wait()
+            if everyone.is_cuda:
+                everyone.record_stream(torch.cuda.current_stream(everyone.device))
         if keep is not None:                                   # unequal shards: drop the padding
             everyone = everyone.index_select(0, keep.to(everyone.device))
             return everyone[:, 0].contiguous(), everyone[:, 1].contiguous()
@@ -137,25 +155,18 @@ class BoxGatherer:
         done.record(torch.cuda.current_stream(out.device))
         return done
 
-    def submit(self, box1, box2, n_pairs=None):
-        if self.settle is not None:
-            self.settle()
-        done = self._finish()
+    def _issue(self, box1, box2, n_pairs):
         world = dist.get_world_size(self.group)
         if n_pairs is None or n_pairs % world == 0:
-            if n_pairs is not None and box1.shape[0] * world != n_pairs:
-                raise ValueError(f'this rank holds {box1.shape[0]} pairs, expected {n_pairs // world}')
             mine = _adjacent(box1, box2)                              # [2, n_local, 4]
             flat = torch.empty((world * 2,) + tuple(mine.shape[1:]), dtype=mine.dtype,
                                device=mine.device)             # concatenation along dim 0
             work = self._collective(flat, mine)
-            self._pending = (work, flat.view((world, 2) + tuple(mine.shape[1:])),
-                             world * box1.shape[0], None)
-            return done
+            self._issued.append((work, flat.view((world, 2) + tuple(mine.shape[1:])),
+                                 world * box1.shape[0], None))
+            return
         rank = dist.get_rank(self.group)
         lo, hi = shard_bounds(n_pairs, rank, world)
-        if box1.shape[0] != hi - lo or box2.shape[0] != hi - lo:
-            raise ValueError(f'rank {rank} holds {box1.shape[0]} pairs, expected {hi - lo} of {n_pairs}')
         cap = -(-n_pairs // world)
         mine = torch.zeros(cap, 2, 4, dtype=box1.dtype, device=box1.device)
         mine[:hi - lo, 0] = box1
@@ -164,11 +175,47 @@ class BoxGatherer:
         work = self._collective(everyone, mine)
         sizes = [shard_bounds(n_pairs, r, world) for r in range(world)]
         keep = torch.cat([torch.arange(r * cap, r * cap + (b - a)) for r, (a, b) in enumerate(sizes)])
-        self._pending = (work, everyone, n_pairs, keep)
+        self._issued.append((work, everyone, n_pairs, keep))
+
+    def _issue_ready(self, everything=False):
+        """Issue the collectives of the waiting batches the model has settled, oldest first."""
+        while self._waiting:
+            box1, box2, n_pairs = self._waiting[0]
+            if not everything and self.model is not None and not self.model.hip_settled(box1):
+                break
+            self._waiting.pop(0)
+            self._issue(box1, box2, n_pairs)
+
+    def submit(self, box1, box2, n_pairs=None):
+        if self.settle is not None:
+            self.settle()
+        world = dist.get_world_size(self.group)
+        if n_pairs is None or n_pairs % world == 0:
+            if n_pairs is not None and box1.shape[0] * world != n_pairs:
+                raise ValueError(f'this rank holds {box1.shape[0]} pairs, expected {n_pairs // world}')
+        else:
+            rank = dist.get_rank(self.group)
+            lo, hi = shard_bounds(n_pairs, rank, world)
+            if box1.shape[0] != hi - lo or box2.shape[0] != hi - lo:
+                raise ValueError(f'rank {rank} holds {box1.shape[0]} pairs, expected {hi - lo} of {n_pairs}')
+        done = self._finish(self._issued.pop(0)) if self._issued else None   # issued by an earlier call
+        self._waiting.append((box1, box2, n_pairs))
+        self._issue_ready()
         return done
 
+    def flush_all(self):
+        """Settle (``model.hip_flush`` when a model was given), issue and complete everything
+        outstanding: the gathered ``(box1, box2)`` of every batch not handed out yet, oldest first."""
+        if self.model is not None:
+            self.model.hip_flush()
+        self._issue_ready(everything=True)
+        out = [self._finish(e) for e in self._issued]
+        self._issued = []
+        return out
+
     def flush(self):
-        return self._finish()
+        out = self.flush_all()
+        return out[-1] if out else None
 
 
 @torch.no_grad()

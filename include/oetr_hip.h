@@ -48,7 +48,8 @@ extern "C" {
  *    further and the caller re-initialises the status block (OETR_FLAG_EXCHANGE below)
  * 6: the status word is PUBLISHED BY THE LAST KERNEL of a forward call instead of by two runtime
  *    dispatches behind it: oetr_flagslot_device_pointer, oetr_forward_flagslot,
- *    oetr_forward_tokens_flagslot, oetr_neck_forward_tokens_status (new exports; nothing else changed) */
+ *    oetr_forward_tokens_flagslot, oetr_neck_forward_tokens_status; oetr_debug_mfma_rate (measurements only)
+ *    (new exports; nothing else changed) */
 #define OETR_ABI_VERSION 6
 #define OETR_D_MODEL 256
 #define OETR_N_HEAD 8
@@ -287,6 +288,13 @@ oetr_status oetr_set_decoder_split(oetr_handle h, int workgroups_per_image);
  * (status-block reset, re-run on one workgroup per image) deterministically.  One shot: the
  * call after that is normal again.  `on` = 0 withdraws a pending fault. */
 oetr_status oetr_debug_decoder_fault(oetr_handle h, int on);
+
+/* Measurements only (ABI 6; bench.py): the dense f16 MFMA rate `device` SUSTAINS right now - every CU on
+ * back-to-back v_mfma_f32_32x32x16_f16 with pseudo-random operands for about `seconds` (first half
+ * settles the power controller, second half is counted), in TFLOP/s.  MI355X reaches its socket power
+ * cap on this loop, so the figure is what a power-bound kernel could reach on this box at this moment,
+ * as opposed to the nominal 2 500 TFLOP/s.  Allocates nothing; SYNCHRONISES `stream`. */
+oetr_status oetr_debug_mfma_rate(int device, double seconds, double *tflops, void *stream);
 
 /* Attention core of the eight encoder layers.  The reference builds
  * QueryTransformer(attention_mode='linear') (src/model.py:82-84; the config knob

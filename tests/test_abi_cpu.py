@@ -23,7 +23,7 @@ def header_functions():
 def test_library_exports_every_declared_symbol():
     lib = pkg.load_library()
     names = header_functions()
-    assert len(names) == 52, names
+    assert len(names) == 53, names
     assert set(names) == set(hip_engine.EXPORTS)
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/oetr_hip.h but not exported'
@@ -105,6 +105,7 @@ def test_null_arguments_are_rejected_not_crashed():
     assert b'status_word' in lib.oetr_last_error()
     out = ctypes.c_void_p()
     assert lib.oetr_flagslot_device_pointer(None, ctypes.byref(out)) == 1
+    assert lib.oetr_debug_mfma_rate(0, 1.0, None, None) == 1
 
 
 def test_product_path_has_no_cpu_fallback():

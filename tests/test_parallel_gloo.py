@@ -113,6 +113,79 @@ def test_pipelined_box_gatherer_world2_gloo(on_stream):
         assert outs == [[0.0, 0.0, 1.0, 1.0], [10.0, 10.0, 11.0, 11.0], [20.0, 20.0, 21.0, 21.0]]
 
 
+class _DeferringModel:
+    """The part of ``OETR`` the gatherer talks to, with the deferred check's behaviour: ``batch()``
+    returns box tensors that hold garbage if the batch "tripped" and are corrected IN PLACE when the
+    batch is settled - oldest first, once ``keep`` newer batches are in flight, or at ``hip_flush()``."""
+
+    def __init__(self, keep):
+        self.keep, self._inflight = keep, []
+
+    def _settle_down_to(self, keep):
+        while len(self._inflight) > keep:
+            boxes, good = self._inflight.pop(0)
+            for t, g in zip(boxes, good):
+                t.copy_(g)
+
+    def batch(self, good1, good2, tripped):
+        self._settle_down_to(self.keep - 1)
+        out = (torch.full_like(good1, 7.0e4), torch.full_like(good2, 7.0e4)) if tripped \
+            else (good1.clone(), good2.clone())
+        self._inflight.append((out, (good1, good2)))
+        return out
+
+    def hip_settled(self, boxes):
+        return not any(boxes is e[0][0] or boxes is e[0][1] for e in self._inflight)
+
+    def hip_flush(self):
+        self._settle_down_to(0)
+
+
+def _deferred_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from imagematching_oetr_amd.parallel import BoxGatherer
+        model = _DeferringModel(keep=3)                  # hip_streams = 3
+        g = BoxGatherer(model=model)
+        outs, issued_at = [], []
+        for k in range(7):                               # seven batches of 2 pairs per rank
+            good = torch.full((2, 4), float(10 * k + rank))
+            b1, b2 = model.batch(good, -good, tripped=(rank == 1 and k in (1, 4)))   # rank 1 trips twice, rank 0 never
+            done = g.submit(b1, b2)
+            issued_at.append(len(g._waiting))
+            if done is not None:
+                outs.append((done[0][:, 0].tolist(), done[1][:, 0].tolist()))
+        outs += [(d[0][:, 0].tolist(), d[1][:, 0].tolist()) for d in g.flush_all()]
+        assert g.flush() is None and not g._waiting and not g._issued
+        q.put((rank, outs, issued_at))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gatherer_issues_a_batch_only_once_the_model_has_settled_it_world2_gloo():
+    """ADVICE r5: under the deferred check a tripped batch is corrected in place AFTER it was returned;
+    ``BoxGatherer(model=...)`` holds a batch's collective back until the model has settled it, so no
+    rank ever receives the stale boxes - and since every rank submits and settles in the same order the
+    collectives line up although only rank 1 trips."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_deferred_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, waiting in results:
+        assert len(outs) == 7, rank
+        for k, (o1, o2) in enumerate(outs):              # [rank 0's 2 pairs, rank 1's 2 pairs], settled values
+            assert o1 == [10.0 * k, 10.0 * k, 10.0 * k + 1, 10.0 * k + 1], (rank, k, o1)
+            assert o2 == [-v for v in o1], (rank, k)
+        assert waiting == [1, 2, 3, 3, 3, 3, 3], (rank, waiting)   # three batches stay back: the ones in flight
+
+
 def _unequal_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
