@@ -529,6 +529,8 @@ def other_configs(args, device, pkg):
         ('configs[4] share: 8 pairs 640x640 vs 1280x1280, default precision', 8, 640, 1280, 'f32_split_f16', 0, 16),
         ('configs[4] share: 8 pairs 640x640 vs 1280x1280, precision policy', 8, 640, 1280, 'f32_split_qk16', 0, 16),
         ('configs[2] share: 8 pairs @640x640, precision policy', 8, 640, 640, 'f32_split_qk16', 0, 40),
+        # the literal "HW = 64x64 correlation volume" of configs[3] (SURVEY 8d "Config 4"): 4096 tokens per image
+        ('configs[3] literal 64x64 tokens: 4 pairs @2048x2048', 4, 2048, 2048, 'f32_split_f16', 0, 6),
     ]
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
@@ -588,6 +590,36 @@ def other_configs(args, device, pkg):
         if eng.precision in eng.F16_RANGE:
             rec['f16_range_flag'] = eng.query_flags()
         out[key] = rec
+    # the all-pairs kernel itself (reference FullAttention, linear_attention.py:53-87) at the same literal size:
+    # L = S = 4096, 8 images, 8 heads x 32 - softmax(QK^T / sqrt D) V, the 4096 x 4096 volume never materialised
+    try:
+        g = torch.Generator().manual_seed(5)
+        fq = ((torch.rand(8, 4096, 8, 32, generator=g) - 0.5) * 4).to(device)
+        fk = ((torch.rand(8, 4096, 8, 32, generator=g) - 0.5) * 4).to(device)
+        fv = ((torch.rand(8, 4096, 8, 32, generator=g) - 0.5) * 2).to(device)
+        for _ in range(2):
+            pkg.full_attention(fq, fk, fv, variant='f32_split_f16')
+        times = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(4):
+                pkg.full_attention(fq, fk, fv, variant='f32_split_f16')
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / 4)
+        ms = statistics.median(times)
+        flop = 4.0 * 8 * 8 * 4096 * 4096 * 32
+        cost, pipe_peak, basis = MFMA_COST['f32_split_f16']
+        out['full_attention L=S=4096, 8 images'] = {
+            'kernel': 'k_full_attention_split [f32_split_f16]', 'avg_launch_us': round(ms * 1e3, 1),
+            'achieved': round(flop / ms / 1e9, 1), 'peak': round(pipe_peak / cost, 1), 'unit': 'TFLOP/s',
+            'frac': round(flop / ms / 1e9 / (pipe_peak / cost), 4), 'bound': 'mfma', 'peak_basis': basis,
+            'flop_per_launch': flop, 'timing': 'median of 5 regions of 4 launches, HIP events around each region'}
+        del fq, fk, fv
+    except Exception as e:
+        out['full_attention L=S=4096, 8 images'] = {'error': repr(e)[:200]}
     out['_seconds'] = round(time.perf_counter() - t_start, 1)
     out['_note'] = ('each entry: median of 5 regions of `steps` steps, batches alternating over `streams` HIP streams '
                     '(64-row encoder tiles unless forced), `serial_pairs_per_s` = the same steps on one stream; '
@@ -1149,7 +1181,12 @@ def main():
                     'c3_32p_1024_tile32': compact('configs[3] 32 pairs @1024x1024, 32-row'),
                     'c4_8p_640v1280': compact('configs[4] share: 8 pairs 640x640 vs 1280x1280, default'),
                     'c4_policy': compact('configs[4] share: 8 pairs 640x640 vs 1280x1280, precision policy'),
-                    'c2_policy': compact('configs[2] share')})
+                    'c2_policy': compact('configs[2] share'),
+                    'c3_4p_2048': compact('configs[3] literal 64x64 tokens')})
+                fa = oc.get('full_attention L=S=4096, 8 images') or {}
+                # [TFLOP/s algorithmic, frac of the 3-MFMA split roof, launch us]
+                out['roofline']['other_configs']['full_attention_L4096'] = (
+                    [fa.get('achieved'), fa.get('frac'), fa.get('avg_launch_us')] if 'error' not in fa else fa)
         except Exception as e:
             out['other_configs_error'] = repr(e)[:300]
     if use_pg:

@@ -177,137 +177,302 @@ hipError_t launch_full_attention(const float* q, const float* k, const float* v,
 // (a = hi + lo/2^11, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation): 12
 // MFMAs of 32 cycles per 32x32 score tile instead of 32 f32 MFMAs of 64 cycles.
 //
-// One block = (image, head, 128 queries), 4 waves x 32 queries.  Per 32-key tile the
-// block converts K and V once into split planes in LDS (K row-major, V transposed with
-// the key order the MFMA k-slots want), then every wave computes, with NO lane
-// exchange at all:
+// One block = (image, head, 256 queries), 8 waves x 32 queries.  Per 64-key tile the block
+// converts K and V once into split planes in LDS (K row-major, V transposed with the key
+// order the MFMA k-slots want; a ring of three buffers: tile t + 2 is loaded under step t's math
+// and written behind it, ONE barrier per tile), then every wave computes, with no lane exchange
+// beyond one cross-half maximum per tile:
 //   S^T = K . Q^T      A = K fragments (LDS),  B = Q (registers, split once)
-//   P   = exp(S^T/sqrt(D) - m)  in the lane that owns the query column
+//   P   = 2^(S^T - m)  in the lane that owns the query column
 //   O^T += V^T . P^T   A = V^T fragments (LDS), B = P straight from the S^T accumulator
 //                      registers (k-slot 8*half + i of step s <-> key crow(8s+i, half))
 // O^T keeps the query in the lane, so the online-softmax rescale and the final 1/l are
 // per-lane scalars.  The L x S score volume exists only in accumulators.
-constexpr int FA_PITCH = 40;   // halves per LDS row (32 + 8): conflict-free ds_read_b128
+//
+// Round 6 (0.19 of the split roof at L = S = 4096; the kernel was VALU-bound,
+// ~20 VALU issue slots per score element beside 0.75 MFMA): what a score element costs now -
+//   * 1/sqrt(D) and log2(e) are folded into Q before its split, scores arrive in log2 units:
+//     P = v_exp_f32(s - m), one subtract and one transcendental (was: multiply, select, the
+//     6-instruction compensated exp and two clamps);
+//   * keys past S are masked in the LAST tile only (a wave-uniform branch);
+//   * the running maximum is exact, but O, its cross accumulator and l are rescaled only in tiles
+//     where some lane's maximum moved (wave-uniform ballot; after the first few tiles it rarely does);
+//   * the cross accumulator of P.V (the 2^-11-scaled half of the split product) runs across tiles and
+//     is folded into O once at the end instead of once per tile;
+//   * the row sum l stays a per-lane partial (its two half-lanes are added once at the end).
+// P is still split into two planes (hi + lo/2^11) like every other operand: a single f16 plane
+// for P (VERDICT r5's suggestion) was measured first - 3e-5 .. 8e-5 against the fp64 oracle where the
+// goldens allow 5e-6, for 13 % of launch time (profiles/r6_full_attention_p1plane.txt; the
+// -DOETR_FA_P1PLANE build keeps the experiment reproducible).
+constexpr int FA_KT = 64;            // keys per tile
+constexpr int FA_KP = 40;            // halves per K row (32 d + 8): conflict-free ds_read_b128
+constexpr int FA_VP = FA_KT + 8;     // halves per V^T row (64 key slots + 8): 9 x 16 B, conflict-free
+#ifndef OETR_FA_WAVES
+#define OETR_FA_WAVES 8
+#endif
+constexpr int FA_WAVES = OETR_FA_WAVES;   // waves per workgroup, 32 queries each
+struct FaTile {
+  _Float16 Kh[FA_KT * FA_KP], Kl[FA_KT * FA_KP];
+  _Float16 Vh[HD * FA_VP], Vl[HD * FA_VP];   // [d][key slot]
+};
 
-__global__ __launch_bounds__(256) void k_full_attention_split(const float* __restrict__ q,
-                                                              const float* __restrict__ k,
-                                                              const float* __restrict__ v,
-                                                              int L, int S, float* __restrict__ out,
-                                                              uint32_t* flags) {
-  __shared__ __attribute__((aligned(16))) _Float16 Kh[32 * FA_PITCH], Kl[32 * FA_PITCH];
-  __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * FA_PITCH], Vl[32 * FA_PITCH];  // [d][slot]
+__global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const float* __restrict__ q,
+                                                                        const float* __restrict__ k,
+                                                                        const float* __restrict__ v,
+                                                                        int L, int S, float* __restrict__ out,
+                                                                        uint32_t* flags) {
+  __shared__ __attribute__((aligned(16))) FaTile ring[3];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, col = lane & 31;
-  const int qchunks = (L + 127) / 128;
+  constexpr int QB = 32 * FA_WAVES;
+  const int qchunks = (L + QB - 1) / QB;
   const int qc = blockIdx.x % qchunks, nh = blockIdx.x / qchunks, n = nh / NH, h = nh % NH;
-  const int q0 = qc * 128 + wave * 32;
-  const float temp = 1.0f / sqrtf((float)HD);
+  const int q0 = qc * QB + wave * 32;
+  const bool active = q0 < L;      // (wave-uniform: a wave past the image end only helps staging)
   Range rg;
 
-  // Q as the B operand of S^T = K Q^T: lane (query = col) holds d = 16s + 8*half + 0..7
+  // Q as the B operand of S^T = K Q^T: lane (query = col) holds d = 16s + 8*half + 0..7, already
+  // multiplied by 1/sqrt(D) * log2(e) - the scores come out of the MFMAs in log2 units
+  const float qs = 0.17677669529663687f * 1.4426950408889634f;
   f32x4 qh[2], ql[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
     if (q0 + col < L) {
       const float* qp = q + (((size_t)n * L + q0 + col) * NH + h) * HD + 16 * s + 8 * half;
-      a0 = *reinterpret_cast<const f32x4*>(qp);
-      a1 = *reinterpret_cast<const f32x4*>(qp + 4);
+      a0 = *reinterpret_cast<const f32x4*>(qp) * qs;
+      a1 = *reinterpret_cast<const f32x4*>(qp + 4) * qs;
     }
     split8(a0, a1, qh[s], ql[s], rg);
   }
-  f32x16 o = {0};   // O^T: rows = d (crow(r, half)), col = query
-  // (masked scores and the initial maximum are a large FINITE negative: exp_neg - the
-  //  6-instruction exp of common.h, arguments <= 0 - would turn -inf into NaN)
+  f32x16 o = {0}, oc = {0};   // O^T and its 2^-11-scaled cross part: rows = d (crow(r, half)), col = query
+  // (masked scores and the initial maximum are a large FINITE negative: no inf - inf anywhere)
   constexpr float NEG = -1.0e30f;
-  float m_run = NEG, l_run = 0.f;
+  float m_run = 0.f, l_run = 0.f;   // m: the reference the score accumulators start from (`maximum` below)
 
-  // staging role: thread -> (key row = tid >> 3, 4 consecutive d = 4 * (tid & 7))
-  const int srow = tid >> 3, sd = 4 * (tid & 7);
-  // position of key `srow` in the k-slot order of the P.V contraction: swap bits 2 and 3
-  const int spos = (srow & ~12) | ((srow & 4) << 1) | ((srow & 8) >> 1);
-  auto load_kv = [&](int k0, f32x4& kk, f32x4& vv) {
-    kk = f32x4{0.f, 0.f, 0.f, 0.f};
-    vv = kk;
-    if (k0 + srow < S) {
-      const size_t off = (((size_t)n * S + k0 + srow) * NH + h) * HD + sd;
-      kk = *reinterpret_cast<const f32x4*>(k + off);
-      vv = *reinterpret_cast<const f32x4*>(v + off);
+  // staging roles.  K: thread -> (key row = tid >> 3, 4 consecutive d = 4 * (tid & 7)), one 16-byte load.
+  // V: thread -> (d = tid & 31, keys 4g .. 4g + 3, g = tid >> 5): four 4-byte loads (a half-wave reads the 128
+  // contiguous bytes of one key), ONE 8-byte store per plane - the four keys are consecutive k-slots of the
+  // P.V contraction: key 16u + 8a + 4b + c sits in slot 16u + 8b + 4a + c (bits 2 and 3 of the key swapped)
+  // (512 such items of each kind per tile: FA_ITEMS per thread)
+  constexpr int FA_ITEMS = 512 / (64 * FA_WAVES);
+  f32x4 kreg[FA_ITEMS], vreg[FA_ITEMS];
+  auto load_tile = [&](int k0) {
+    const size_t base = ((size_t)n * S) * NH * HD + h * HD;
+#pragma unroll
+    for (int it = 0; it < FA_ITEMS; ++it) {
+      const int item = tid + 64 * FA_WAVES * it;
+      const int kr = item >> 3, kd = 4 * (item & 7), vd = item & 31, vg = item >> 5;
+      kreg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vreg[it] = kreg[it];
+      if (k0 + kr < S) kreg[it] = *reinterpret_cast<const f32x4*>(k + base + (size_t)(k0 + kr) * (NH * HD) + kd);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (k0 + 4 * vg + b < S) vreg[it][b] = v[base + (size_t)(k0 + 4 * vg + b) * (NH * HD) + vd];
     }
   };
-  f32x4 kreg, vreg;
-  load_kv(0, kreg, vreg);
-  for (int k0 = 0; k0 < S; k0 += 32) {
-    __syncthreads();   // every wave is done with the previous tile's planes
-    store_planes4<GM_SPLIT>(Kh + srow * FA_PITCH, Kl + srow * FA_PITCH, sd, kreg, rg);
-    {
-      uint32_t h0, l0, h1, l1;
-      cvt_planes2<GM_SPLIT>(vreg[0], vreg[1], h0, l0, rg);
-      cvt_planes2<GM_SPLIT>(vreg[2], vreg[3], h1, l1, rg);
-      uint16_t* vh = reinterpret_cast<uint16_t*>(Vh);
-      uint16_t* vl = reinterpret_cast<uint16_t*>(Vl);
-      vh[(sd + 0) * FA_PITCH + spos] = (uint16_t)h0; vh[(sd + 1) * FA_PITCH + spos] = (uint16_t)(h0 >> 16);
-      vh[(sd + 2) * FA_PITCH + spos] = (uint16_t)h1; vh[(sd + 3) * FA_PITCH + spos] = (uint16_t)(h1 >> 16);
-      vl[(sd + 0) * FA_PITCH + spos] = (uint16_t)l0; vl[(sd + 1) * FA_PITCH + spos] = (uint16_t)(l0 >> 16);
-      vl[(sd + 2) * FA_PITCH + spos] = (uint16_t)l1; vl[(sd + 3) * FA_PITCH + spos] = (uint16_t)(l1 >> 16);
-    }
-    if (k0 + 32 < S) load_kv(k0 + 32, kreg, vreg);   // next tile's rows under this tile's math
-    __syncthreads();
-
-    // S^T tile: rows = keys, cols = queries
-    f32x16 st = {0}, cr = {0};
+  auto write_tile = [&](FaTile& B) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const f32x4 ah = *reinterpret_cast<const f32x4*>(Kh + col * FA_PITCH + 16 * s + 8 * half);
-      const f32x4 al = *reinterpret_cast<const f32x4*>(Kl + col * FA_PITCH + 16 * s + 8 * half);
-      mma16_split3(ah, al, qh[s], ql[s], st, cr);
+    for (int it = 0; it < FA_ITEMS; ++it) {
+      const int item = tid + 64 * FA_WAVES * it;
+      const int kr = item >> 3, kd = 4 * (item & 7), vd = item & 31, vg = item >> 5;
+      const int vslot = 16 * (vg >> 2) + 8 * (vg & 1) + 4 * ((vg >> 1) & 1);
+      store_planes4<GM_SPLIT>(B.Kh + kr * FA_KP, B.Kl + kr * FA_KP, kd, kreg[it], rg);
+      uint32_t h0, l0, h1, l1;
+      cvt_planes2<GM_SPLIT>(vreg[it][0], vreg[it][1], h0, l0, rg);
+      cvt_planes2<GM_SPLIT>(vreg[it][2], vreg[it][3], h1, l1, rg);
+      *reinterpret_cast<u32x2*>(B.Vh + vd * FA_VP + vslot) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(B.Vl + vd * FA_VP + vslot) = u32x2{l0, l1};
+    }
+  };
+  // ---- the per-tile pieces -------------------------------------------------------------------------
+  // S^T tile of the keys in B: rows = keys (two 32-key halves), cols = queries; 12 MFMAs, operands from LDS
+  // and the Q registers only - independent of every VALU result, free to run beside the softmax of the
+  // tile before.  The accumulators enter holding -m (see `maximum`).
+  auto scores = [&](const FaTile& B, f32x16 (&sa)[2], f32x16 (&ca)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const f32x4 ah = *reinterpret_cast<const f32x4*>(B.Kh + (32 * j + col) * FA_KP + 16 * s + 8 * half);
+        const f32x4 al = *reinterpret_cast<const f32x4*>(B.Kl + (32 * j + col) * FA_KP + 16 * s + 8 * half);
+        mma16_split3<false>(ah, al, qh[s], ql[s], sa[j], ca[j]);
+      }
+  };
+  // The score accumulators START at -m (the lane's query's reference maximum as it stood when the tile's
+  // MFMAs were issued), so the fold below yields x = s - m directly.  m follows the true maximum LAZILY: it is
+  // raised - and O, its cross accumulator, l and this tile's x rescaled - only when some lane's tile maximum
+  // exceeds the reference by more than 2^FA_LAZY (wave-uniform ballot; rare after the first tile, which always
+  // sets the reference).  In between P = 2^x may exceed 1 - by at most 2^FA_LAZY = 256, far inside the f16
+  // range of its hi plane; the final 1/l removes the common factor exactly as it removes 2^-m.
+  constexpr float FA_LAZY = 8.0f;
+  auto maximum = [&](f32x16 (&sa)[2], const f32x16 (&ca)[2], int k0, auto tail_c, bool first) {
+    constexpr bool tail = decltype(tail_c)::value;   // (compile time: as a run-time flag hipcc if-converted the 96 compare / select / add
+                                                     //  instructions of the mask into EVERY tile's step - a third of its VALU work)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[j][r] = fmaf(ca[j][r], SPLIT_INV, sa[j][r]);
+    if constexpr (tail) {   // keys past S: only the last tile has any
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + 32 * j + crow(r, half) >= S) sa[j][r] = NEG;
     }
     float mt = NEG;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float sv = fmaf(cr[r], SPLIT_INV, st[r]);
-      st[r] = (k0 + crow(r, half) < S) ? sv * temp : NEG;
-      mt = fmaxf(mt, st[r]);
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mt = __builtin_fmaxf(__builtin_fmaxf(mt, sa[j][r]), sa[j][r + 1]);   // v_max3_f32
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = exp_neg(fminf(m_run - m_new, 0.f));  // 0 on the first tile
-    float ps = 0.f;
+    if (first || __builtin_amdgcn_ballot_w64(mt > FA_LAZY) != 0) {
+      const float adj = first ? mt : fmaxf(mt, 0.f);       // (first tile: the reference was 0, nothing accumulated yet)
+      if (!first) {
+        const float alpha = __builtin_amdgcn_exp2f(-adj);
+        l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { st[r] = exp_neg(fminf(st[r] - m_new, 0.f)); ps += st[r]; }
-    ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
+        for (int r = 0; r < 16; ++r) { o[r] *= alpha; oc[r] *= alpha; }
+      }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;   // this lane's query, all of its d rows
-    // O^T += V^T P^T
-    f32x16 oc = {0};
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x4 ph, pl;
-      split8(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]},
-             f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]}, ph, pl, rg);
-      const f32x4 ah = *reinterpret_cast<const f32x4*>(Vh + col * FA_PITCH + 16 * s + 8 * half);
-      const f32x4 al = *reinterpret_cast<const f32x4*>(Vl + col * FA_PITCH + 16 * s + 8 * half);
-      mma16_split3(ah, al, ph, pl, o, oc);
+        for (int r = 0; r < 16; ++r) sa[j][r] -= adj;
+      m_run += adj;
     }
+  };
+  // P = 2^x in place, its row-sum share, and its split planes: B operands of the P.V steps.
+  // The split is common.h's split2 with SCALAR multiplies: packed f32 VALU (v_pk_mul_f32 / v_pk_fma_f32, which
+  // split2 uses on purpose and hipcc's SLP pass forms from adjacent scalar ops - this file is built with
+  // -fno-slp-vectorize) costs ~22 cycles per instruction beside MFMAs on gfx950 (MI355X_MICROARCH.md), and here
+  // every one of them sits beside MFMAs.  (P <= 2^FA_LAZY: nothing for the range guard.)
+  auto probs = [&](f32x16 (&sa)[2], f32x4 (&ph)[4], f32x4 (&pl)[4]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = fmaf(oc[r], SPLIT_INV, o[r]);
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sa[j][r] = __builtin_amdgcn_exp2f(sa[j][r]);       // (x = s - m already: `maximum`)
+        l_run += sa[j][r];
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a = sa[j][8 * s + 2 * i], b = sa[j][8 * s + 2 * i + 1];
+          const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+          hi[i] = __builtin_bit_cast(uint32_t, h);
+          lo[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -SPLIT_SCALE, a * SPLIT_SCALE),
+                                                                         __builtin_fmaf((float)h[1], -SPLIT_SCALE, b * SPLIT_SCALE)));
+        }
+        ph[2 * j + s] = __builtin_bit_cast(f32x4, u32x4{hi[0], hi[1], hi[2], hi[3]});
+        pl[2 * j + s] = __builtin_bit_cast(f32x4, u32x4{lo[0], lo[1], lo[2], lo[3]});
+      }
+  };
+  // O^T += V^T P^T
+  auto apply = [&](const FaTile& B, const f32x4 (&ph)[4], const f32x4 (&pl)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 ah = *reinterpret_cast<const f32x4*>(B.Vh + col * FA_VP + 16 * ks + 8 * half);
+      const f32x4 al = *reinterpret_cast<const f32x4*>(B.Vl + col * FA_VP + 16 * ks + 8 * half);
+#ifdef OETR_FA_P1PLANE   // experiment (profiles/r6_full_attention_p1plane.txt): P as ONE f16 plane, V split
+      o = mma16<GM_SPLIT>(ah, ph[ks], o);
+      oc = mma16<GM_SPLIT>(al, ph[ks], oc);
+#else
+      mma16_split3<false>(ah, al, ph[ks], pl[ks], o, oc);
+#endif
+    }
+  };
+
+  // ---- software pipeline over the key tiles -----------------------------------------------------------
+  // Step t: [S^T of tile t + 1: 12 MFMAs] beside [P of tile t: exp / sum / split - VALU], then [P.V of tile t:
+  // 12 MFMAs] beside [cross fold and maximum of tile t + 1 - VALU]: the matrix pipe and the VALU of ONE wave
+  // overlap (before: every wave of the workgroup ran the same phase at the same time behind the tile's
+  // barrier, and the two waves of a SIMD queued for the same pipe).  Three LDS buffers: step t reads K of
+  // tile t + 1 and V of tile t while tile t + 2 is written; one barrier per step.  (The same pipeline at
+  // 32-key granularity - half the live accumulators - measured 8 % slower: 561 vs 518 us at L = S = 4096;
+  // forced to 128 VGPRs for two workgroups per CU it spills 205 registers.)
+  const int T = (S + FA_KT - 1) / FA_KT;
+  const bool ragged = (S % FA_KT) != 0;
+  load_tile(0);
+  write_tile(ring[0]);
+  if (T > 1) {
+    load_tile(FA_KT);
+    write_tile(ring[1]);
+  }
+  __syncthreads();
+  f32x16 sA[2] = {}, sB[2] = {};
+  if (active) {
+    f32x16 c0[2] = {};
+    scores(ring[0], sA, c0);
+    if (T == 1 && ragged) maximum(sA, c0, 0, std::true_type{}, true);
+    else maximum(sA, c0, 0, std::false_type{}, true);
+  }
+  auto step = [&](int t, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto tail_c) {   // t + 1 < T; tail_c: tile t + 1 is the ragged last one
+    if (t + 2 < T) load_tile((t + 2) * FA_KT);
+    if (active) {
+      const FaTile& BK = ring[(t + 1) % 3];
+      const FaTile& BV = ring[t % 3];
+      f32x16 cn[2] = {};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nxt[0][r] = nxt[1][r] = -m_run;
+      f32x4 ph[4], pl[4];
+      scores(BK, nxt, cn);
+      probs(cur, ph, pl);
+      apply(BV, ph, pl);
+      maximum(nxt, cn, (t + 1) * FA_KT, tail_c, false);
+    }
+    if (t + 2 < T) write_tile(ring[(t + 2) % 3]);
+    __syncthreads();
+  };
+  auto last = [&](int t, f32x16 (&cur)[2]) {
+    if (active) {
+      f32x4 ph[4], pl[4];
+      probs(cur, ph, pl);
+      apply(ring[t % 3], ph, pl);
+    }
+  };
+  {
+    int t = 0;
+    for (; t + 3 < T; t += 2) {       // (neither step reaches the last tile)
+      step(t, sA, sB, std::false_type{});
+      step(t + 1, sB, sA, std::false_type{});
+    }
+    // what is left: one step (t + 2 == T), two (t + 3 == T), or none (t + 1 == T); the final step meets the last tile
+    auto final_step = [&](int tt, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+      if (ragged) step(tt, cur, nxt, std::true_type{});
+      else step(tt, cur, nxt, std::false_type{});
+    };
+    if (t + 3 == T) {
+      step(t, sA, sB, std::false_type{});
+      final_step(t + 1, sB, sA);
+      last(t + 2, sA);
+    } else if (t + 2 == T) {
+      final_step(t, sA, sB);
+      last(t + 1, sB);
+    } else {
+      last(t, sA);
+    }
   }
   if (q0 + col < L) {
-    const float inv = 1.0f / l_run;
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
     float* dst = out + (((size_t)n * L + q0 + col) * NH + h) * HD + 4 * half;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)   // registers 4*g4 .. 4*g4+3 = d rows 8*g4 + 4*half + 0..3
-      *reinterpret_cast<f32x4*>(dst + 8 * g4) =
-          f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv};
+    for (int g4 = 0; g4 < 4; ++g4) {   // registers 4*g4 .. 4*g4+3 = d rows 8*g4 + 4*half + 0..3
+      f32x4 y;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = fmaf(oc[4 * g4 + i], SPLIT_INV, o[4 * g4 + i]) * inv;
+      *reinterpret_cast<f32x4*>(dst + 8 * g4) = y;
+    }
   }
   if (flags) range_report<GM_SPLIT>(rg, flags);
 }
 
 hipError_t launch_full_attention_split(const float* q, const float* k, const float* v, int n, int L,
                                        int S, float* out, uint32_t* flags, hipStream_t s) {
-  const int qchunks = (L + 127) / 128;
-  hipLaunchKernelGGL(k_full_attention_split, dim3((unsigned)(n * NH * qchunks)), dim3(256), 0, s, q,
+  const int qchunks = (L + 32 * FA_WAVES - 1) / (32 * FA_WAVES);
+  hipLaunchKernelGGL(k_full_attention_split, dim3((unsigned)(n * NH * qchunks)), dim3(64 * FA_WAVES), 0, s, q,
                      k, v, L, S, out, flags);
   return hipGetLastError();
 }

@@ -103,3 +103,48 @@ def test_configs2_policy_8_pairs_at_640(gpu):
     w = orc.make_hot_weights(1, sharpen=True)
     eng = _engine(w, gpu, 'f32_split_qk16')
     _check_batch(eng, gpu, w, 8, (20, 20), (20, 20), (640, 640), (640, 640), seed=540, n_oracle=8)
+
+
+@pytest.mark.parametrize('precision', ['f32_split_f16', 'f32_split_f16@64'])
+def test_configs3_literal_64x64_tokens_4_pairs_at_2048(gpu, precision):
+    """BASELINE configs[3]'s literal "HW = 64x64 correlation volume" (SURVEY 8d "Config 4"): 4 pairs @
+    2048x2048 -> 4096 tokens per image through the linear path; pair independence bit for bit, boxes in
+    range, IoU >= 1 - 1e-3 against the CPU oracle on a 1-pair slice (VERDICT r5 missing item 2)."""
+    w = orc.make_hot_weights(4, sharpen=True)
+    eng = _engine(w, gpu, precision)
+    _check_batch(eng, gpu, w, 4, (64, 64), (64, 64), (2048, 2048), (2048, 2048), seed=550, n_oracle=1,
+                 slice_exact='@' in precision)
+
+
+def test_all_pairs_attention_at_L4096_properties(gpu):
+    """The all-pairs kernel (reference FullAttention, src/models/linear_attention.py:53-87) at the literal
+    4096 x 4096 volume, 8 heads: too large for the fp64 oracle in the suite's budget as a whole, so
+    (i) a slice of queries against the oracle over ALL 4096 keys at the goldens' tolerance, (ii) softmax
+    properties that do not depend on size - V = const gives that constant exactly to fp32 rounding,
+    permuting the keys (with their values) changes nothing beyond the summation order, a query's
+    result does not depend on the other queries bit for bit - and (iii) run-to-run determinism."""
+    from imagematching_oetr_amd import full_attention
+    L = 4096
+    gen = torch.Generator().manual_seed(77)
+    q = (torch.rand(1, L, 8, 32, generator=gen) - 0.5) * 4
+    k = (torch.rand(1, L, 8, 32, generator=gen) - 0.5) * 4
+    v = (torch.rand(1, L, 8, 32, generator=gen) - 0.5) * 2
+    dq, dk, dv = q.to(gpu), k.to(gpu), v.to(gpu)
+    out = full_attention(dq, dk, dv, variant='f32_split_f16', check_range=True)
+    assert torch.isfinite(out).all()
+    rows = torch.arange(0, L, 97)
+    ref = orc.full_attention(q[:, rows].double(), k.double(), v.double())
+    assert float((out[:, rows].cpu().double() - ref).abs().max()) <= 5e-6
+    exact = full_attention(dq, dk, dv, variant='f32')
+    assert float((out - exact).abs().max()) <= 5e-6
+    # (ii) properties
+    const = torch.full_like(dv, 0.625)
+    assert float((full_attention(dq, dk, const, variant='f32_split_f16') - 0.625).abs().max()) <= 2e-6
+    perm = torch.randperm(L, generator=gen).to(gpu)
+    assert float((full_attention(dq, dk[:, perm].contiguous(), dv[:, perm].contiguous(), variant='f32_split_f16')
+                  - out).abs().max()) <= 2e-6
+    part = full_attention(dq[:, 1000:1300].contiguous(), dk, dv, variant='f32_split_f16')   # another query blocking (300 of 4096)
+    assert float((part - out[:, 1000:1300]).abs().max()) <= 2e-6
+    # (iii) the same launch again, bit for bit (the kernel's MFMA operands come straight out of VALU conversions)
+    for _ in range(5):
+        assert torch.equal(full_attention(dq, dk, dv, variant='f32_split_f16'), out)
