@@ -383,17 +383,33 @@ __device__ __forceinline__ void gemm_rows32(const float* __restrict__ A, int lda
 #pragma unroll
   for (int t = 0; t < NT; ++t) w_ptr[t] = Wp + (size_t)(nt0 + t) * KS * 64;   // (uniform when nt0 is: lane comes last)
 
+  // K is summed in NB blocks, each in an accumulator of its own that starts from zero and is added to `acc` when
+  // the block is done (round 6): v_mfma_f32_32x32x2_f32 adds ONE product per accumulator step,
+  // so a single accumulator is a chain of K = 256 .. 512 dependent fp32 additions per output - the exact-fp32 build
+  // was the LEAST accurate one (cxy 2.1e-2 px on the sharpened 1024 / 1280-px goldens where the f16-MFMA builds,
+  // 16 .. 32 steps per output, stay at 4e-3).  Four blocks: chains of 64 .. 128, then four adds - the blocked
+  // summation every CPU GEMM (the reference's included) does anyway.  32 VALU adds per block and wave beside
+  // 64 .. 128 MFMAs of 64 cycles.
+  constexpr int NB = 4, CPB = NCH / NB;
+  static_assert(NCH % (2 * NB) == 0, "K must be a multiple of 16*U*NB");
   GemmRegs<NT, U> r0, r1;
   gemm_fetch<NT, U>(r0, a_ptr, w_ptr, 0, (unsigned)lane);
-  for (int c = 0; c < NCH; c += 2) {
-    gemm_fetch<NT, U>(r1, a_ptr, w_ptr, c + 1, (unsigned)lane);
-    __builtin_amdgcn_sched_barrier(0);
-    gemm_mma<NT, U>(r0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 2 < NCH) gemm_fetch<NT, U>(r0, a_ptr, w_ptr, c + 2, (unsigned)lane);
-    __builtin_amdgcn_sched_barrier(0);
-    gemm_mma<NT, U>(r1, acc);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int b = 0; b < NB; ++b) {
+    f32x16 part[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) part[t] = f32x16{0};
+    for (int c = b * CPB; c < (b + 1) * CPB; c += 2) {
+      gemm_fetch<NT, U>(r1, a_ptr, w_ptr, c + 1, (unsigned)lane);
+      __builtin_amdgcn_sched_barrier(0);
+      gemm_mma<NT, U>(r0, part);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < NCH) gemm_fetch<NT, U>(r0, a_ptr, w_ptr, c + 2, (unsigned)lane);
+      __builtin_amdgcn_sched_barrier(0);
+      gemm_mma<NT, U>(r1, part);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] += part[t];
   }
 }
 

@@ -31,20 +31,24 @@
 // The two small attention blocks of the f16-based modes - the per-tile KV state phi(K)^T V and
 // the attention apply phi(Q).KV - take their MFMA operands straight from VALU conversions.
 //  * APPLY runs as fp32-class split f16 MFMAs (common.h: mma16_split3, fenced).
-//  * STATE runs on f32 MFMAs (v_mfma_f32_32x32x2_f32, exact products), software-pipelined: the
-//    operands of accumulator register r + 1 are formed while the MFMA of register r runs.
-//    Round 2's split-f16 form of the state (6 f16 MFMAs per row tile instead of 16 f32 ones,
-//    1.8 us per 64-row launch faster) returned timing-dependent states and is gone from the
-//    source.  What round 4 established about it (profiles/r4_hazard_study.txt): the
-//    failures need BOTH row-tile code paths of that form in the kernel - a workgroup-uniform
-//    run-time branch between a path with the row masks (ragged tiles) and one without (full
-//    tiles); builds with either path alone: 0 differing of 157 000 forwards under both
-//    amplifiers (vmcnt(0) before every GEMM step, s_setprio 3 around the state), two-path
-//    builds 14 .. 8002 of 37 000, fenced or not.  Every hazard distance in the failing
-//    instruction stream was checked against hardware probes (tools/mfma_branch_hazard_probe.hip,
-//    tools/sgpr_war_probe.hip, tools/mfma_hazard_probe.hip) and holds; the mechanism is still
-//    not named, so no split-f16 state ships and none can be built by a flag.  Commit 23fac5d
-//    holds the study's knobs (OETR_SPLIT_STATE, OETR_HZ).
+//  * STATE runs as split f16 MFMAs too (kv_state_64, OETR_SPLIT_STATE = 1: 6 f16 MFMAs per row tile
+//    instead of 16 f32 ones, 1.8 us per 64-row launch), in ONE code path.  History, because the argument
+//    for shipping it is empirical: round 2's form of this state returned timing-dependent results (2 - 800
+//    of 25 000 forwards) and was replaced by exact f32 MFMAs in round 3.  Round 4's hazard study
+//    (profiles/r4_hazard_study.txt, HISTORY.md) found what every failing build shares - BOTH row-tile code
+//    paths of that form in the kernel, a workgroup-uniform run-time branch between a path with the row masks
+//    (ragged tiles) and one without (full tiles): builds with either path alone, 0 differing of 157 000
+//    forwards under both amplifiers (vmcnt(0) before every GEMM step, s_setprio 3 around the state);
+//    two-path builds 14 .. 8 002 of 37 000, fenced or not.  Every hazard distance in the failing instruction
+//    stream was checked against hardware probes (tools/mfma_branch_hazard_probe.hip, tools/sgpr_war_probe.hip,
+//    tools/mfma_hazard_probe.hip) and holds: THE MECHANISM IS NOT NAMED.  Round 5 rebuilt the state with the
+//    masks applied unconditionally (one path) and soaked it with the amplifiers as compile options: 0
+//    differing of 1 559 115 forwards (profiles/r5_determinism_soak.txt).  That is evidence, not an
+//    explanation, so the tripwire runs where the driver runs it (round 6): `make` also builds
+//    liboetr_hip_soak.so (-DOETR_SOAK_AMP=3, both amplifiers), and
+//    tests/test_gpu_determinism.py::test_amplified_soak_build_is_deterministic runs the interleaved-shape
+//    loop against it for 20 s in every GPU test run.  If that test ever reports a differing forward, set
+//    OETR_SPLIT_STATE 0 (the f32-MFMA state is still in the source) before anything else.
 
 #ifndef OETR_SOAK_AMP
 #define OETR_SOAK_AMP 0   // determinism-soak builds (tools/r5_soak.sh): 1 = vmcnt(0) before every GEMM step, 2 = s_setprio 3 around the state

@@ -1026,7 +1026,7 @@ class NeckEngine:
                 _check(self.lib, self.lib.oetr_neck_forward_tokens_status(
                     self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),
                     tokens_out.data_ptr(), status_word.data_ptr(), _stream(self.device)),
-                    'oetr_neck_forward_tokens_status', 'oetr_debug_mfma_rate')
+                    'oetr_neck_forward_tokens_status')
                 return tokens_out
             _check(self.lib, self.lib.oetr_neck_forward_tokens(
                 self._h, x.data_ptr(), n, hb, wb, ws.data_ptr(), ws.numel(),

@@ -96,6 +96,56 @@ def _interleaved(model, precision, tile, rounds, attention, prereduce, split, ma
     assert eng.query_flags() == 0
 
 
+def test_amplified_soak_build_is_deterministic(model):
+    """The tripwire of the split-f16 linear-attention state (csrc/encoder.hip: OETR_SPLIT_STATE - shipped on
+    evidence, its round-2 failure mode never named): ``liboetr_hip_soak.so`` is the library
+    with BOTH amplifiers of round 4's hazard study compiled into the encoder kernels (``-DOETR_SOAK_AMP=3``:
+    ``s_waitcnt vmcnt(0)`` before every GEMM step - the waves of a workgroup drift apart - and ``s_setprio 3``
+    around the state).  Under them the two-path forms of that state failed 14 .. 8 002 of 37 000 forwards;
+    the shipped one-path form must show 0 - interleaved shapes, both tile sizes, 20 s in every GPU run."""
+    import time
+    from pathlib import Path
+    from imagematching_oetr_amd import hip_engine
+    soak = Path(hip_engine.LIB_PATH).with_name('liboetr_hip_soak.so')
+    assert soak.exists(), f'{soak} not built (make -C imagematching_oetr_amd/csrc)'
+    shipped = hip_engine.load_library()
+    dev = torch.device('cuda', 0)
+    try:
+        hip_engine._lib = hip_engine.load_library(str(soak))
+        assert hip_engine._lib is not shipped
+        total = 0
+        for tile, budget in ((64, 10.0), (32, 10.0)):
+            eng = pkg.HotPathEngine(model.hot_path_state(), device=dev, precision='f32_split_f16', enc_tile=tile)
+            assert eng.lib is hip_engine._lib
+            gen = torch.Generator().manual_seed(1)
+            cases = []
+            for n, h1, w1, h2, w2 in SHAPES:
+                f1 = (torch.rand(n, 256, h1, w1, generator=gen) - 0.5).to(dev)
+                f2 = (torch.rand(n, 256, h2, w2, generator=gen) - 0.5).to(dev)
+                p1 = model.pos_encoding(f1.cpu()).contiguous().to(dev)
+                p2 = model.pos_encoding(f2.cpu()).contiguous().to(dev)
+                cases.append((f1, f2, p1, p2, (h1 * 32, w1 * 32), (h2 * 32, w2 * 32)))
+            keys = ('memory1', 'memory2', 'hs1', 'hs2', 'box1', 'box2')
+            refs = [{k: v.clone() for k, v in eng.forward(*c, stages=True).items() if k in keys} for c in cases]
+            differing, runs, t0 = [], 0, time.time()
+            while time.time() - t0 < budget:
+                for ci, c in enumerate(cases):
+                    if runs % 3 == 0:
+                        eng.forward(*c, stages=True, enc_layers=1 + runs % 5)
+                    out = eng.forward(*c, stages=True)
+                    runs += 1
+                    bad = [k for k in keys if not torch.equal(out[k], refs[ci][k])]
+                    if bad:
+                        differing.append((tile, runs, SHAPES[ci], bad))
+            assert not differing, (f'{len(differing)} of {runs} forwards of the AMPLIFIED build differ from the first of '
+                                   f'their shape: {differing[:5]} - set OETR_SPLIT_STATE 0 (csrc/encoder.hip)')
+            assert runs >= 500, runs        # (the loop really ran: ~200 forwards per second)
+            total += runs
+            del eng
+    finally:
+        hip_engine._lib = shipped
+
+
 def test_neck_is_a_function_of_its_inputs():
     """The same for the HIP neck: three map sizes interleaved."""
     from oracle import oetr_oracle as orc

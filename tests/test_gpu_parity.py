@@ -32,22 +32,22 @@ from oracle import oetr_oracle as orc
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-# Round 5: every tolerance is <= 2x the worst error OBSERVED on MI355X for that stage
-# over the goldens, the masked goldens, the edge grids and the fuzz sample (profiles/r5_parity_margins.json,
-# written by this module).  Two-plane modes (the default f32_split_f16 at both tile shapes, the policy):
+# Every tolerance is <= 2x the worst error OBSERVED on MI355X for that stage over the goldens, the masked goldens,
+# the edge grids and the fuzz sample (profiles/r6_parity_margins.json, written by this module under OETR_MARGIN_LOG).
+# Two-plane modes (the default f32_split_f16 at both tile shapes):
 #   memory 6.3e-5  hs 3.5e-5 (a 1 x 1 grid)  logits 2.9e-4  cxy 6.6e-3 px (4.0e-3 on the goldens)  tlbr 2.0e-6
-# i.e. cxy sits inside SURVEY 8c's 1e-2 px.  Exact fp32 (OETR_DTYPE_F32, the re-run route) is the LESS
-# accurate build: its MFMA (32x32x2) adds one product per accumulator step, K = 256 .. 512 dependent
-# fp32 additions per output against 16 .. 32 for the f16 MFMAs - memory 7.1e-5, cxy 2.1e-2 px on the
-# 1024 / 1280-px sharpened goldens (the soft-argmax amplification described above): its own, wider row.
+# i.e. cxy sits inside SURVEY 8c's 1e-2 px.  Exact fp32 (OETR_DTYPE_F32, the route an out-of-range batch is re-run
+# on) shares the row since round 6: its MFMA (32x32x2) adds one product per accumulator step, and with ONE
+# accumulator per output (K = 256 .. 512 dependent additions) it was the least accurate build - cxy 2.1e-2 px on
+# the sharpened 1024 / 1280-px goldens, a row of its own (TOL_F32); summed in four blocks (common.h: gemm_rows32)
+# it observes memory 9.5e-6, logits 1.3e-4, cxy 3.5e-3 px - the most accurate one, as exact products should be.
 TOL = dict(memory=1.3e-4, hs=7e-5, logits=6e-4, cxy=1e-2, tlbr=4e-6, box=1e-2)
-TOL_F32 = dict(memory=1.5e-4, hs=7e-5, logits=9e-4, cxy=4.2e-2, tlbr=4e-6, box=4.2e-2)
 # two forms of the SAME arithmetic (tail forms, decoder on one / four workgroups): fp32 summation order only
 FORM_TOL = dict(hs=1e-5, box=1e-2)
 
 
 def tol(precision=''):
-    return TOL_F32 if precision == 'f32' else TOL
+    return TOL
 
 HOT = sorted(glob.glob(str(Path(__file__).parent / 'golden' / 'hot_*.npz')))
 
@@ -59,13 +59,12 @@ def maxerr(a, b):
 
 
 # Observed margins: every comparison against the oracle / the reference's goldens
-# leaves its max error here - worst case per (case, precision, against, stage) - and the module writes
-# gpurun_out/parity_margins.json when it is done (copied to profiles/r5_parity_margins.json): the
-# tolerances above are <= 2x the worst observation of a stage, and a regression inside the tolerance is
-# visible in the table.
+# leaves its max error here - worst case per (case, precision, against, stage) - and, when OETR_MARGIN_LOG
+# names a file, the module writes the table there when it is done (profiles/r6_parity_margins.json was made
+# that way; a plain test run writes nothing): the tolerances above are <= 2x the worst observation of a
+# stage, and a regression inside the tolerance is visible in the table.
 MARGINS = {}
-MARGIN_LOG = Path(os.environ.get('OETR_MARGIN_LOG',
-                                 Path(__file__).resolve().parents[1] / 'gpurun_out' / 'parity_margins.json'))
+MARGIN_LOG = Path(os.environ['OETR_MARGIN_LOG']) if os.environ.get('OETR_MARGIN_LOG') else None
 
 
 def margin(case, precision, against, stage, err):
@@ -77,19 +76,22 @@ def margin(case, precision, against, stage, err):
 @pytest.fixture(scope='module', autouse=True)
 def _write_margins():
     yield
-    if not MARGINS:
+    if not MARGINS or MARGIN_LOG is None:
         return
     rows = [dict(case=c, precision=p, against=a, stage=s, max_err=float(f'{e:.3e}'))
             for (c, p, a, s), e in sorted(MARGINS.items())]
-    worst = {}
+    worst, worst_f32 = {}, {}
     for r in rows:
         if 'ratio' in r['against']:
             continue
         st = r['stage'].rstrip('12')
         worst[st] = max(worst.get(st, 0.0), r['max_err'])
+        if r['precision'] == 'f32':
+            worst_f32[st] = max(worst_f32.get(st, 0.0), r['max_err'])
     try:
         MARGIN_LOG.parent.mkdir(parents=True, exist_ok=True)
-        MARGIN_LOG.write_text(json.dumps({'tolerances': TOL, 'worst_per_stage': worst, 'rows': rows}, indent=1))
+        MARGIN_LOG.write_text(json.dumps({'tolerances': TOL, 'worst_per_stage': worst, 'worst_per_stage_exact_f32': worst_f32,
+                                          'rows': rows}, indent=1))
     except OSError:
         pass
 
