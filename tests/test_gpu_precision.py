@@ -8,7 +8,7 @@
 * the single-pass 16-bit operand modes ``f16`` (BASELINE configs[4]: "fp16 with fp32
   accumulate") and ``bf16`` (configs[2]: "bf16 MFMA attention"), gated on the
   north_star bar - boxes within 1e-3 IoU of the reference's - on every golden, with
-  the drift of the intermediate tensors RECORDED (``gpurun_out/precision_drift.json``,
+  the drift of the intermediate tensors RECORDED (under ``OETR_DRIFT_LOG=<file>``,
   copied to ``profiles/``) and bounded by separate, wider tolerances than the fp32 ones;
 * the range guard of the f16-based modes: out-of-range weights are rejected by
   ``oetr_create``, out-of-range activations set ``OETR_FLAG_F16_RANGE`` (never a silent
@@ -51,8 +51,8 @@ IOU_FLOOR = {'f16': dict(plain=0.995, sharp=0.90), 'bf16': dict(plain=0.95, shar
 BAR_XFAIL = ('single-pass 16-bit GEMM operands miss the 1e-3 IoU bar on the seeded goldens: '
              'measured min IoU f16 0.9975 (plain heads) / 0.935 (sharpened), bf16 0.973 / 0.883 '
              '(profiles/r3_precision_drift.json); kept as an expected failure, not dropped')
-DRIFT_LOG = Path(os.environ.get('OETR_DRIFT_LOG',
-                                Path(__file__).resolve().parents[1] / 'gpurun_out' / 'precision_drift.json'))
+# (written only when OETR_DRIFT_LOG names a file - a plain test run leaves no files behind)
+DRIFT_LOG = Path(os.environ['OETR_DRIFT_LOG']) if os.environ.get('OETR_DRIFT_LOG') else None
 
 
 def maxerr(a, b):
@@ -68,6 +68,8 @@ def _engine(w, gpu, precision):
 
 
 def _record(entry):
+    if DRIFT_LOG is None:
+        return
     try:
         DRIFT_LOG.parent.mkdir(parents=True, exist_ok=True)
         rows = json.loads(DRIFT_LOG.read_text()) if DRIFT_LOG.exists() else []
@@ -107,7 +109,7 @@ def _golden_drift(path, precision, gpu):
 @pytest.mark.parametrize('path', HOT, ids=lambda p: p.split('hot_')[-1][:-4])
 def test_reduced_precision_drift_is_recorded_and_bounded(path, precision, gpu):
     """16-bit operand modes vs what the REFERENCE produced (goldens): the drift of every
-    stage is recorded (gpurun_out/precision_drift.json -> profiles/) and the well-conditioned
+    stage is recorded (OETR_DRIFT_LOG=<file> -> profiles/) and the well-conditioned
     tensors (memory, hs, tlbr) plus the box IoU are bounded by the mode's own tolerances."""
     entry, drift, ious = _golden_drift(path, precision, gpu)
     mode = precision.partition('@')[0]
