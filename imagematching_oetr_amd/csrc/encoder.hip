@@ -1007,6 +1007,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
 
   f32x16 xacc[NMT];  // residual stream of this wave's 32 channels, both row tiles (transposed C layout)
   PHASE_STAMP(p, 0);
+  if (!HAS_B) PHASE_STAMP(p, 13);   // (first launch: slots 13 / 14 survive the <B,..> launches behind it - tools/phase_timing_a.py)
 
   if (HAS_B) {
     const int ss = p.b_cross ? 1 - side : side;
@@ -1273,6 +1274,7 @@ __device__ __forceinline__ void encoder64_body(const EncLaunch& p, float* smem) 
       store_tile_tokens<THREADS, RTW>(p.x + row_base * C, R1f, nvalid, tid);
       if (n == 0) store_tile_tokens<THREADS, RTW>(p.pos_out + (size_t)(g.prow0[side] + l0) * C, R2f, nvalid, tid);
     }
+    PHASE_STAMP(p, 14);   // (first launch: input tile in LDS - transposed from NCHW - and stored token-major)
   }
 
   // (MASKED: the tile's mask values go where the LayerNorm exchange buffer was - dead after phase B;

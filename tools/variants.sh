@@ -7,7 +7,7 @@ while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   OUT=../../tools/variants/$name
   mkdir -p $OUT
-  for f in api encoder decoder heads attention neck crop reader; do
+  for f in api encoder decoder heads attention neck crop reader calib; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $f.hip -o $OUT/$f.o &
   done
   wait
