@@ -348,8 +348,11 @@ class FlagTicket:
             return int(self._slot.item())
         word = int(self._slot.item()) & 0xffffffff
         if not word & FLAG_PUBLISHED and self._stream is not None:     # eager call: poll, then synchronise
-            deadline = time.perf_counter() + self.POLL_S
+            deadline, spins = time.perf_counter() + self.POLL_S, 0
             while not word & FLAG_PUBLISHED and time.perf_counter() < deadline:
+                spins += 1
+                if not spins & 63:
+                    time.sleep(0)      # (a long wait means the device is the bottleneck: let other Python threads run)
                 word = int(self._slot.item()) & 0xffffffff
             if not word & FLAG_PUBLISHED:
                 self._stream.synchronize()

@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): bench lines + rocprofv3 kernel stats + PMC passes.
 # usage: tools/profile_round.sh <tag>     outputs under gpurun_out/<tag>/ ; copy the
 # summaries you want judged into profiles/<tag>_*.
-TAG=${1:-r4}
+TAG=${1:-r6}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -33,7 +33,7 @@ bash tools/extra_configs.sh $TAG > $OUT/extra_configs.log 2>&1
 mv $ROOT/gpurun_out/${TAG}_extra_configs.jsonl $OUT/extra_configs.jsonl 2>/dev/null
 # ---- rocprofv3: one process runs BOTH encoder shapes (3-stream pass with 64-token
 #      workgroups, then the serial pass with 32-token ones) --------------------------
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-e2e --no-trace --no-exact-f32 --steps 50 --warmup 5 --repeats 1"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-e2e --no-trace --no-exact-f32 --no-rccl-world1 --no-power --steps 50 --warmup 5 --repeats 1"
 SERIAL32="$BENCH --streams 1"
 SERIAL64="$BENCH --streams 1 --enc-tile 64"
 cd /tmp
@@ -55,12 +55,18 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_L
 # stand-alone FullAttention kernels
 FA="python $ROOT/bench.py --kernel full_attention --L 1024 --steps 20 --warmup 3 --repeats 2"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/fa_trace -o trace -- $FA > $OUT/fa_trace.log 2>&1
+# ... and at the literal 64x64-token volume (L = S = 4096, 8 images): kernel stats + SQ counters of the split kernel alone
+FA4="python $ROOT/tools/fa_run.py 4096 f32_split_f16 20"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/fa4096_trace -o trace -- $FA4 > $OUT/fa4096_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -d $OUT/fa4096_pmc_sq -o pmc -- $FA4 > $OUT/fa4096_pmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fa4096_pmc_fetch -o pmc -- $FA4 > $OUT/fa4096_pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/fa4096_pmc_write -o pmc -- $FA4 > $OUT/fa4096_pmc_write.log 2>&1
 cd $ROOT
 # summarise on the box; the raw rocpd databases are too big to carry back
-for d in trace trace64 trace_qk16 overlap_trace neck_trace fa_trace; do
+for d in trace trace64 trace_qk16 overlap_trace neck_trace fa_trace fa4096_trace; do
   db=$(find $OUT/$d -name "*.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_summary.py $db $OUT/${d}_kernel_stats.csv > /dev/null
 done
-for d in pmc_fetch pmc_write pmc_sq pmc_lds neck_pmc_fetch neck_pmc_write neck_pmc_lds; do
+for d in pmc_fetch pmc_write pmc_sq pmc_lds neck_pmc_fetch neck_pmc_write neck_pmc_lds fa4096_pmc_sq fa4096_pmc_fetch fa4096_pmc_write; do
   db=$(find $OUT/$d -name "*.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_pmc.py $db $OUT/$d.csv > /dev/null
 done
 find $OUT -name "*.db" -delete
