@@ -597,18 +597,20 @@ def other_configs(args, device, pkg):
         fq = ((torch.rand(8, 4096, 8, 32, generator=g) - 0.5) * 4).to(device)
         fk = ((torch.rand(8, 4096, 8, 32, generator=g) - 0.5) * 4).to(device)
         fv = ((torch.rand(8, 4096, 8, 32, generator=g) - 0.5) * 2).to(device)
-        for _ in range(2):
+        # (40 launches first: after an idle gap the socket's power controller overshoots - launches 5-8 of a burst take
+        #  700+ us where the first took 575 - and needs ~50 launches, 25 ms, to settle at the sustained 515-520 us:
+        #  tools/fa_each.py, profiles/r6_full_attention_p1plane.txt)
+        for _ in range(40):
             pkg.full_attention(fq, fk, fv, variant='f32_split_f16')
         times = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
             e0.record()
-            for _ in range(4):
+            for _ in range(10):
                 pkg.full_attention(fq, fk, fv, variant='f32_split_f16')
             e1.record()
             torch.cuda.synchronize()
-            times.append(e0.elapsed_time(e1) / 4)
+            times.append(e0.elapsed_time(e1) / 10)
         ms = statistics.median(times)
         flop = 4.0 * 8 * 8 * 4096 * 4096 * 32
         cost, pipe_peak, basis = MFMA_COST['f32_split_f16']
@@ -616,7 +618,7 @@ def other_configs(args, device, pkg):
             'kernel': 'k_full_attention_split [f32_split_f16]', 'avg_launch_us': round(ms * 1e3, 1),
             'achieved': round(flop / ms / 1e9, 1), 'peak': round(pipe_peak / cost, 1), 'unit': 'TFLOP/s',
             'frac': round(flop / ms / 1e9 / (pipe_peak / cost), 4), 'bound': 'mfma', 'peak_basis': basis,
-            'flop_per_launch': flop, 'timing': 'median of 5 regions of 4 launches, HIP events around each region'}
+            'flop_per_launch': flop, 'timing': 'median of 5 back-to-back regions of 10 launches behind 40 warm-up launches, HIP events around each region'}
         del fq, fk, fv
     except Exception as e:
         out['full_attention L=S=4096, 8 images'] = {'error': repr(e)[:200]}

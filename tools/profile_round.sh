@@ -56,7 +56,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_L
 FA="python $ROOT/bench.py --kernel full_attention --L 1024 --steps 20 --warmup 3 --repeats 2"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/fa_trace -o trace -- $FA > $OUT/fa_trace.log 2>&1
 # ... and at the literal 64x64-token volume (L = S = 4096, 8 images): kernel stats + SQ counters of the split kernel alone
-FA4="python $ROOT/tools/fa_run.py 4096 f32_split_f16 20"
+FA4="python $ROOT/tools/fa_run.py 4096 f32_split_f16 150"   # (150 launches: the first ~50 ride the power controller's transient, tools/fa_each.py)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/fa4096_trace -o trace -- $FA4 > $OUT/fa4096_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -d $OUT/fa4096_pmc_sq -o pmc -- $FA4 > $OUT/fa4096_pmc_sq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fa4096_pmc_fetch -o pmc -- $FA4 > $OUT/fa4096_pmc_fetch.log 2>&1
