@@ -275,12 +275,19 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
               f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv});
     return;
   } else {
+  // Round 6: the formulation of attention.hip's k_full_attention_split - 1/sqrt(D) log2(e) folded
+  // into Q before its split (scores in log2 units: v_exp_f32 directly), score accumulators started at -m (the
+  // cross fold yields x = s - m), m raised LAZILY (only when some lane's tile maximum exceeds it by more than
+  // 2^FA_LAZY: P <= 256, inside the f16 range of its hi plane; the final 1/l removes the common factor), the
+  // P.V cross accumulator folded once at the end, keys past S masked in a compile-time variant of the LAST tile
+  // only, l a per-lane partial.  ~190 VALU instructions per 32-key tile instead of ~330.
   f32x4 qh[2], ql[2];
   {
+    const float qs = temp * 1.4426950408889634f;
     const float* qp = p.qp + (row_base + min(col, nvalid - 1)) * C + head * HD + 8 * half;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-      split8(*reinterpret_cast<const f32x4*>(qp + 16 * s), *reinterpret_cast<const f32x4*>(qp + 16 * s + 4),
+      split8(*reinterpret_cast<const f32x4*>(qp + 16 * s) * qs, *reinterpret_cast<const f32x4*>(qp + 16 * s + 4) * qs,
              qh[s], ql[s], rg);
   }
   auto load = [&](int k0, f32x4 (&kk)[4], f32x4 (&vv)[4]) {
@@ -294,55 +301,76 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
       vv[2 * s + 1] = *reinterpret_cast<const f32x4*>(vr + k0 + 16 * s + 8);
     }
   };
-  f32x16 o = {0};   // O^T: rows = d (crow(r, half)), col = query
-  float m_run = NEG, l_run = 0.f;
+  constexpr float FA_LAZY = 8.0f;
+  f32x16 o = {0}, oc = {0};   // O^T and its 2^-11-scaled cross part: rows = d (crow(r, half)), col = query
+  float m_run = 0.f, l_run = 0.f;   // m: the reference the score accumulators start from
   f32x4 kk[4], vv[4];
   load(0, kk, vv);
-  for (int k0 = 0; k0 < S; k0 += 32) {
+  auto tile = [&](int k0, auto tail_c) {
+    constexpr bool tail = decltype(tail_c)::value;
     f32x4 kh[2], kl[2], vh[2], vl[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       split8(kk[2 * s], kk[2 * s + 1], kh[s], kl[s], rg);
       split8(vv[2 * s], vv[2 * s + 1], vh[s], vl[s], rg);
     }
-    if (k0 + 32 < S) load(k0 + 32, kk, vv);   // next tile's rows under this tile's math
-    f32x16 st = {0}, cr = {0};
+    if (!tail && k0 + 32 < S) load(k0 + 32, kk, vv);   // next tile's rows under this tile's math
+    f32x16 st, cr = {0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = -m_run;
 #pragma unroll
     for (int s = 0; s < 2; ++s) mma16_split3(kh[s], kl[s], qh[s], ql[s], st, cr);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = fmaf(cr[r], SPLIT_INV, st[r]);
+    if constexpr (tail) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (k0 + crow(r, half) >= S) st[r] = NEG;
+    }
     float mt = NEG;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float sv = fmaf(cr[r], SPLIT_INV, st[r]);
-      st[r] = (k0 + crow(r, half) < S) ? sv * temp : NEG;
-      mt = fmaxf(mt, st[r]);
-    }
+    for (int r = 0; r < 16; r += 2) mt = __builtin_fmaxf(__builtin_fmaxf(mt, st[r]), st[r + 1]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = exp_neg(fminf(m_run - m_new, 0.f));
-    float ps = 0.f;
+    const bool first = k0 == 0;
+    if (first || __builtin_amdgcn_ballot_w64(mt > FA_LAZY) != 0) {
+      const float adj = first ? mt : fmaxf(mt, 0.f);
+      if (!first) {
+        const float alpha = __builtin_amdgcn_exp2f(-adj);
+        l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { st[r] = exp_neg(fminf(st[r] - m_new, 0.f)); ps += st[r]; }
-    ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
+        for (int r = 0; r < 16; ++r) { o[r] *= alpha; oc[r] *= alpha; }
+      }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
-    f32x16 oc = {0};
+      for (int r = 0; r < 16; ++r) st[r] -= adj;
+      m_run += adj;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = __builtin_amdgcn_exp2f(st[r]);
+      l_run += st[r];
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       f32x4 ph, pl;
+      Range none;   // (P <= 2^FA_LAZY: nothing to guard)
       split8(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]},
-             f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]}, ph, pl, rg);
+             f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]}, ph, pl, none);
       mma16_split3(vh[s], vl[s], ph, pl, o, oc);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = fmaf(oc[r], SPLIT_INV, o[r]);
+  };
+  {
+    int k0 = 0;
+    for (; k0 + 32 <= S; k0 += 32) tile(k0, std::false_type{});
+    if (k0 < S) tile(k0, std::true_type{});     // the ragged last tile: the only one with keys past S
   }
-  const float inv = 1.0f / l_run;
+  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
 #pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4)   // registers 4*g4.. = d rows 8*g4 + 4*half + 0..3 of query `col`
-    S1.put4(col, head * HD + 8 * g4 + 4 * half,
-            f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv});
+  for (int g4 = 0; g4 < 4; ++g4) {   // registers 4*g4.. = d rows 8*g4 + 4*half + 0..3 of query `col`
+    f32x4 y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = fmaf(oc[4 * g4 + i], SPLIT_INV, o[4 * g4 + i]) * inv;
+    S1.put4(col, head * HD + 8 * g4 + 4 * half, y);
+  }
   }   // f16-based modes
 }
 
