@@ -160,9 +160,13 @@ from imagematching_oetr_amd.parallel import BoxGatherer, shard_bounds
 from oracle import oetr_oracle as orc
 torch.set_grad_enabled(False)
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-dev = torch.device('cuda', int(os.environ['LOCAL_RANK']))
+backend = os.environ.get('OETR_TEST_BACKEND', 'nccl')
+dev = torch.device('cuda', int(os.environ['LOCAL_RANK']) % torch.cuda.device_count())   # (gloo dry run: both ranks on the one GPU)
 torch.cuda.set_device(dev)
-dist.init_process_group('nccl', device_id=dev)
+if backend == 'nccl':
+    dist.init_process_group('nccl', device_id=dev)
+else:
+    dist.init_process_group(backend)
 torch.manual_seed(0)
 model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
 sd = model.state_dict(); sd.update(orc.make_hot_weights(5, sharpen=True)); model.load_state_dict(sd, strict=True)
@@ -193,12 +197,16 @@ print('rank', rank, 'ok', len(outs))
 '''
 
 
-def test_rccl_two_ranks_over_xgmi(tmp_path):
-    """Two ranks, one per GPU, over RCCL: the sharded hot path + the pipelined box all-gather.  Needs two
-    GPUs - the driver's 1-GPU box skips it; it is the first thing to run on a multi-GPU node."""
-    if torch.cuda.device_count() < 2:
-        pytest.skip('needs 2 GPUs (the world-2 logic runs on gloo in tests/test_parallel_gloo.py)')
-    env = dict(os.environ, OETR_REPO=str(REPO), HSA_ENABLE_IPC_MODE_LEGACY='0')
+@pytest.mark.parametrize('backend', ['nccl', 'gloo'])
+def test_two_ranks_sharded_hot_path_and_pipelined_gather(tmp_path, backend):
+    """Two ranks under torchrun: the sharded hot path in the throughput mode + the pipelined box all-gather
+    (`BoxGatherer(model=...)`), every rank checking ALL pairs' boxes against the whole batch computed locally.
+    'nccl': one rank per GPU over RCCL / xGMI - needs two GPUs, the driver's 1-GPU box skips it; it is the first
+    thing to run on a multi-GPU node.  'gloo': the SAME worker with both ranks on the one GPU (device tensors through
+    gloo) - runs everywhere and keeps the worker honest."""
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (the same worker runs under gloo on one GPU in the other case)')
+    env = dict(os.environ, OETR_REPO=str(REPO), HSA_ENABLE_IPC_MODE_LEGACY='0', OETR_TEST_BACKEND=backend)
     script = tmp_path / 'rccl_worker.py'
     script.write_text(WORKER)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
