@@ -392,7 +392,8 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
   // barrier, and the two waves of a SIMD queued for the same pipe).  Three LDS buffers: step t reads K of
   // tile t + 1 and V of tile t while tile t + 2 is written; one barrier per step.  (The same pipeline at
   // 32-key granularity - half the live accumulators - measured 8 % slower: 561 vs 518 us at L = S = 4096;
-  // forced to 128 VGPRs for two workgroups per CU it spills 205 registers.)
+  // forced to 128 VGPRs for two workgroups per CU it spills 205 registers; the UNPIPELINED 32-key loop under that
+  // cap - four waves per SIMD as each other's cover - spills 37 and takes 886 us: profiles/r6_full_attention_p1plane.txt.)
   const int T = (S + FA_KT - 1) / FA_KT;
   const bool ragged = (S % FA_KT) != 0;
   load_tile(0);

@@ -49,7 +49,7 @@ for L in (1024, 4096):
     flop = 4.0 * n * 8 * L * L * 32
     for variant in ('f32', 'f32_split_f16'):
         fn = lambda: pkg.full_attention(q, k, v, variant=variant)
-        for _ in range(3):
+        for _ in range(60):      # (behind the power controller's transient: tools/fa_each.py)
             fn()
         best = 1e9
         for _ in range(5):
