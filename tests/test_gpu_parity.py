@@ -259,6 +259,32 @@ def test_full_attention_split_edge_shapes_and_range(gpu):
         full_attention(big, big, big, variant='f32_split_f16', check_range=True)
 
 
+def test_full_attention_split_lazy_maximum_and_tile_boundaries(gpu):
+    """The round-6 kernel keeps a LAZY reference maximum (raised only when a tile's maximum exceeds it by more
+    than 2^8) and works in 64-key tiles / 256-query workgroups: (i) keys whose scores grow along S, so that the
+    reference is raised again and again after the first tile, and scores that shrink (the first tile's reference
+    stays, P underflows towards 0); (ii) S and L on, just below and just above every tile / workgroup boundary.
+    Against the fp64 oracle at the goldens' tolerance; exact-fp32 variant beside it."""
+    from imagematching_oetr_amd import full_attention
+    gen = torch.Generator().manual_seed(11)
+    for ramp in ((0.1, 6.0), (6.0, 0.1)):
+        S = 1000
+        q = (torch.rand(2, 300, 8, 32, generator=gen) - 0.5) * 4
+        k = (torch.rand(2, S, 8, 32, generator=gen) - 0.5) * 4 * torch.linspace(ramp[0], ramp[1], S).view(1, S, 1, 1)
+        v = (torch.rand(2, S, 8, 32, generator=gen) - 0.5) * 2
+        ref = orc.full_attention(q.double(), k.double(), v.double())
+        for variant in ('f32', 'f32_split_f16'):
+            out = full_attention(q.to(gpu), k.to(gpu), v.to(gpu), variant=variant)
+            assert maxerr(out, ref) <= 5e-6, (ramp, variant, maxerr(out, ref))
+    for (L, S) in [(255, 63), (256, 64), (257, 65), (31, 127), (32, 128), (33, 129), (513, 193), (64, 1)]:
+        q = (torch.rand(1, L, 8, 32, generator=gen) - 0.5) * 4
+        k = (torch.rand(1, S, 8, 32, generator=gen) - 0.5) * 4
+        v = (torch.rand(1, S, 8, 32, generator=gen) - 0.5) * 2
+        ref = orc.full_attention(q.double(), k.double(), v.double())
+        out = full_attention(q.to(gpu), k.to(gpu), v.to(gpu), variant='f32_split_f16')
+        assert maxerr(out, ref) <= 5e-6, (L, S, maxerr(out, ref))
+
+
 @pytest.mark.parametrize('precision', PRECISIONS)
 @pytest.mark.parametrize('n,g1,g2', [
     (1, (1, 1), (1, 1)),          # single token per image
