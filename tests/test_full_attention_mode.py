@@ -99,6 +99,43 @@ def test_full_attention_mode_contract(gpu):
 
 
 @pytest.mark.gpu
+def test_full_attention_mode_sharp_scores_take_the_lazy_maximum_path(gpu):
+    """Round 6: the encoder's all-pairs tile keeps a LAZY reference maximum (raised only when a key tile's
+    maximum exceeds it by more than 2^8).  With the initialisation's weights the scores are small and that
+    branch never runs after the first tile: sharpen Q and K (x 5 each: scores x 25) so that it does - 1 600
+    keys = 50 tiles per query - and compare with the oracle and with the exact-fp32 build, whose tile keeps
+    the exact running maximum (another code path)."""
+    from imagematching_oetr_amd import HotPathEngine
+    w = dict(orc.make_hot_weights(2))
+    for l in range(8):
+        for name in ('q_proj', 'k_proj'):
+            key = f'transformer.encoder.{l}.{name}.weight'
+            w[key] = w[key] * 5.0
+    g1, g2 = (5, 5), (40, 40)
+    f1, f2 = orc.make_features(51, 2, *g1), orc.make_features(52, 2, *g2)
+    p1, p2 = orc.position_table(*g1), orc.position_table(*g2)
+    im1, im2 = (160, 160), (1280, 1280)
+    ref = orc.hot_path(f1.double(), f2.double(), {k: v.double() for k, v in w.items()}, im1, im2, return_stages=True,
+                       attention=orc.full_attention)
+    # sharp softmaxes amplify fp32 rounding: the yardstick is what torch's own fp32 does against fp64 on this case
+    ref32 = orc.hot_path(f1, f2, w, im1, im2, return_stages=True, attention=orc.full_attention)
+    drift = max(maxerr(ref32['memory' + s], ref['memory' + s]) for s in ('1', '2'))
+    bound = max(4 * drift, 2 * TOL['memory'])
+    outs = {}
+    for prec in ('f32_split_f16', 'f32'):
+        eng = HotPathEngine(w, device=gpu, attention='full', precision=prec)
+        outs[prec] = eng.forward(f1.to(gpu), f2.to(gpu), p1.to(gpu), p2.to(gpu), im1, im2, stages=True)
+        assert eng.query_flags() == 0
+        for s in ('1', '2'):
+            err = maxerr(outs[prec]['memory' + s], ref['memory' + s])
+            assert err <= bound, (prec, s, err, drift)
+    assert maxerr(outs['f32_split_f16']['memory1'], outs['f32']['memory1'].cpu()) <= 2 * bound
+    # the attention really is sharp: a uniform average over the keys would give something else entirely
+    lin = orc.hot_path(f1, f2, w, im1, im2, return_stages=True)
+    assert maxerr(lin['memory1'], ref['memory1']) > 1e-1
+
+
+@pytest.mark.gpu
 def test_module_reruns_an_overflowing_full_attention_batch_in_exact_fp32(gpu):
     """``attention='full'`` has an exact-fp32 build too (``OETR_DTYPE_F32``): an out-of-range batch
     is answered with ITS boxes, as in the linear mode (reference ``transformer.py:86-89`` is fp32)."""
