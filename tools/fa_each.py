@@ -1,3 +1,5 @@
+"""Per-launch duration of the stand-alone FullAttention kernel over 60 back-to-back launches after an idle gap (the
+socket power controller's transient: profiles/r6_full_attention_p1plane.txt).  python tools/fa_each.py"""
 import sys
 sys.path.insert(0, '/root/repo')
 import torch, time

@@ -1,3 +1,5 @@
+"""Host cost of a submitted batch through the module (GPU box): submit into an idle device, hip_streams = 1 and 3,
+plus a cProfile of 300 submits in the throughput mode.  python tools/host_cost.py"""
 import sys, time, cProfile, pstats
 sys.path.insert(0, '/root/repo')
 import torch
