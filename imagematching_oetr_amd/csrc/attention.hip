@@ -191,19 +191,22 @@ hipError_t launch_full_attention(const float* q, const float* k, const float* v,
 //
 // Round 6 (0.19 of the split roof at L = S = 4096; the kernel was VALU-bound,
 // ~20 VALU issue slots per score element beside 0.75 MFMA): what a score element costs now -
-//   * 1/sqrt(D) and log2(e) are folded into Q before its split, scores arrive in log2 units:
-//     P = v_exp_f32(s - m), one subtract and one transcendental (was: multiply, select, the
-//     6-instruction compensated exp and two clamps);
-//   * keys past S are masked in the LAST tile only (a wave-uniform branch);
-//   * the running maximum is exact, but O, its cross accumulator and l are rescaled only in tiles
-//     where some lane's maximum moved (wave-uniform ballot; after the first few tiles it rarely does);
-//   * the cross accumulator of P.V (the 2^-11-scaled half of the split product) runs across tiles and
-//     is folded into O once at the end instead of once per tile;
+//   * 1/sqrt(D) and log2(e) are folded into Q before its split, scores arrive in log2 units: P = v_exp_f32(x)
+//     (was: multiply, select, the 6-instruction compensated exp and two clamps);
+//   * keys past S are masked in the LAST tile only (a compile-time variant of the step);
+//   * the reference maximum m follows the true maximum lazily: O, its cross accumulator and l are rescaled only in
+//     tiles where some lane's maximum moved (wave-uniform ballot; after the first few tiles it rarely does);
+//   * the cross accumulator of P.V (V's lo plane) runs across tiles and is folded into O once at the end;
 //   * the row sum l stays a per-lane partial (its two half-lanes are added once at the end).
-// P is still split into two planes (hi + lo/2^11) like every other operand: a single f16 plane
-// for P (VERDICT r5's suggestion) was measured first - 3e-5 .. 8e-5 against the fp64 oracle where the
-// goldens allow 5e-6, for 13 % of launch time (profiles/r6_full_attention_p1plane.txt; the
-// -DOETR_FA_P1PLANE build keeps the experiment reproducible).
+// Later the same round (`scores`, `m_run`, `probs` below; steps and numbers: profiles/r6_full_attention_steps.txt):
+//   * the score side needs NO VALU instruction per element any more: K's and Q's lo planes are UNSCALED (split2u), so
+//     all three products of the split go into ONE accumulator (no cross accumulator, no fold), and -m enters as one
+//     more MFMA (A = ones in two k-slots, B = -m as an f16 pair) instead of a per-tile fill of the accumulators;
+//   * P carries a factor 2^FA_SH (the final 1/l removes it) and its lo plane is unscaled too: no multiply in its split.
+//   6.5 -> 4.5 VALU instructions per score element (exp, row sum, half a max3, convert, residual, convert).
+// P is still split into two planes like every other operand: a single f16 plane for P (VERDICT r5's suggestion) was
+// measured first - 3e-5 .. 8e-5 against the fp64 oracle where the goldens allow 5e-6, for 13 % of launch time
+// (profiles/r6_full_attention_p1plane.txt; the -DOETR_FA_P1PLANE build keeps the experiment reproducible).
 constexpr int FA_KT = 64;            // keys per tile
 constexpr int FA_KP = 40;            // halves per K row (32 d + 8): conflict-free ds_read_b128
 constexpr int FA_VP = FA_KT + 8;     // halves per V^T row (64 key slots + 8): 9 x 16 B, conflict-free
@@ -211,8 +214,24 @@ constexpr int FA_VP = FA_KT + 8;     // halves per V^T row (64 key slots + 8): 9
 #define OETR_FA_WAVES 8
 #endif
 constexpr int FA_WAVES = OETR_FA_WAVES;   // waves per workgroup, 32 queries each
+constexpr float FA_SH = 4.0f;             // log2 of the common factor P, O and l carry (k_full_attention_split: m_run)
+// Two floats -> (hi, lo) f16 pairs with an UNSCALED lo plane: hi = RNE f16(x), lo = RNE f16(x - hi) (the difference
+// is exact in f32; v_fma_mix_f32 reads the f16 half directly; v_cvt_pk_f16_f32 for both planes).  x = hi + lo to
+// <= 2^-23 relative wherever lo is a normal f16 number; below that (|lo| < 2^-14, i.e. |x| < ~0.25) lo is a DENORMAL
+// with absolute error <= 2^-25 - v_mfma_f32_32x32x16_f16 honours f16 denormal inputs on gfx950
+// (tools/mfma_denorm_probe.hip, run on the box: profiles/r6_full_attention_steps.txt).
+// A product against such a plane has the scale of the hi . hi product and accumulates into the SAME accumulator.
+// `neg1` = -1.0f held in an SGPR the compiler cannot see through (with the literal hipcc rewrites the fma into
+// v_cvt_f32_f16 + v_sub_f32: two instructions per element instead of one).
+__device__ __forceinline__ void split2u(float a, float b, float neg1, uint32_t& hi, uint32_t& lo, Range& rg) {
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{__builtin_fmaf((float)h[0], neg1, a),
+                                                                     __builtin_fmaf((float)h[1], neg1, b)}, f16x2));
+  rg.see2(a, b);
+}
 struct FaTile {
-  _Float16 Kh[FA_KT * FA_KP], Kl[FA_KT * FA_KP];
+  _Float16 Kh[FA_KT * FA_KP], Kl[FA_KT * FA_KP];   // K: hi, UNSCALED lo (split2u)
   _Float16 Vh[HD * FA_VP], Vl[HD * FA_VP];   // [d][key slot]
 };
 
@@ -229,6 +248,8 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
   const int q0 = qc * QB + wave * 32;
   const bool active = q0 < L;      // (wave-uniform: a wave past the image end only helps staging)
   Range rg;
+  float neg1 = -1.0f;               // (opaque to the compiler: see split2u)
+  asm volatile("" : "+s"(neg1));
 
   // Q as the B operand of S^T = K Q^T: lane (query = col) holds d = 16s + 8*half + 0..7, already
   // multiplied by 1/sqrt(D) * log2(e) - the scores come out of the MFMAs in log2 units
@@ -242,12 +263,44 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
       a0 = *reinterpret_cast<const f32x4*>(qp) * qs;
       a1 = *reinterpret_cast<const f32x4*>(qp + 4) * qs;
     }
-    split8(a0, a1, qh[s], ql[s], rg);
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;   // (unscaled lo plane, like K's: `scores`)
+    split2u(a0[0], a0[1], neg1, h0, l0, rg);
+    split2u(a0[2], a0[3], neg1, h1, l1, rg);
+    split2u(a1[0], a1[1], neg1, h2, l2, rg);
+    split2u(a1[2], a1[3], neg1, h3, l3, rg);
+    qh[s] = __builtin_bit_cast(f32x4, u32x4{h0, h1, h2, h3});
+    ql[s] = __builtin_bit_cast(f32x4, u32x4{l0, l1, l2, l3});
   }
-  f32x16 o = {0}, oc = {0};   // O^T and its 2^-11-scaled cross part: rows = d (crow(r, half)), col = query
+  f32x16 o = {0}, oc = {0};   // O^T and the part that meets V's (2^11-scaled) lo plane: rows = d (crow(r, half)), col = query
   // (masked scores and the initial maximum are a large FINITE negative: no inf - inf anywhere)
   constexpr float NEG = -1.0e30f;
-  float m_run = 0.f, l_run = 0.f;   // m: the reference the score accumulators start from (`maximum` below)
+  // Everything behind the exponential carries a factor 2^FA_SH (P' = 2^FA_SH . P; O, its cross accumulator and l with
+  // it - the final 1/l removes it exactly like 2^-m): P's lo plane is then f16(P' - hi) with NO 2^11 scaling, its product
+  // with V_hi has the scale of hi . V_hi and goes into the SAME accumulator - one VALU multiply per score element fewer.
+  // FA_SH = 4: the lo plane of a weight P >= 2^-6 is a normal f16 number, below that a denormal with absolute error
+  // 2^-25 = 2^-29 of the row's largest weight (at S = 4096 equal weights: 1e-7 of the output after averaging).  The
+  // factor costs accuracy where the scores are tiny: x = s - m + FA_SH is formed at magnitude FA_SH (2^-23 absolute at
+  // 4; with 11 - the lo plane normal down to 2^-13 - the S = 2 fuzz cases sat at 4-5x torch fp32's own drift).
+  // m_run = (reference maximum) - FA_SH.  It enters the scores THROUGH THE MATRIX PIPE: one more MFMA per 32-key half
+  // whose A fragment is 1 in k-slots 0 and 1 (every key row) and whose B fragment holds, in the lane's query column,
+  // -m_run as two f16 values (hi + lo) in those slots - the product is -m_run in every row of the column.  m_run is
+  // kept to 21 significant bits (and a multiple of 2^-24), so hi + lo IS m_run: whatever its value, it is the SAME
+  // number in every tile between two adjustments - the common factor the final 1/l removes - and the rescale factor of
+  // an adjustment is computed from the same two numbers.  The reference only has to be NEAR the maximum; this near
+  // (x_max = FA_SH to 2^-21 |m|) the row's largest weight is P' = 2^FA_SH (1 + eps), which the two planes hold almost
+  // exactly - an integer-valued m_run (exact power-of-two rescales) left P'_max anywhere within a factor sqrt(2), with the
+  // generic 2^-23 representation error that l, summed from the unsplit P', does not share: 1.8e-7 on a ONE-key row.
+  // |m_run| beyond the f16 range (scores beyond 6e4 in log2 units) is reported through the range guard like any other
+  // operand.  2 MFMAs per tile on a pipe that is 40 % busy, against a per-element subtraction (or, before, the fold
+  // and the per-tile fill of the accumulators with -m).
+  // (Tried on the way: a 16-register tuple holding -m_run as the C operand of every chain's first MFMA - hipcc copies
+  //  the tuple at the join behind the lazy branch, more moves than the fill; and see `scores` for why the chain cannot
+  //  simply START at -m_run.)
+  float m_run = -FA_SH, l_run = 0.f;
+  const uint32_t onebits = lane < 32 ? 0x3c003c00u : 0u;           // (1.0h, 1.0h) in k-slots 0, 1 of the half-0 lanes
+  const f32x4 afrag = __builtin_bit_cast(f32x4, u32x4{onebits, 0u, 0u, 0u});
+  f32x4 mfrag = __builtin_bit_cast(f32x4, u32x4{lane < 32 ? 0x00004400u : 0u, 0u, 0u, 0u});   // (4.0h, 0): -m_run = FA_SH
+  static_assert(FA_SH == 4.0f, "initial mfrag encodes 4.0 as f16 0x4400");
 
   // staging roles.  K: thread -> (key row = tid >> 3, 4 consecutive d = 4 * (tid & 7)), one 16-byte load.
   // V: thread -> (d = tid & 31, keys 4g .. 4g + 3, g = tid >> 5): four 4-byte loads (a half-wave reads the 128
@@ -276,8 +329,11 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
       const int item = tid + 64 * FA_WAVES * it;
       const int kr = item >> 3, kd = 4 * (item & 7), vd = item & 31, vg = item >> 5;
       const int vslot = 16 * (vg >> 2) + 8 * (vg & 1) + 4 * ((vg >> 1) & 1);
-      store_planes4<GM_SPLIT>(B.Kh + kr * FA_KP, B.Kl + kr * FA_KP, kd, kreg[it], rg);
       uint32_t h0, l0, h1, l1;
+      split2u(kreg[it][0], kreg[it][1], neg1, h0, l0, rg);
+      split2u(kreg[it][2], kreg[it][3], neg1, h1, l1, rg);
+      *reinterpret_cast<u32x2*>(B.Kh + kr * FA_KP + kd) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(B.Kl + kr * FA_KP + kd) = u32x2{l0, l1};
       cvt_planes2<GM_SPLIT>(vreg[it][0], vreg[it][1], h0, l0, rg);
       cvt_planes2<GM_SPLIT>(vreg[it][2], vreg[it][3], h1, l1, rg);
       *reinterpret_cast<u32x2*>(B.Vh + vd * FA_VP + vslot) = u32x2{h0, h1};
@@ -285,33 +341,58 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
     }
   };
   // ---- the per-tile pieces -------------------------------------------------------------------------
-  // S^T tile of the keys in B: rows = keys (two 32-key halves), cols = queries; 12 MFMAs, operands from LDS
-  // and the Q registers only - independent of every VALU result, free to run beside the softmax of the
-  // tile before.  The accumulators enter holding -m (see `maximum`).
-  auto scores = [&](const FaTile& B, f32x16 (&sa)[2], f32x16 (&ca)[2]) {
+  // S^T tile of the keys in B: rows = keys (two 32-key halves), cols = queries; 14 MFMAs, operands from LDS and
+  // registers that no VALU result of the step feeds - free to run beside the softmax of the tile before.
+  // ONE accumulator per 32-key half; the three products of the split all have the scale of K_hi . Q_hi:
+  //   K_hi . Q_lo  +  K_lo . Q_hi  +  (-m_run)  +  K_hi . Q_hi          (both lo planes unscaled: split2u)
+  // - no cross accumulator (32 registers) and no fold.  ORDER MATTERS: the chain starts from zero with the SMALL
+  // products (2^-12 of the scores) and takes the big ones last.  The MFMA adds its 16 products and C in one aligned
+  // sum, and small addends beside a large one lose their low bits there: with the accumulator started at -m and the big
+  // products first, the error against the fp64 oracle was 2-3x the two-accumulator kernel's (6.8x torch fp32's own
+  // drift on the worst fuzz case, 4.76e-6 on the sharpened probe where the goldens allow 5e-6).  With the small terms
+  // summed among themselves first, their SUM is cut once when the first big step comes in - the fold's single rounding.
+  // (Measured and dropped: Q's lo plane kept 2^11-scaled against a third K plane K_hi x 2^-11 - Q' = Q x 0.255 is
+  //  small, its unscaled lo plane mostly denormal - bought nothing on the probes or the fuzz, for 3 % of launch time.)
+  // The two 32-key halves are independent chains; their MFMAs alternate.
+  auto scores = [&](const FaTile& B, f32x16 (&sa)[2]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) sa[j] = f32x16{0};
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const f32x4 ah = *reinterpret_cast<const f32x4*>(B.Kh + (32 * j + col) * FA_KP + 16 * s + 8 * half);
-        const f32x4 al = *reinterpret_cast<const f32x4*>(B.Kl + (32 * j + col) * FA_KP + 16 * s + 8 * half);
-        mma16_split3<false>(ah, al, qh[s], ql[s], sa[j], ca[j]);
+    for (int s = 0; s < 2; ++s) {
+      f32x4 al[2], ah[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        al[j] = *reinterpret_cast<const f32x4*>(B.Kl + (32 * j + col) * FA_KP + 16 * s + 8 * half);
+        ah[j] = *reinterpret_cast<const f32x4*>(B.Kh + (32 * j + col) * FA_KP + 16 * s + 8 * half);
       }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sa[j] = mma16<GM_SPLIT>(ah[j], ql[s], sa[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sa[j] = mma16<GM_SPLIT>(al[j], qh[s], sa[j]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 ah[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        ah[j] = *reinterpret_cast<const f32x4*>(B.Kh + (32 * j + col) * FA_KP + 16 * s + 8 * half);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sa[j] = mma16<GM_SPLIT>(ah[j], qh[s], sa[j]);
+      if (s == 0) {   // - m_run BETWEEN the two big steps: every intermediate sum is about half the size of m
+#pragma unroll
+        for (int j = 0; j < 2; ++j) sa[j] = mma16<GM_SPLIT>(afrag, mfrag, sa[j]);
+      }
+    }
   };
-  // The score accumulators START at -m (the lane's query's reference maximum as it stood when the tile's
-  // MFMAs were issued), so the fold below yields x = s - m directly.  m follows the true maximum LAZILY: it is
+  // x = s - m, m = the lane's query's reference maximum.  m follows the true maximum LAZILY: it is
   // raised - and O, its cross accumulator, l and this tile's x rescaled - only when some lane's tile maximum
   // exceeds the reference by more than 2^FA_LAZY (wave-uniform ballot; rare after the first tile, which always
-  // sets the reference).  In between P = 2^x may exceed 1 - by at most 2^FA_LAZY = 256, far inside the f16
-  // range of its hi plane; the final 1/l removes the common factor exactly as it removes 2^-m.
+  // sets the reference).  In between P = 2^x may exceed 1 - by at most 2^FA_LAZY = 256: P' = 2^FA_SH . P <= 2^12 stays
+  // far inside the f16 range of its hi plane; the final 1/l removes the common factor exactly as it removes 2^-m.
   constexpr float FA_LAZY = 8.0f;
-  auto maximum = [&](f32x16 (&sa)[2], const f32x16 (&ca)[2], int k0, auto tail_c, bool first) {
+  auto maximum = [&](f32x16 (&sa)[2], int k0, auto tail_c, bool first) {
     constexpr bool tail = decltype(tail_c)::value;   // (compile time: as a run-time flag hipcc if-converted the 96 compare / select / add
                                                      //  instructions of the mask into EVERY tile's step - a third of its VALU work)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sa[j][r] = fmaf(ca[j][r], SPLIT_INV, sa[j][r]);
     if constexpr (tail) {   // keys past S: only the last tile has any
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -325,8 +406,13 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mt = __builtin_fmaxf(__builtin_fmaxf(mt, sa[j][r]), sa[j][r + 1]);   // v_max3_f32
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    if (first || __builtin_amdgcn_ballot_w64(mt > FA_LAZY) != 0) {
-      const float adj = first ? mt : fmaxf(mt, 0.f);       // (first tile: the reference was 0, nothing accumulated yet)
+    if (first || __builtin_amdgcn_ballot_w64(mt > FA_SH + FA_LAZY) != 0) {
+      // the new reference: the lane's maximum (first tile: nothing accumulated yet, any direction; later: raised only),
+      // rounded to 21 significant bits and to a multiple of 2^-24 - exactly the sum of two f16 values (see m_run)
+      const float nm = -(m_run + (first ? mt - FA_SH : fmaxf(mt - FA_SH, 0.f)));
+      float nq = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, nm) + 4u) & ~7u);
+      if (__builtin_fabsf(nm) < 0.0625f) nq = __builtin_rintf(nm * 16777216.0f) * (1.0f / 16777216.0f);
+      const float adj = -nq - m_run;   // (0 in a lane whose reference stays: its -m_run is already of that form)
       if (!first) {
         const float alpha = __builtin_amdgcn_exp2f(-adj);
         l_run *= alpha;
@@ -337,14 +423,19 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sa[j][r] -= adj;
-      m_run += adj;
+      m_run = -nq;
+      const _Float16 mh = (_Float16)nq, ml = (_Float16)(nq - (float)mh);
+      const uint32_t mb = (uint32_t)__builtin_bit_cast(unsigned short, mh) | ((uint32_t)__builtin_bit_cast(unsigned short, ml) << 16);
+      mfrag[0] = __builtin_bit_cast(float, lane < 32 ? mb : 0u);
+      rg.see2(nq, 0.f);
     }
   };
-  // P = 2^x in place, its row-sum share, and its split planes: B operands of the P.V steps.
-  // The split is common.h's split2 with SCALAR multiplies: packed f32 VALU (v_pk_mul_f32 / v_pk_fma_f32, which
-  // split2 uses on purpose and hipcc's SLP pass forms from adjacent scalar ops - this file is built with
-  // -fno-slp-vectorize) costs ~22 cycles per instruction beside MFMAs on gfx950 (MI355X_MICROARCH.md), and here
-  // every one of them sits beside MFMAs.  (P <= 2^FA_LAZY: nothing for the range guard.)
+  // P' = 2^x in place, its row-sum share, and its split planes: B operands of the P.V steps.
+  // hi = RNE f16(P'), lo = RNE f16(P' - hi): the difference is exact (v_fma_mix_f32 reads the f16 half directly),
+  // UNSCALED - see the note at m_run; four VALU instructions per pair.  Scalar f32 operations only: packed f32 VALU
+  // (v_pk_mul_f32 / v_pk_fma_f32, which hipcc's SLP pass forms from adjacent scalar ops - this file is built with
+  // -fno-slp-vectorize) costs ~22 cycles per instruction beside MFMAs on gfx950 (MI355X_MICROARCH.md), and here every
+  // one of them sits beside MFMAs.  (P' <= 2^(FA_SH + FA_LAZY) = 2^12: nothing for the range guard.)
   auto probs = [&](f32x16 (&sa)[2], f32x4 (&ph)[4], f32x4 (&pl)[4]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -363,8 +454,8 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
           const float a = sa[j][8 * s + 2 * i], b = sa[j][8 * s + 2 * i + 1];
           const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
           hi[i] = __builtin_bit_cast(uint32_t, h);
-          lo[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -SPLIT_SCALE, a * SPLIT_SCALE),
-                                                                         __builtin_fmaf((float)h[1], -SPLIT_SCALE, b * SPLIT_SCALE)));
+          lo[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{__builtin_fmaf((float)h[0], neg1, a),
+                                                                              __builtin_fmaf((float)h[1], neg1, b)}, f16x2));
         }
         ph[2 * j + s] = __builtin_bit_cast(f32x4, u32x4{hi[0], hi[1], hi[2], hi[3]});
         pl[2 * j + s] = __builtin_bit_cast(f32x4, u32x4{lo[0], lo[1], lo[2], lo[3]});
@@ -380,7 +471,9 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
       o = mma16<GM_SPLIT>(ah, ph[ks], o);
       oc = mma16<GM_SPLIT>(al, ph[ks], oc);
 #else
-      mma16_split3<false>(ah, al, ph[ks], pl[ks], o, oc);
+      o = mma16<GM_SPLIT>(ah, ph[ks], o);     // V_hi . P'_hi
+      oc = mma16<GM_SPLIT>(al, ph[ks], oc);   // V_lo (x 2^11) . P'_hi
+      o = mma16<GM_SPLIT>(ah, pl[ks], o);     // V_hi . P'_lo (unscaled lo plane: the same scale)
 #endif
     }
   };
@@ -405,24 +498,20 @@ __global__ __launch_bounds__(64 * FA_WAVES) void k_full_attention_split(const fl
   __syncthreads();
   f32x16 sA[2] = {}, sB[2] = {};
   if (active) {
-    f32x16 c0[2] = {};
-    scores(ring[0], sA, c0);
-    if (T == 1 && ragged) maximum(sA, c0, 0, std::true_type{}, true);
-    else maximum(sA, c0, 0, std::false_type{}, true);
+    scores(ring[0], sA);
+    if (T == 1 && ragged) maximum(sA, 0, std::true_type{}, true);
+    else maximum(sA, 0, std::false_type{}, true);
   }
   auto step = [&](int t, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto tail_c) {   // t + 1 < T; tail_c: tile t + 1 is the ragged last one
     if (t + 2 < T) load_tile((t + 2) * FA_KT);
     if (active) {
       const FaTile& BK = ring[(t + 1) % 3];
       const FaTile& BV = ring[t % 3];
-      f32x16 cn[2] = {};
-#pragma unroll
-      for (int r = 0; r < 16; ++r) nxt[0][r] = nxt[1][r] = -m_run;
       f32x4 ph[4], pl[4];
-      scores(BK, nxt, cn);
+      scores(BK, nxt);
       probs(cur, ph, pl);
       apply(BV, ph, pl);
-      maximum(nxt, cn, (t + 1) * FA_KT, tail_c, false);
+      maximum(nxt, (t + 1) * FA_KT, tail_c, false);
     }
     if (t + 2 < T) write_tile(ring[(t + 2) % 3]);
     __syncthreads();

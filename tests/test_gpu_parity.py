@@ -285,6 +285,51 @@ def test_full_attention_split_lazy_maximum_and_tile_boundaries(gpu):
         assert maxerr(out, ref) <= 5e-6, (L, S, maxerr(out, ref))
 
 
+def test_full_attention_split_unscaled_planes_and_matrix_pipe_reference(gpu):
+    """The second round-6 pass of the split kernel (csrc/attention.hip: `scores`, `m_run`, `probs`): K's, Q's and P's
+    lo planes are UNSCALED f16 values (denormal for small operands - the MFMA honours them), the three products of a
+    score go into one accumulator, and the reference maximum enters as an MFMA product, an f16 PAIR.  (i) operands so
+    small that every lo plane is denormal or zero; (ii) scores with a large common offset per query - |m| in the
+    hundreds, the pair's lo half in use - where fp32 itself drifts (bounded by torch fp32's own error against fp64);
+    (iii) scores in the thousands (one-hot rows, |m| ~ 1e4); (iv) a reference beyond the f16 range is REPORTED;
+    (v) one- and two-key rows, where a weight's representation error cannot average out."""
+    from imagematching_oetr_amd import OetrRangeError, full_attention
+    gen = torch.Generator().manual_seed(23)
+
+    def run(q, k, v, tol_floor=5e-6):
+        ref = orc.full_attention(q.double(), k.double(), v.double())
+        drift = maxerr(orc.full_attention(q, k, v), ref)
+        out = full_attention(q.to(gpu), k.to(gpu), v.to(gpu), variant='f32_split_f16', check_range=True)
+        assert torch.isfinite(out).all()
+        err = maxerr(out, ref)
+        assert err <= max(tol_floor, 4 * drift), (err, drift)
+        return err
+
+    for scale in (1e-3, 3e-2):                                             # (i)
+        q = (torch.rand(2, 200, 8, 32, generator=gen) - 0.5) * scale
+        k = (torch.rand(2, 333, 8, 32, generator=gen) - 0.5) * scale
+        v = (torch.rand(2, 333, 8, 32, generator=gen) - 0.5) * 2
+        assert run(q, k, v) <= 1e-6
+    u = torch.nn.functional.normalize(torch.rand(32, generator=gen) - 0.5, dim=0)
+    for off in (30.0, 60.0):                                               # (ii) s = off^2 / sqrt(32) + O(1) per query
+        q = (torch.rand(2, 130, 8, 32, generator=gen) - 0.5) * 2 + off * u
+        k = (torch.rand(2, 500, 8, 32, generator=gen) - 0.5) * 2 + off * u
+        v = (torch.rand(2, 500, 8, 32, generator=gen) - 0.5) * 2
+        run(q, k, v)
+    q = (torch.rand(1, 64, 8, 32, generator=gen) - 0.5) * 80               # (iii)
+    k = (torch.rand(1, 200, 8, 32, generator=gen) - 0.5) * 80
+    v = (torch.rand(1, 200, 8, 32, generator=gen) - 0.5) * 2
+    run(q, k, v)
+    big = torch.full((1, 4, 8, 32), 150.0)                                 # (iv) s = 32 * 150^2 / sqrt(32) * log2(e) = 1.8e5
+    with pytest.raises(OetrRangeError):
+        full_attention(big.to(gpu), big.to(gpu), big.to(gpu), variant='f32_split_f16', check_range=True)
+    for (L, S) in [(1, 1), (70, 1), (5, 2), (300, 2), (64, 3)]:            # (v)
+        q = (torch.rand(2, L, 8, 32, generator=gen) - 0.5) * 4
+        k = (torch.rand(2, S, 8, 32, generator=gen) - 0.5) * 4
+        v = (torch.rand(2, S, 8, 32, generator=gen) - 0.5) * 2
+        assert run(q, k, v) <= (1.5e-7 if S == 1 else 1e-6), (L, S)
+
+
 @pytest.mark.parametrize('precision', PRECISIONS)
 @pytest.mark.parametrize('n,g1,g2', [
     (1, (1, 1), (1, 1)),          # single token per image

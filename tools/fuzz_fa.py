@@ -1,5 +1,5 @@
 """Random-shape fuzz of the stand-alone FullAttention kernels vs the fp64 oracle (run on the GPU box):
-python tools/fuzz_fa.py [seed] [cases]"""
+python tools/fuzz_fa.py [seed] [cases] [all: print every case]"""
 import sys, random
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -36,6 +36,6 @@ for case in range(ncase):
             ok = False
     if not ok:
         bad += 1
-    if not ok or case >= ncase - 3:
+    if not ok or case >= ncase - 3 or len(sys.argv) > 3:
         print(('OK  ' if ok else 'BAD ') + line)
 print(f'{bad} bad of {ncase}; worst error / max(torch fp32 drift, 2e-7): ' + ', '.join(f'{k} {v:.1f}x' for k, v in worst.items()))
