@@ -214,22 +214,6 @@ constexpr int FA_VP = FA_KT + 8;     // halves per V^T row (64 key slots + 8): 9
 #define OETR_FA_WAVES 8
 #endif
 constexpr int FA_WAVES = OETR_FA_WAVES;   // waves per workgroup, 32 queries each
-constexpr float FA_SH = 4.0f;             // log2 of the common factor P, O and l carry (k_full_attention_split: m_run)
-// Two floats -> (hi, lo) f16 pairs with an UNSCALED lo plane: hi = RNE f16(x), lo = RNE f16(x - hi) (the difference
-// is exact in f32; v_fma_mix_f32 reads the f16 half directly; v_cvt_pk_f16_f32 for both planes).  x = hi + lo to
-// <= 2^-23 relative wherever lo is a normal f16 number; below that (|lo| < 2^-14, i.e. |x| < ~0.25) lo is a DENORMAL
-// with absolute error <= 2^-25 - v_mfma_f32_32x32x16_f16 honours f16 denormal inputs on gfx950
-// (tools/mfma_denorm_probe.hip, run on the box: profiles/r6_full_attention_steps.txt).
-// A product against such a plane has the scale of the hi . hi product and accumulates into the SAME accumulator.
-// `neg1` = -1.0f held in an SGPR the compiler cannot see through (with the literal hipcc rewrites the fma into
-// v_cvt_f32_f16 + v_sub_f32: two instructions per element instead of one).
-__device__ __forceinline__ void split2u(float a, float b, float neg1, uint32_t& hi, uint32_t& lo, Range& rg) {
-  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
-  hi = __builtin_bit_cast(uint32_t, h);
-  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{__builtin_fmaf((float)h[0], neg1, a),
-                                                                     __builtin_fmaf((float)h[1], neg1, b)}, f16x2));
-  rg.see2(a, b);
-}
 struct FaTile {
   _Float16 Kh[FA_KT * FA_KP], Kl[FA_KT * FA_KP];   // K: hi, UNSCALED lo (split2u)
   _Float16 Vh[HD * FA_VP], Vl[HD * FA_VP];   // [d][key slot]

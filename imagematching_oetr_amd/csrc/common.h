@@ -529,6 +529,23 @@ __device__ __forceinline__ void split8(const f32x4& a0, const f32x4& a1, f32x4& 
   hi = __builtin_bit_cast(f32x4, u32x4{h0, h1, h2, h3});
   lo = __builtin_bit_cast(f32x4, u32x4{l0, l1, l2, l3});
 }
+constexpr float FA_SH = 4.0f;   // all-pairs attention: log2 of the common factor P, O and l carry (attention.hip: m_run)
+// Two floats -> (hi, lo) f16 pairs with an UNSCALED lo plane: hi = RNE f16(x), lo = RNE f16(x - hi) (the difference
+// is exact in f32; v_fma_mix_f32 reads the f16 half directly; v_cvt_pk_f16_f32 for both planes).  x = hi + lo to
+// <= 2^-23 relative wherever lo is a normal f16 number; below that (|lo| < 2^-14, i.e. |x| < ~0.25) lo is a DENORMAL
+// with absolute error <= 2^-25 - v_mfma_f32_32x32x16_f16 honours f16 denormal inputs on gfx950
+// (tools/mfma_denorm_probe.hip, run on the box: profiles/r6_full_attention_steps.txt).  Users: the all-pairs
+// attention (attention.hip: k_full_attention_split; encoder.hip: full_attention_tile).
+// A product against such a plane has the scale of the hi . hi product and accumulates into the SAME accumulator.
+// `neg1` = -1.0f held in an SGPR the compiler cannot see through (with the literal hipcc rewrites the fma into
+// v_cvt_f32_f16 + v_sub_f32: two instructions per element instead of one).
+__device__ __forceinline__ void split2u(float a, float b, float neg1, uint32_t& hi, uint32_t& lo, Range& rg) {
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{__builtin_fmaf((float)h[0], neg1, a),
+                                                                     __builtin_fmaf((float)h[1], neg1, b)}, f16x2));
+  rg.see2(a, b);
+}
 // main += ah.bh ; cross += ah.bl + al.bh   (one k16 step of a split product; ONE cross
 // accumulator: these blocks are 2-4 steps long and short of registers, the dependent
 // cross MFMAs cost a few stalled cycles)

@@ -275,20 +275,34 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
               f32x4{o[4 * g4] * inv, o[4 * g4 + 1] * inv, o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv});
     return;
   } else {
-  // Round 6: the formulation of attention.hip's k_full_attention_split - 1/sqrt(D) log2(e) folded
-  // into Q before its split (scores in log2 units: v_exp_f32 directly), score accumulators started at -m (the
-  // cross fold yields x = s - m), m raised LAZILY (only when some lane's tile maximum exceeds it by more than
-  // 2^FA_LAZY: P <= 256, inside the f16 range of its hi plane; the final 1/l removes the common factor), the
-  // P.V cross accumulator folded once at the end, keys past S masked in a compile-time variant of the LAST tile
-  // only, l a per-lane partial.  ~190 VALU instructions per 32-key tile instead of ~330.
+  // Round 6: the formulation of attention.hip's k_full_attention_split, both passes - 1/sqrt(D) log2(e)
+  // folded into Q before its split (scores in log2 units: v_exp_f32 directly); K's, Q's and P's lo planes UNSCALED
+  // (split2u: the MFMA honours f16 denormals), so the three products of a score go into ONE accumulator - chain from
+  // zero, small products first (the MFMA's aligned sum cuts small addends beside large ones), -m as an MFMA product
+  // (A = ones in two k-slots, B = -m as an f16 pair, m kept to 21 bits) between the two big steps; m raised LAZILY
+  // (only when some lane's tile maximum exceeds it by more than 2^FA_LAZY: P' = 2^FA_SH P <= 2^12, inside the f16 range
+  // of its hi plane; the final 1/l removes the common factor); the P.V accumulator of V's lo plane folded once at the
+  // end; keys past S masked in a compile-time variant of the LAST tile only; l a per-lane partial.
+  // ~125 VALU instructions per 32-key tile (first pass: ~190; round 2: ~330).
+  float neg1 = -1.0f;               // (opaque to the compiler: see split2u)
+  asm volatile("" : "+s"(neg1));
+  auto split8u = [&](const f32x4& a0, const f32x4& a1, f32x4& hi, f32x4& lo, Range& r) {
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    split2u(a0[0], a0[1], neg1, h0, l0, r);
+    split2u(a0[2], a0[3], neg1, h1, l1, r);
+    split2u(a1[0], a1[1], neg1, h2, l2, r);
+    split2u(a1[2], a1[3], neg1, h3, l3, r);
+    hi = __builtin_bit_cast(f32x4, u32x4{h0, h1, h2, h3});
+    lo = __builtin_bit_cast(f32x4, u32x4{l0, l1, l2, l3});
+  };
   f32x4 qh[2], ql[2];
   {
     const float qs = temp * 1.4426950408889634f;
     const float* qp = p.qp + (row_base + min(col, nvalid - 1)) * C + head * HD + 8 * half;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-      split8(*reinterpret_cast<const f32x4*>(qp + 16 * s) * qs, *reinterpret_cast<const f32x4*>(qp + 16 * s + 4) * qs,
-             qh[s], ql[s], rg);
+      split8u(*reinterpret_cast<const f32x4*>(qp + 16 * s) * qs, *reinterpret_cast<const f32x4*>(qp + 16 * s + 4) * qs,
+              qh[s], ql[s], rg);
   }
   auto load = [&](int k0, f32x4 (&kk)[4], f32x4 (&vv)[4]) {
     const float* kr = kb + (size_t)min(k0 + col, S - 1) * C;   // rows past S: clamped, masked below
@@ -302,8 +316,11 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
     }
   };
   constexpr float FA_LAZY = 8.0f;
-  f32x16 o = {0}, oc = {0};   // O^T and its 2^-11-scaled cross part: rows = d (crow(r, half)), col = query
-  float m_run = 0.f, l_run = 0.f;   // m: the reference the score accumulators start from
+  f32x16 o = {0}, oc = {0};   // O^T and the part that meets V's (2^11-scaled) lo plane: rows = d (crow(r, half)), col = query
+  float m_run = -FA_SH, l_run = 0.f;   // m_run = (reference maximum) - FA_SH; -m_run as an f16 pair in k-slots 0, 1:
+  const f32x4 afrag = __builtin_bit_cast(f32x4, u32x4{lane < 32 ? 0x3c003c00u : 0u, 0u, 0u, 0u});
+  f32x4 mfrag = __builtin_bit_cast(f32x4, u32x4{lane < 32 ? 0x00004400u : 0u, 0u, 0u, 0u});   // (4.0h, 0)
+  static_assert(FA_SH == 4.0f, "initial mfrag encodes 4.0 as f16 0x4400");
   f32x4 kk[4], vv[4];
   load(0, kk, vv);
   auto tile = [&](int k0, auto tail_c) {
@@ -311,17 +328,19 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
     f32x4 kh[2], kl[2], vh[2], vl[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      split8(kk[2 * s], kk[2 * s + 1], kh[s], kl[s], rg);
+      split8u(kk[2 * s], kk[2 * s + 1], kh[s], kl[s], rg);
       split8(vv[2 * s], vv[2 * s + 1], vh[s], vl[s], rg);
     }
     if (!tail && k0 + 32 < S) load(k0 + 32, kk, vv);   // next tile's rows under this tile's math
-    f32x16 st, cr = {0};
+    f32x16 st = {0};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = -m_run;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) mma16_split3(kh[s], kl[s], qh[s], ql[s], st, cr);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = fmaf(cr[r], SPLIT_INV, st[r]);
+    for (int s = 0; s < 2; ++s) {
+      st = mma16<GM_SPLIT>(kh[s], ql[s], st);
+      st = mma16<GM_SPLIT>(kl[s], qh[s], st);
+    }
+    st = mma16<GM_SPLIT>(kh[0], qh[0], st);
+    st = mma16<GM_SPLIT>(afrag, mfrag, st);     // - m_run
+    st = mma16<GM_SPLIT>(kh[1], qh[1], st);
     if constexpr (tail) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -332,8 +351,12 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
     for (int r = 0; r < 16; r += 2) mt = __builtin_fmaxf(__builtin_fmaxf(mt, st[r]), st[r + 1]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const bool first = k0 == 0;
-    if (first || __builtin_amdgcn_ballot_w64(mt > FA_LAZY) != 0) {
-      const float adj = first ? mt : fmaxf(mt, 0.f);
+    if (first || __builtin_amdgcn_ballot_w64(mt > FA_SH + FA_LAZY) != 0) {
+      // the new reference, rounded to 21 significant bits and a multiple of 2^-24: exactly the sum of two f16 values
+      const float nm = -(m_run + (first ? mt - FA_SH : fmaxf(mt - FA_SH, 0.f)));
+      float nq = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, nm) + 4u) & ~7u);
+      if (__builtin_fabsf(nm) < 0.0625f) nq = __builtin_rintf(nm * 16777216.0f) * (1.0f / 16777216.0f);
+      const float adj = -nq - m_run;
       if (!first) {
         const float alpha = __builtin_amdgcn_exp2f(-adj);
         l_run *= alpha;
@@ -342,7 +365,11 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] -= adj;
-      m_run += adj;
+      m_run = -nq;
+      const _Float16 mh = (_Float16)nq, ml = (_Float16)(nq - (float)mh);
+      const uint32_t mb = (uint32_t)__builtin_bit_cast(unsigned short, mh) | ((uint32_t)__builtin_bit_cast(unsigned short, ml) << 16);
+      mfrag[0] = __builtin_bit_cast(float, lane < 32 ? mb : 0u);
+      rg.see2(nq, 0.f);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -352,10 +379,12 @@ __device__ __forceinline__ void full_attention_tile(const EncLaunch& p, int n, i
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       f32x4 ph, pl;
-      Range none;   // (P <= 2^FA_LAZY: nothing to guard)
-      split8(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]},
-             f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]}, ph, pl, none);
-      mma16_split3(vh[s], vl[s], ph, pl, o, oc);
+      Range none;   // (P' <= 2^(FA_SH + FA_LAZY): nothing to guard)
+      split8u(f32x4{st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3]},
+              f32x4{st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]}, ph, pl, none);
+      o = mma16<GM_SPLIT>(vh[s], ph, o);
+      oc = mma16<GM_SPLIT>(vl[s], ph, oc);
+      o = mma16<GM_SPLIT>(vh[s], pl, o);
     }
   };
   {

@@ -23,7 +23,8 @@ engines = {}
 for name in names:
     hip_engine._lib = hip_engine.load_library(str(REPO / 'tools' / 'variants' / name / 'liboetr_hip.so'))
     engines[name] = pkg.HotPathEngine(w, device=dev, precision=os.environ.get('PREC', 'f32_split_f16'),
-                                      enc_tile=int(os.environ.get('TILE', 0)) or None)
+                                      enc_tile=int(os.environ.get('TILE', 0)) or None,
+                                      attention=os.environ.get('ATTN', 'linear'))
 if os.environ.get('TAILMODE'):
     for e in engines.values(): e.set_tail_mode(int(os.environ['TAILMODE']))
 if os.environ.get('DECSPLIT'):
