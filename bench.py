@@ -863,7 +863,7 @@ def main():
             gatherer = pg['gatherer']
             if gatherer is not None:
                 # the all-gather of a batch's boxes is ISSUED once the model has settled that batch's deferred
-                # check (BoxGatherer(model=...): k batches later, from this submit - no rank ever receives boxes
+                # check (BoxGatherer(model=...): 2k batches later, from this submit - no rank ever receives boxes
                 # that are corrected afterwards): on that batch's own side stream in the throughput mode (a
                 # blocking collective there - the other side streams carry on), on RCCL's stream under the
                 # next batch's kernels in the serial mode; completed at a later submit / the flush

@@ -175,9 +175,15 @@ class OETR(nn.Module):
         #: encoder workgroups, direct tail form: fewest CU-microseconds per batch).  The trunk stays
         #: on the caller's stream; every side stream waits for its inputs.  Box tensors are complete
         #: - and range-checked, in submission order - after hip_flush() (forward_pairs* call it); at
-        #: most hip_streams batches are in flight.  1 (default): latency mode, everything on the
+        #: most hip_streams x hip_queue_depth batches are in flight.  1 (default): latency mode, everything on the
         #: caller's stream with the automatic rules.
         self.hip_streams = 1
+        #: throughput mode: batches QUEUED per side stream before the host settles the oldest.  1: a stream's next
+        #: batch is submitted once its previous one has published its status word - the stream stands empty for the
+        #: host's reaction and the first launch; 2 (default): the host runs a round ahead, the next batch is already
+        #: queued behind the running one (tools/queue_depth_probe.py: +1.2 % steady state, +2 % in a 20-step region;
+        #: 3 measures like 2).  A batch's check is then settled when 2k more have been submitted (or at hip_flush()).
+        self.hip_queue_depth = 2
         #: the engines' throughput settings without the streams (None: follow hip_streams > 1)
         self.hip_throughput = None
         self._inflight = collections.deque()   # submitted, not yet settled: (boxes, tickets, rerun, stream, event)
@@ -484,6 +490,11 @@ class OETR(nn.Module):
             raise ValueError(f'hip_streams must be in 1..{self.MAX_STREAMS}, got {self.hip_streams}')
         return k
 
+    def _inflight_cap(self, k):
+        """Batches in flight in the throughput mode: ``hip_queue_depth`` per side stream, at most seven in all
+        (two status words per batch at most, sixteen in an engine's ring), never fewer than one per stream."""
+        return max(k, min(k * max(1, int(self.hip_queue_depth)), 7))
+
     def _streams(self, k):
         dev = self.engine().device
         while len(self._side_streams) < k:
@@ -494,8 +505,9 @@ class OETR(nn.Module):
         """``enqueue()`` -> (boxes, tickets): the HIP calls of one batch and the asynchronous reads of
         the status words behind them.  One stream (default): on the caller's stream, after the
         deferred check of the previous batch.  ``hip_streams`` = k > 1: on side stream (batch index
-        mod k), which first waits for the caller's stream (the batch's inputs); at most k batches
-        stay in flight, their checks are settled oldest first.  ``rerun`` None: nothing to check."""
+        mod k), which first waits for the caller's stream (the batch's inputs); at most
+        ``hip_queue_depth`` batches per stream stay in flight (`_inflight_cap`), their checks are settled
+        oldest first.  ``rerun`` None: nothing to check."""
         k = self._stream_count()
         capturing = torch.cuda.is_current_stream_capturing()
         if k == 1 or capturing:
@@ -507,7 +519,7 @@ class OETR(nn.Module):
             if rerun is None:
                 return boxes
             return self._range_checked(boxes, tickets, rerun)
-        self._settle_down_to(k - 1)
+        self._settle_down_to(self._inflight_cap(k) - 1)
         dev = self.engine().device
         side = self._streams(k)[self._submitted % k]
         self._submitted += 1
@@ -528,8 +540,9 @@ class OETR(nn.Module):
     def hip_settled(self, boxes):
         """True once the deferred check of the batch that returned ``boxes`` (either of its two
         tensors) has been settled - its values are final (``parallel.BoxGatherer(model=...)``
-        issues a batch's all-gather only then).  Batches settle oldest first: when k more have
-        been submitted (``hip_streams = k``; two in the latency mode) or at ``hip_flush()``."""
+        issues a batch's all-gather only then).  Batches settle oldest first: when
+        k x ``hip_queue_depth`` more have been submitted (``hip_streams = k``; two in the latency mode)
+        or at ``hip_flush()``."""
         return not any(boxes is e[0][0] or boxes is e[0][1] for e in self._inflight)
 
     def hip_batch_stream(self):

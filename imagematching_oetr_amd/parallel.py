@@ -97,7 +97,7 @@ class BoxGatherer:
 
     * ``model=`` (the throughput recipe): the collective of a batch is ISSUED only once the
       model has settled that batch (``OETR.hip_settled``) - i.e. at the ``submit`` that follows
-      the settling, k batches later under ``hip_streams = k``, or at ``flush``.  Every rank
+      the settling, k x ``hip_queue_depth`` batches later under ``hip_streams = k``, or at ``flush``.  Every rank
       submits and settles in the same order, so the collectives line up whatever tripped
       where; the in-place correction is ordered before the collective (the model orders the
       batch's side stream behind the caller's stream before it enqueues there again).

@@ -453,8 +453,8 @@ def test_training_forward_matches_the_reference_results(gpu, golden_dir):
 def test_throughput_mode_is_the_serial_result_bit_for_bit(gpu):
     """the throughput mode as a product path.  ``model.hip_streams = 3``: consecutive
     batches alternate over three side streams with the engines' throughput settings (64-token encoder
-    workgroups, direct tail), one workspace per stream, at most three batches in flight, range checks
-    settled in submission order.  Twelve batches of three shapes, one of them overflow-injected (its
+    workgroups, direct tail), one workspace per stream, ``hip_queue_depth`` batches queued per stream (one: at
+    most three in flight; two, the default: six), range checks settled in submission order.  Twelve batches of three shapes, one of them overflow-injected (its
     status word trips on a side stream while its neighbours are in flight; it is re-run in exact fp32
     and corrected in place): after hip_flush() every batch equals - bit for bit - what the same
     settings return one batch at a time; the tripped batch equals the exact-fp32 engine."""
@@ -489,12 +489,14 @@ def test_throughput_mode_is_the_serial_result_bit_for_bit(gpu):
     assert torch.equal(serial[4][0], e[0]) and torch.equal(serial[4][1], e[1])
     # three streams
     model.hip_streams, model.hip_throughput = 3, None
+    assert model.hip_queue_depth == 2
     for rnd in range(3):
+        model.hip_queue_depth = 1 if rnd == 1 else 2
         outs, most = [], 0
         for b in batches:
             outs.append(model.boxes_from_features(*b))
             most = max(most, len(model._inflight))
-        assert most == 3, most
+        assert most == (3 if rnd == 1 else 6), most
         assert model.hip_batch_stream() in model._side_streams
         model.hip_flush()
         assert len(model._inflight) == 0
