@@ -417,7 +417,7 @@ class OETR(nn.Module):
         # the deferred checks of earlier batches, oldest first - the same count _submit keeps in flight
         # (latency mode: ONE batch stays behind the one being submitted, the host never waits for the device)
         k = self._stream_count()
-        self._settle_down_to(k - 1 if k > 1 else (1 if self.hip_defer_check else 0))
+        self._settle_down_to(self._inflight_cap(k) - 1 if k > 1 else (1 if self.hip_defer_check else 0))
         h1, w1 = image1.shape[1:3]
         h2, w2 = image2.shape[1:3]
         self.h1, self.w1, self.h2, self.w2 = h1, w1, h2, w2
