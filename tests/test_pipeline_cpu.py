@@ -140,3 +140,19 @@ def test_forward_pairs_sharded_world2_gloo(n):
         assert torch.equal(torch.tensor(b0), e0) and torch.equal(torch.tensor(b1), e1), rank
         done += pairs_run
     assert done == n            # every pair was computed exactly once across the ranks
+
+
+def test_throughput_mode_in_flight_cap():
+    """``hip_queue_depth`` batches queued per side stream: never fewer than one per stream, never more than seven in
+    flight (two status words per batch at most, sixteen in an engine's ring) - host logic, no device."""
+    import imagematching_oetr_amd as pkg
+    model = pkg.OETR(pkg.get_cfg_defaults().OETR).eval()
+    assert model.hip_queue_depth == 2
+    want = {(1, 1): 1, (2, 1): 2, (3, 1): 3, (3, 2): 6, (3, 3): 7, (4, 2): 7, (7, 2): 7, (8, 1): 8, (8, 2): 8, (2, 0): 2}
+    for (k, depth), cap in want.items():
+        model.hip_queue_depth = depth
+        assert model._inflight_cap(k) == cap, (k, depth)
+        assert 2 * model._inflight_cap(k) <= 16
+    model.hip_streams = 9
+    with pytest.raises(ValueError):
+        model._stream_count()
