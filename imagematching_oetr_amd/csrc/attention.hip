@@ -174,8 +174,9 @@ hipError_t launch_full_attention(const float* q, const float* k, const float* v,
 
 // -------------------------------------------------------------- full, split f16
 // The same math on the f16 matrix pipe with the fp32-class operand split of common.h
-// (a = hi + lo/2^11, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation): 12
-// MFMAs of 32 cycles per 32x32 score tile instead of 32 f32 MFMAs of 64 cycles.
+// (a = hi + lo, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation): 13 MFMAs
+// of 32 cycles per 32-key x 32-query tile (6 + 1 for the scores, 6 for P.V) instead of 32
+// f32 MFMAs of 64 cycles.
 //
 // One block = (image, head, 256 queries), 8 waves x 32 queries.  Per 64-key tile the block
 // converts K and V once into split planes in LDS (K row-major, V transposed with the key
