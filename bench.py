@@ -1061,8 +1061,8 @@ def main():
                                + (', attention=full' if args.attention == 'full' else ''),
                    'pairs_per_gpu': n, 'global_pairs': n_total,
                    'streams': n_streams,
-                   'api': 'OETR.boxes_from_features with model.hip_streams = %d (product path; deferred range check '
-                          'per batch, settled by hip_flush inside the timed region)' % n_streams,
+                   'api': 'OETR.boxes_from_features with model.hip_streams = %d (product path; module default of two batches '
+                          'queued per stream; deferred range check per batch, settled by hip_flush inside the timed region)' % n_streams,
                    'world_size': world, 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                    'rank_step_ms_fastest_slowest': ([round(v / args.steps * 1e3, 4) for v in main_res['rank_spread']]
                                                      if main_res.get('rank_spread') else None),
