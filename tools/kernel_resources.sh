@@ -7,7 +7,8 @@ cd "$(dirname "$0")/../imagematching_oetr_amd/csrc"
 echo "# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage of the shipped sources ($(git log -1 --format=%h 2>/dev/null || echo tree)), one line per kernel"
 echo "# VGPRs | AGPRs | scratch B/lane | VGPR spills | SGPR spills | LDS B/block | waves/SIMD | kernel"
 for f in encoder decoder heads attention neck crop reader; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Rpass-analysis=kernel-resource-usage -c $f.hip -o /dev/null 2>&1 |
+  extra=""; case $f in encoder|attention) extra="-fno-slp-vectorize";; esac      # (per-file flags of csrc/Makefile)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -Rpass-analysis=kernel-resource-usage -c $f.hip -o /dev/null 2>&1 |
     python3 -c '
 import re, sys
 cur = {}
